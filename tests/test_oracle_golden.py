@@ -1,0 +1,171 @@
+"""CPU: pin the oracle (oracle/*.py) to the golden fixtures that tools/gen_golden.py
+produced by running the imported reference.  If these fail the oracle is wrong and no
+GPU parity claim means anything."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aggregation_oracle as agg
+from oracle import predict_oracle as pred
+from oracle import uncertainty_oracle as unc
+from oracle.unet3d_oracle import conv3d_k3_naive, unet3d_forward
+from tests.helpers import GOLDEN, formula_sd_torch, load_npz, unpack_masks
+from values_amd.formula import formula_tensor, formula_volume
+
+KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
+
+
+def test_unc_hand_case_closed_form():
+    g = load_npz("unc_kat.npz")
+    r = unc.calculate_uncertainty(g["hand_in"])
+    ln2 = np.log(2.0)
+    np.testing.assert_allclose(r["pred_entropy"], [ln2, 0.5623351, ln2, 0.0], atol=1e-6)
+    np.testing.assert_allclose(r["aleatoric_uncertainty"], [0.0, 0.4990473, ln2, 0.0], atol=1e-6)
+    np.testing.assert_allclose(r["epistemic_uncertainty"], [ln2, 0.0632878, 0.0, 0.0], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["hand", "r3d", "r2d", "ex"])
+def test_unc_matches_reference_outputs(case):
+    g = load_npz("unc_kat.npz")
+    r = unc.calculate_uncertainty(g[f"{case}_in"])
+    for k in KEYS:
+        assert r[k].dtype == np.float32 and g[f"{case}_{k}"].dtype == np.float32
+        # f64 inputs: only the final f32 roundings can differ; f32 inputs (2D layout, entropies ~3):
+        # numpy-vs-torch f32 log differs by 1-2 ulp (2.4e-7 each) and MI is a difference of two such sums
+        atol = 1e-6 if case == "r2d" else 2e-7
+        np.testing.assert_allclose(r[k], g[f"{case}_{k}"], atol=atol, rtol=0)
+        assert not np.isnan(r[k]).any()
+
+
+def test_unc_ssn_swaps_keys():
+    g = load_npz("unc_kat.npz")
+    r = unc.calculate_uncertainty(g["hand_in"], ssn=True)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g[f"hand_ssn_{k}"], atol=2e-7)
+
+
+def test_one_minus_msr():
+    g = load_npz("unc_kat.npz")
+    r = unc.calculate_one_minus_msr(g["msr_in"])
+    np.testing.assert_array_equal(r["pred_entropy"], g["msr_pred_entropy"])
+
+
+def test_conv_naive_vs_torch():
+    x = formula_tensor((1, 3, 5, 6, 7), 1)
+    w = formula_tensor((4, 3, 3, 3, 3), 2)
+    b = formula_tensor((4,), 3)
+    ref = torch.nn.functional.conv3d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=1)
+    np.testing.assert_allclose(conv3d_k3_naive(x, w, b), ref.numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize("size", [16, 32])
+def test_unet3d_oracle_matches_reference(size):
+    g = load_npz(f"unet3d_{size}.npz")
+    sd = formula_sd_torch()
+    x = torch.from_numpy(formula_volume((1, 1, size, size, size)))
+    np.testing.assert_array_equal(x.numpy().astype(np.float32), g["input"])
+    T = g["logits"].shape[0]
+    logits = []
+    for t in range(T):
+        masks = {k: torch.from_numpy(v) for k, v in unpack_masks(g, t).items()}
+        with torch.no_grad():
+            logits.append(unet3d_forward(sd, x, masks=masks)[0].numpy())
+    logits = np.stack(logits)
+    np.testing.assert_allclose(logits, g["logits"], atol=5e-7)  # fixture stores f32
+    sm = unc.softmax(logits, axis=1)
+    r = unc.calculate_uncertainty(sm)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g[k], atol=1e-6)
+    mean, mean_seg, pred_seg = unc.mean_and_argmax(sm)
+    np.testing.assert_allclose(mean, g["mean_softmax"], atol=1e-6)
+    np.testing.assert_array_equal(mean_seg, g["mean_seg"])
+    np.testing.assert_array_equal(pred_seg, g["pred_seg"])
+    with torch.no_grad():
+        nd = unet3d_forward(sd, x, masks=None)[0].numpy()
+    np.testing.assert_allclose(nd, g["logits_nodrop"], atol=5e-7)
+
+
+def test_ensemble_tta_order():
+    g = load_npz("ensemble_tta_16.npz")
+    x = g["input"].astype(np.float64)
+    xn = g["input_noise"].astype(np.float64)
+    sds = [formula_sd_torch(seed_tag=s) for s in range(3)]
+
+    def mk(sd):
+        def f(xi, _):
+            with torch.no_grad():
+                return unet3d_forward(sd, torch.from_numpy(np.ascontiguousarray(xi)), masks=None).numpy()
+        return f
+
+    fw = [mk(sd) for sd in sds]
+    preds = pred.predict_patch(fw, x, tta=True, x_noise=xn)
+    assert preds.shape == g["softmax_pred"].shape == (48, 2, 16, 16, 16)
+    np.testing.assert_allclose(preds, g["softmax_pred"], atol=5e-7)
+    r = unc.calculate_uncertainty(preds)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g[k], atol=1e-6)
+    ens = pred.predict_patch(fw, x, n_pred=1)
+    np.testing.assert_allclose(ens, g["ens_softmax_pred"], atol=5e-7)
+    r = unc.calculate_uncertainty(ens)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g["ens_" + k], atol=1e-6)
+
+
+def test_patch_index_matches_reference():
+    with open(os.path.join(GOLDEN, "patch_index.json")) as f:
+        g = json.load(f)
+    shapes = g.pop("_shapes")
+    for key, crops in g.items():
+        tag, name, patch, overlap = key.split("|")
+        mine = pred.crop_indices(shapes[name], int(patch), float(overlap))
+        assert [[list(c) for c in ci] for ci in mine] == crops, key
+
+
+def test_accumulate_matches_reference_concat_data():
+    g = load_npz("accum_24.npz")
+    size, patch, T = 24, 16, 3
+    crops = pred.crop_indices((size,) * 3, patch, 0.5)
+    fake = np.abs(formula_tensor((len(crops), T, 2, patch, patch, patch), tag=55, scale=1.0))
+    fake = fake / fake.sum(axis=2, keepdims=True)
+    acc = pred.Accumulator(T, (size,) * 3)
+    for pi, crop in enumerate(crops):
+        for t in range(T):
+            acc.add(crop, fake[pi, t], t)
+    np.testing.assert_allclose(acc.softmax_pred, g["softmax_sum"], atol=1e-6)
+    np.testing.assert_array_equal(acc.num_predictions, g["num_predictions"])
+    np.testing.assert_allclose(acc.normalised(), g["normalised"], atol=1e-6)
+    # D10: the reference applies calculate_uncertainty to the UN-normalised sum
+    r = unc.calculate_uncertainty(acc.softmax_pred)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g["unc_" + k], atol=2e-5, rtol=1e-6)
+
+
+def test_aggregations_match_reference():
+    with open(os.path.join(GOLDEN, "agg_kat.json")) as f:
+        g = json.load(f)
+    for size in (24, 64):
+        tag = g[f"vol{size}_tag"]
+        img = np.abs(formula_tensor((size,) * 3, tag=tag, scale=0.7)).astype(np.float32)
+        c = size // 3
+        img[c:c + 6, c + 2:c + 9, c + 1:c + 7] += 0.5
+        r = g[f"vol{size}"]
+        for key, kw in (("patch10", dict(patch_size=10)), ("patch10_mean", dict(patch_size=10, mean=True)),
+                        ("patch_5_7_9", dict(patch_size=[5, 7, 9]))):
+            mine = agg.patch_level_aggregation(img, **kw)
+            # scipy picks fftconvolve here and transforms the float32 map in single precision,
+            # so the reference value itself carries ~1e-7 relative FFT noise
+            assert mine["max_score"] == pytest.approx(r[key]["max_score"], rel=1e-6)
+            assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in r[key]["bounding_box"]]
+        assert agg.image_level_aggregation(img)["max_score"] == pytest.approx(r["image"]["max_score"], rel=1e-12)
+        assert agg.image_level_aggregation(img, mean=True) == pytest.approx(r["image_mean"], rel=1e-12)
+        for thr in (0.3, 0.6, 5.0):
+            for mean in (True, False):
+                mine = agg.threshold_aggregation(img, threshold=thr, mean=mean)
+                assert float(mine["max_score"]) == pytest.approx(r[f"thr_{thr}_{int(mean)}"]["max_score"], rel=1e-6)
+    img2 = np.abs(formula_tensor((40, 56), tag=33, scale=1.0)).astype(np.float32)
+    mine = agg.patch_level_aggregation(img2, patch_size=10)
+    assert mine["max_score"] == pytest.approx(g["img2d"]["patch10"]["max_score"], rel=1e-6)
+    assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in g["img2d"]["patch10"]["bounding_box"]]

@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by IMPORTING the reference (/root/reference) and running
+its own functions/classes.  Runs only in the build container (the reference never
+travels to the GPU box); the outputs are small data fixtures that do.
+
+    python tools/gen_golden.py            # writes tests/golden/
+
+Third-party modules the reference imports at module top but that are not installed
+here (hydra, torchmetrics, batchgenerators, medpy, ...) are replaced by MagicMock --
+none of them is on the arithmetic path captured below.
+"""
+from __future__ import annotations
+
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import tempfile
+from unittest.mock import MagicMock
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MOCK_ROOTS = ("hydra", "omegaconf", "torchmetrics", "batchgenerators", "medpy", "pytorch_lightning",
+              "torchvision", "cv2", "albumentations", "jsbeautifier", "pydantic_settings", "SimpleITK")
+
+
+class _MockFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in MOCK_ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__spec__ = spec
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _MockFinder())
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, "/root/reference/uncertainty_modeling")
+sys.path.insert(0, "/root/reference/evaluation")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import uncertainty_modeling.test_3D as ref_t3  # noqa: E402
+from uncertainty_modeling.data_carrier_3D import DataCarrier3D  # noqa: E402
+from uncertainty_modeling.models.unet3D_module import UNet3D as RefUNet3D  # noqa: E402
+from uncertainty_modeling.toy_datamodule_3D import get_val_test_data_samples as ref_samples_toy  # noqa: E402
+from uncertainty_modeling.lidc_idri_datamodule_3D import get_val_test_data_samples as ref_samples_lidc  # noqa: E402
+import evaluation.uncertainty_aggregation.aggregate_uncertainties as ref_agg  # noqa: E402
+
+from values_amd.formula import formula_tensor, formula_unet3d_state_dict, formula_volume, hash_uniform  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def _t(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------- G1
+def gen_unc_kat():
+    out = {}
+    # hand case: T=2, C=2, 4 voxels
+    p = np.array([[1.0, 0.0], [0.9, 0.1], [0.5, 0.5], [0.0, 1.0]]).T  # (C, 4)
+    q = np.array([[0.0, 1.0], [0.6, 0.4], [0.5, 0.5], [0.0, 1.0]]).T
+    hand = np.stack([p, q])  # (2, 2, 4)
+    out["hand_in"] = hand
+    for ssn in (False, True):
+        r = _t(ref_t3.calculate_uncertainty(torch.from_numpy(hand), ssn=ssn))
+        for k, v in r.items():
+            out[f"hand_{'ssn_' if ssn else ''}{k}"] = v
+    # random (4,2,16,16,16) f64 softmax
+    logits = formula_tensor((4, 2, 16, 16, 16), tag=11, scale=4.0)
+    sm = F.softmax(torch.from_numpy(logits), dim=1)
+    out["r3d_in"] = sm.numpy()
+    for k, v in _t(ref_t3.calculate_uncertainty(sm)).items():
+        out[f"r3d_{k}"] = v
+    # 2D layout: (4, 25, 32, 48) f32 with an all-zero last channel (test_2D.py:208-218)
+    logits = formula_tensor((4, 24, 16, 24), tag=12, scale=3.0).astype(np.float32)
+    sm = F.softmax(torch.from_numpy(logits), dim=1)
+    sm = torch.cat([sm, torch.zeros(4, 1, 16, 24)], dim=1)
+    out["r2d_in"] = sm.numpy()
+    for k, v in _t(ref_t3.calculate_uncertainty(sm)).items():
+        out[f"r2d_{k}"] = v
+    # exact 0/1 probabilities mixed with ordinary ones
+    u = hash_uniform(3 * 512, tag=13).reshape(3, 512)
+    p0 = np.where(u < -0.5, 0.0, np.where(u > 0.5, 1.0, (u + 1) / 2))
+    ex = np.stack([p0, 1 - p0], axis=1).reshape(3, 2, 8, 8, 8)
+    out["ex_in"] = ex
+    for k, v in _t(ref_t3.calculate_uncertainty(torch.from_numpy(ex))).items():
+        out[f"ex_{k}"] = v
+    # one-minus-msr
+    one = sm[0].numpy()
+    out["msr_in"] = one
+    out["msr_pred_entropy"] = _t(ref_t3.calculate_one_minus_msr(torch.from_numpy(one)))["pred_entropy"]
+    np.savez_compressed(os.path.join(OUT, "unc_kat.npz"), **out)
+    print("G1 unc_kat.npz", {k: v.shape for k, v in out.items() if k.endswith("pred_entropy")})
+
+
+# ----------------------------------------------------------------------------- G2
+def _ref_model(seed_tag=0, do_dropout=True, **kw):
+    m = RefUNet3D(num_classes=2, do_dropout=do_dropout, **kw)
+    sd = formula_unet3d_state_dict(seed_tag=seed_tag)
+    m.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    return m.double()  # test_3D.py:425
+
+
+def _hook_dropout_masks(model):
+    """Capture the keep-mask of each of the 17 nn.Dropout modules, by module name."""
+    store = {}
+    handles = []
+
+    def mk(name):
+        def hook(mod, inp, out):
+            x = inp[0]
+            keep = (out != 0) | (x == 0)  # where the input is exactly 0 the mask is irrelevant
+            store[name] = keep.detach().clone()
+        return hook
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Dropout):
+            top = name.split(".")[0]
+            handles.append(mod.register_forward_hook(mk(top)))
+    return store, handles
+
+
+def gen_unet(size, T, fname):
+    torch.manual_seed(123)
+    model = _ref_model(do_dropout=True)
+    x = torch.from_numpy(formula_volume((1, 1, size, size, size)))
+    store, handles = _hook_dropout_masks(model)
+    out = {"input": x.numpy().astype(np.float32)}
+    logits_all, sm_all = [], []
+    for t in range(T):
+        with torch.no_grad():
+            logits = model.forward(x)
+        sm = F.softmax(logits, dim=1)  # test_3D.py:472
+        logits_all.append(logits[0].numpy())
+        sm_all.append(sm[0])
+        for name, m in store.items():
+            out[f"mask_{t}_{name}"] = np.packbits(m.numpy().astype(np.uint8).ravel())
+            out[f"maskshape_{name}"] = np.array(m.shape)
+    for h in handles:
+        h.remove()
+    logits_all = np.stack(logits_all)  # (T, 2, S,S,S) f64
+    sm_stack = torch.stack(sm_all)  # (T, 2, ...)
+    out["logits"] = logits_all.astype(np.float32)
+    # buffer exactly like concat_data: numpy float64 (T,2,...) -> calculate_uncertainty
+    buf = sm_stack.numpy().astype(np.float64)
+    unc = _t(ref_t3.calculate_uncertainty(torch.from_numpy(buf)))
+    for k, v in unc.items():
+        out[k] = v
+    mean = np.mean(buf, axis=0)  # data_carrier_3D.py:254
+    out["mean_softmax"] = mean.astype(np.float32)
+    out["mean_seg"] = np.argmax(mean, axis=0).astype(np.uint8)  # :255
+    out["pred_seg"] = np.argmax(buf, axis=1).astype(np.uint8)  # :282
+    srt = np.sort(mean, axis=0)
+    out["mean_margin"] = (srt[-1] - srt[-2]).astype(np.float32)
+    # dropout disabled: deterministic pass + per-layer checksums for bisecting
+    model_nd = _ref_model(do_dropout=False)
+    acts = {}
+    hs = []
+    for name in ["contr_1_1", "contr_1_2", "contr_2_1", "contr_2_2", "contr_3_1", "contr_3_2", "contr_4_1",
+                 "contr_4_2", "center", "expand_4_1", "expand_4_2", "upscale4", "expand_3_1", "expand_3_2",
+                 "upscale3", "expand_2_1", "expand_2_2", "upscale2", "expand_1_1", "expand_1_2", "final"]:
+        hs.append(getattr(model_nd, name).register_forward_hook(
+            lambda mod, i, o, name=name: acts.__setitem__(name, o.detach().clone())))
+    with torch.no_grad():
+        logits_nd = model_nd.forward(x)
+    for h in hs:
+        h.remove()
+    out["logits_nodrop"] = logits_nd[0].numpy().astype(np.float32)
+    for name, a in acts.items():
+        out[f"chk_{name}"] = np.array([a.mean().item(), a.abs().max().item(), a.std().item()])
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    sz = os.path.getsize(os.path.join(OUT, fname))
+    print(f"G2 {fname}: {sz / 1e6:.2f} MB; logits range {logits_all.min():.3f}..{logits_all.max():.3f};"
+          f" MI max {unc['epistemic_uncertainty'].max():.4f}")
+
+
+# ----------------------------------------------------------------------------- G3
+def gen_ensemble_tta():
+    """3 members, TTA identity + 7 flips on [orig, noisy], through the reference's
+    concat_data, in the loop order of test_3D.py:417-456.  The noisy input is
+    formula data (batchgenerators' GaussianNoiseTransform is third-party and absent)."""
+    size = 16
+    models = [_ref_model(seed_tag=s, do_dropout=False) for s in range(3)]
+    x = torch.from_numpy(formula_volume((1, 1, size, size, size)))
+    noise = torch.from_numpy(formula_tensor((1, 1, size, size, size), tag=99, scale=0.1))
+    x_noise = (x + noise).float().double()
+    dc = DataCarrier3D()
+    batch = {"image_paths": ["img0.npy"], "label_paths": [["l0"]], "crop_idx": [((0, size), (0, size), (0, size))],
+             "org_image_size": [(size, size, size)], "data": x.clone(),
+             "seg": torch.zeros(1, 1, size, size, size, dtype=torch.int32)}
+    flip_dims = [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]
+    n_pred = 2 * len(flip_dims) + 2
+    pred_idx = 0
+    with torch.no_grad():
+        for model in models:
+            for xi in [x, x_noise]:
+                output = model.forward(xi)
+                sm = F.softmax(output, dim=1)
+                dc.concat_data(batch=batch, softmax_pred=sm, n_pred=n_pred * len(models), pred_idx=pred_idx)
+                pred_idx += 1
+                for fd in flip_dims:
+                    output = torch.flip(model.forward(torch.flip(xi, fd)), fd)
+                    sm = F.softmax(output, dim=1)
+                    dc.concat_data(batch=batch, softmax_pred=sm, n_pred=n_pred * len(models), pred_idx=pred_idx)
+                    pred_idx += 1
+    buf = dc.data["img0.npy"]["softmax_pred"]
+    unc = _t(ref_t3.calculate_uncertainty(torch.from_numpy(buf)))
+    out = {"input": x.numpy().astype(np.float32), "input_noise": x_noise.numpy().astype(np.float32),
+           "softmax_pred": buf.astype(np.float32), "num_predictions": dc.data["img0.npy"]["num_predictions"]}
+    out.update(unc)
+    mean = np.mean(buf, axis=0)
+    out["mean_seg"] = np.argmax(mean, axis=0).astype(np.uint8)
+    srt = np.sort(mean, axis=0)
+    out["mean_margin"] = (srt[-1] - srt[-2]).astype(np.float32)
+    # plain 3-member ensemble, n_pred=1 (config C3 ordering)
+    dc2 = DataCarrier3D()
+    with torch.no_grad():
+        for i, model in enumerate(models):
+            sm = F.softmax(model.forward(x), dim=1)
+            dc2.concat_data(batch=batch, softmax_pred=sm, n_pred=len(models), pred_idx=i)
+    buf2 = dc2.data["img0.npy"]["softmax_pred"]
+    out["ens_softmax_pred"] = buf2.astype(np.float32)
+    for k, v in _t(ref_t3.calculate_uncertainty(torch.from_numpy(buf2))).items():
+        out["ens_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "ensemble_tta_16.npz"), **out)
+    print("G3 ensemble_tta_16.npz", buf.shape, os.path.getsize(os.path.join(OUT, "ensemble_tta_16.npz")) / 1e6, "MB")
+
+
+# ----------------------------------------------------------------------------- G4
+def gen_patch_index():
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for sub in ("imagesTs", "labelsTs", "images", "labels"):
+            os.makedirs(os.path.join(td, sub))
+        cases = {"a64": (64, 64, 64), "b128": (128, 128, 128), "c96": (96, 64, 80)}
+        for name, shp in cases.items():
+            np.save(os.path.join(td, "imagesTs", name + ".npy"), np.zeros(shp, dtype=np.float32))
+            np.save(os.path.join(td, "images", name + ".npy"), np.zeros(shp, dtype=np.float32))
+        for patch, overlap in [(64, 1), (64, 0.5), (32, 0.5), (32, 1)]:
+            for fn, tag in ((ref_samples_toy, "toy"), (ref_samples_lidc, "lidc")):
+                samples = fn(base_dir=td, test=True, patch_size=patch, patch_overlap=overlap,
+                             subject_ids=[n + ".npy" for n in cases])
+                for s in samples:
+                    key = f"{tag}|{os.path.basename(s['image_path']).split('.')[0]}|{patch}|{overlap}"
+                    res.setdefault(key, []).append([list(c) for c in s["crop_idx"]])
+    res["_shapes"] = {k: list(v) for k, v in cases.items()}
+    with open(os.path.join(OUT, "patch_index.json"), "w") as f:
+        json.dump(res, f)
+    print("G4 patch_index.json", {k: len(v) for k, v in res.items() if k.startswith("toy")})
+
+    # accumulate: 32^3 image, patch 16, overlap 0.5, through the reference concat_data
+    size, patch = 24, 16
+    from oracle.predict_oracle import crop_indices  # only for the LIST; pinned above against the reference
+    crops = crop_indices((size, size, size), patch, 0.5)
+    dc = DataCarrier3D()
+    T = 3
+    fake = formula_tensor((len(crops), T, 2, patch, patch, patch), tag=55, scale=1.0)
+    fake = np.abs(fake)
+    fake = fake / fake.sum(axis=2, keepdims=True)
+    for pi, crop in enumerate(crops):
+        batch = {"image_paths": ["img.npy"], "label_paths": [["l0"]], "crop_idx": [crop],
+                 "org_image_size": [(size, size, size)], "data": torch.zeros(1, 1, patch, patch, patch),
+                 "seg": torch.zeros(1, 1, patch, patch, patch, dtype=torch.int32)}
+        for t in range(T):
+            dc.concat_data(batch=batch, softmax_pred=torch.from_numpy(fake[pi, t][None]), n_pred=T, pred_idx=t)
+    v = dc.data["img.npy"]
+    unc = _t(ref_t3.calculate_uncertainty(torch.from_numpy(v["softmax_pred"])))  # on the UN-normalised sum (D10)
+    norm = v["softmax_pred"] / np.clip(v["num_predictions"], 1, None)
+    out = {"softmax_sum": v["softmax_pred"].astype(np.float32), "num_predictions": v["num_predictions"],
+           "normalised": norm.astype(np.float32)}
+    out.update({"unc_" + k: a for k, a in unc.items()})
+    np.savez_compressed(os.path.join(OUT, "accum_24.npz"), **out)
+    print("G4 accum_24.npz", len(crops), "patches; count max", v["num_predictions"].max())
+
+
+# ----------------------------------------------------------------------------- G6
+def gen_agg():
+    res = {}
+    for size, tag in ((24, 31), (64, 32)):
+        img = np.abs(formula_tensor((size, size, size), tag=tag, scale=0.7)).astype(np.float32)
+        # add a hot blob so the max patch is unique
+        c = size // 3
+        img[c:c + 6, c + 2:c + 9, c + 1:c + 7] += 0.5
+        key = f"vol{size}"
+        r = {}
+        r["patch10"] = ref_agg.patch_level_aggregation(img, patch_size=10)
+        r["patch10_mean"] = ref_agg.patch_level_aggregation(img, patch_size=10, mean=True)
+        r["patch_5_7_9"] = ref_agg.patch_level_aggregation(img, patch_size=[5, 7, 9])
+        r["image"] = ref_agg.image_level_aggregation(img)
+        r["image_mean"] = ref_agg.image_level_aggregation(img, mean=True)
+        for thr in (0.3, 0.6, 5.0):
+            for mean in (True, False):
+                t = ref_agg.threshold_aggregation(img, threshold=thr, mean=mean)
+                r[f"thr_{thr}_{int(mean)}"] = {k: float(v) for k, v in t.items()}
+        res[key] = r
+        res[key + "_tag"] = tag
+    # 2D map too (the aggregation is dimension-generic, patch_size int -> per-dim list)
+    img2 = np.abs(formula_tensor((40, 56), tag=33, scale=1.0)).astype(np.float32)
+    res["img2d"] = {"patch10": ref_agg.patch_level_aggregation(img2, patch_size=10),
+                    "image": ref_agg.image_level_aggregation(img2)}
+    with open(os.path.join(OUT, "agg_kat.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("G6 agg_kat.json", res["vol24"]["patch10"])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg"]
+    if "unc" in which:
+        gen_unc_kat()
+    if "unet16" in which:
+        gen_unet(16, 4, "unet3d_16.npz")
+    if "unet32" in which:
+        gen_unet(32, 4, "unet3d_32.npz")
+    if "tta" in which:
+        gen_ensemble_tta()
+    if "patch" in which:
+        gen_patch_index()
+    if "agg" in which:
+        gen_agg()

@@ -1,0 +1,202 @@
+/*
+ * values_amd.h -- C ABI of libvalues_amd.so: the MI355X (gfx950) hot path of ValUES'
+ * multi-pass segmentation-uncertainty inference.
+ *
+ * The reference (IML-DKFZ/values) is pure Python on PyTorch and has no FFI of its own;
+ * every entry point below names the reference call site whose device work it replaces.
+ * The Python mirror of the reference's interface (the values_amd Python package) binds these with
+ * ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = VX_E_* argument error, >0 = hipError_t;
+ *     vx_last_error_string() describes the last failure on the calling thread.
+ *   - no allocation inside: the caller owns every buffer (device pointers) and passes
+ *     an explicit workspace; nothing is freed by the library.
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*), nothing
+ *     synchronises, so all entry points are capturable into a hipGraph.
+ *   - activations inside the library are channels-last ("NDHWC") float32 with an explicit
+ *     per-voxel channel pitch; tensors crossing the boundary in the reference's NCDHW
+ *     layout are marked so.
+ */
+#ifndef VALUES_AMD_H
+#define VALUES_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vx_stream_t; /* hipStream_t */
+
+enum {
+  VX_OK = 0,
+  VX_E_NULL = -1,      /* required pointer is null */
+  VX_E_SHAPE = -2,     /* unsupported / inconsistent shape */
+  VX_E_DTYPE = -3,     /* unsupported dtype / layout / mode enum */
+  VX_E_WORKSPACE = -4, /* workspace too small */
+  VX_E_ALIGN = -5      /* pointer or pitch not 16-byte aligned */
+};
+
+enum { VX_F32 = 0, VX_F64 = 1 };
+enum { VX_ACT_NONE = 0, VX_ACT_LRELU = 1 /* slope 0.01 */, VX_ACT_RELU = 2 };
+/* dropout (torch.nn.Dropout in training mode, p = 0.5, scale 2):
+ *   NONE : identity
+ *   HASH : counter-based bit generator keyed by (seed, layer id, sample, element)
+ *   MASK : caller-supplied keep-mask, uint8 0/1, channels-last, same geometry as the
+ *          tensor it is applied to (parity tests inject the reference's masks) */
+enum { VX_DROP_NONE = 0, VX_DROP_HASH = 1, VX_DROP_MASK = 2 };
+
+int vx_version(void);
+const char* vx_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------
+ * K10/K11/K12: fused softmax -> {mean prob, predictive entropy, expected entropy,
+ * mutual information, argmax} reduction over T predictions, one pass over the input.
+ * Replaces calculate_uncertainty (uncertainty_modeling/test_3D.py:486-518), the mean /
+ * argmax of DataCarrier3D.save_data (data_carrier_3D.py:253-255, 281-283) and, with
+ * from_logits, the F.softmax of test_3D.py:435,448,472.
+ *   x        : [B][T][C][nvox] (planar, the reference's (T,C,*spatial) per volume), f32 or f64
+ *   from_logits: 0 = x holds probabilities, 1 = x holds logits (softmax over C fused; C <= 8)
+ *   outputs  : per volume b: mean_prob [B][C][nvox] (nullable), pred_entropy / exp_entropy /
+ *              mutual_info [B][nvox] f32, argmax [B][nvox] u8 (nullable, first maximal class
+ *              like np.argmax), sample_argmax [B][T][nvox] u8 (nullable)
+ * NaN products (0 * log 0) are skipped exactly like test_3D.py:493-494, 503-504.
+ */
+int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
+                  float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
+                  uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream);
+
+/* calculate_one_minus_msr (test_3D.py:521-525) / ExperimentDataloader.get_max_softmax_pred
+ * (evaluation/experiment_dataloader.py:38-49): out[v] = 1 - max_c x[c][v]; x [C][nvox]. */
+int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, void* out, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Weight packing (one-off, at checkpoint load: load_models_from_checkpoint, test_3D.py:222-247).
+ *   conv3d  : torch (Cout, Cin, 3,3,3) f32 -> MFMA fragment order; returns floats needed via *_size
+ *   convT   : torch (Cin, Cout, 2,2,2) f32 -> [dz][dy][ci][dx][co]
+ */
+int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout);
+int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin, int Cout, vx_stream_t stream);
+int64_t vx_convT_k2s2_packed_floats(int Cin, int Cout);
+int vx_pack_convT_k2s2(const float* w_torch, float* w_packed, int Cin, int Cout, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * K1 (+K3,K4 epilogue, K2 statistics): 3x3x3 convolution, padding 1, channels-last.
+ * Replaces nn.Conv3d(k=3,p=1) of the contract / expand / center blocks
+ * (models/unet3D_module.py:233, 264, 99-111) with its trailing LeakyReLU / ReLU / Dropout
+ * fused when the block has no norm, and with the InstanceNorm statistics (per sample and
+ * channel sum / sum of squares per workgroup tile, deterministic, no atomics) emitted
+ * for vx_instnorm_finalize when it has.
+ */
+typedef struct vx_conv3d_args {
+  const float* in;      /* [N][D][H][W][in_pitch], channels [0, Cin) used; Cin % 8 == 0 */
+  const float* w_packed;
+  const float* bias;    /* [Cout] */
+  float* out;           /* [N][D][H][W][out_pitch], written at channel offset out_coff */
+  int32_t in_pitch, out_pitch, out_coff;
+  int32_t N, D, H, W, Cin, Cout; /* Cout % 8 == 0 */
+  int32_t act;          /* VX_ACT_* applied after bias */
+  int32_t drop_mode;    /* VX_DROP_* applied after act */
+  uint32_t drop_seed, drop_layer;
+  const uint8_t* drop_mask; /* [N][D][H][W][Cout] when VX_DROP_MASK */
+  float* stats_partial; /* nullable: [N][ntiles][Cout][2] (sum, sumsq of out before act) */
+} vx_conv3d_args;
+int vx_conv3d_k3_tiles(int D, int H, int W);  /* ntiles per sample for stats_partial sizing */
+int vx_conv3d_k3(const vx_conv3d_args* a, vx_stream_t stream);
+
+/* First layer, Cin == 1 (contr_1_1): input is the reference's (V,1,D,H,W) volume batch.
+ * Sample n reads volume src[n] (nullable: n / repeat) with flip code flip[n] (nullable: 0;
+ * bit0 = flip D, bit1 = flip H, bit2 = flip W -- torch.flip dims 2,3,4 of test_3D.py:430,445). */
+int vx_conv3d_k3_c1_tiles(int D, int H, int W); /* ntiles per sample of this kernel's stats_partial */
+int vx_conv3d_k3_c1(const float* in, const float* w_torch /* (Cout,1,3,3,3) */, const float* bias, float* out,
+                    int out_pitch, int N, int D, int H, int W, int Cout, int repeat, const int32_t* src,
+                    const int32_t* flip, float* stats_partial, vx_stream_t stream);
+
+/* K2: reduce stats_partial -> mean[N][C], rstd[N][C] (biased variance, eps 1e-5:
+ * nn.InstanceNorm3d defaults, unet3D_module.py:234). */
+int vx_instnorm_finalize(const float* stats_partial, int N, int ntiles, int C, int64_t nvox, float eps,
+                         float* mean, float* rstd, vx_stream_t stream);
+
+/* K2+K3+K4(+K5,K7): y = Dropout(LeakyReLU((x - mean) * rstd)) written to `out` (any pitch /
+ * channel offset: the skip half of the decoder's concat buffer, unet3D_module.py:332-356)
+ * and, if pool_out != NULL, MaxPool3d(2,2) of y (unet3D_module.py:50, 314-323). */
+typedef struct vx_norm_args {
+  const float* x; int32_t x_pitch;
+  const float* mean; const float* rstd; /* nullable both: no normalisation */
+  float* out; int32_t out_pitch, out_coff;
+  float* pool_out; int32_t pool_pitch;
+  int32_t N, D, H, W, C;
+  int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask;
+} vx_norm_args;
+int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
+
+/* K6: ConvTranspose3d(k=2, s=2) (+ReLU+Dropout for center.4), unet3D_module.py:113-120, 157-190;
+ * writes channels [out_coff, out_coff+Cout) of the concat buffer (K7: torch.cat disappears). */
+typedef struct vx_convT_args {
+  const float* in; int32_t in_pitch;
+  const float* w_packed; const float* bias;
+  float* out; int32_t out_pitch, out_coff;
+  int32_t N, D, H, W, Cin, Cout; /* input dims; output is 2D x 2H x 2W */
+  int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* mask [N][2D][2H][2W][Cout] */
+} vx_convT_args;
+int vx_convT_k2s2(const vx_convT_args* a, vx_stream_t stream);
+
+/* K8 (+K13): final 1x1x1 conv (unet3D_module.py:199, 365) -> logits in the reference's NCDHW
+ * layout, sample n written to slot dst[n] (nullable: n) of out [slots][C][D][H][W], un-flipped by
+ * flip[n] (test_3D.py:445-447). w: torch (C, F, 1,1,1). */
+int vx_conv1x1_ncdhw(const float* in, int in_pitch, const float* w, const float* bias, float* out, int N, int D,
+                     int H, int W, int F, int C, const int32_t* dst, const int32_t* flip, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Whole-network launch: UNet3D.forward (unet3D_module.py:296-373) for N samples.
+ */
+typedef struct vx_unet3d_weights {
+  /* packed 3x3x3 convs in execution order:
+   * contr_1_1(torch layout, Cin==1) contr_1_2 contr_2_1 contr_2_2 contr_3_1 contr_3_2 contr_4_1 contr_4_2
+   * center.0 center.2 expand_4_1 expand_4_2 expand_3_1 expand_3_2 expand_2_1 expand_2_2 expand_1_1 expand_1_2 */
+  const float* conv_w[18];
+  const float* conv_b[18];
+  /* packed transposed convs: center.4 upscale4 upscale3 upscale2 */
+  const float* up_w[4];
+  const float* up_b[4];
+  const float* final_w; /* torch (C, F) */
+  const float* final_b;
+  int32_t F;            /* initial_filter_size */
+  int32_t num_classes;
+} vx_unet3d_weights;
+
+typedef struct vx_unet3d_run {
+  const float* x;        /* (V,1,D,H,W) */
+  int32_t N, D, H, W;    /* N samples; D,H,W multiples of 16 */
+  int32_t repeat;        /* sample n reads volume n / repeat when src == NULL */
+  const int32_t* src;    /* nullable [N] */
+  const int32_t* flip;   /* nullable [N] */
+  const int32_t* dst;    /* nullable [N]: logits slot */
+  int32_t drop_mode;     /* VX_DROP_*; HASH uses seed; MASK uses masks[17] */
+  uint32_t seed;
+  const uint8_t* masks[17]; /* channels-last keep-masks in DROPOUT order (oracle/unet3d_oracle.py) */
+  float* logits;         /* [slots][C][D][H][W] */
+  void* workspace; size_t workspace_bytes;
+} vx_unet3d_run;
+
+size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F);
+int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
+ *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and
+ *                first (C-order) index with isclose(value, max); result[0]=max, idx[0..2]
+ *   vx_sum_thr : image_level_aggregation (:34-37) + threshold_aggregation (:61-67):
+ *                sums[0]=sum(map), sums[1]=sum(map[map>=thr]), sums[2]=count(map>=thr)
+ * map is f32 [D][H][W] (2D maps: D = 1, pd = 1). workspace: 2 * D*H*W doubles.
+ */
+int vx_box_max(const float* map, int D, int H, int W, int pd, int ph, int pw, double* result, int32_t* idx,
+               void* workspace, size_t workspace_bytes, vx_stream_t stream);
+int vx_sum_thr(const float* map, int64_t n, float thr, double* sums, vx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALUES_AMD_H */

@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library loads and exports every symbol include/values_amd.h declares; the ctypes
+struct mirrors have the C sizes; host-side logic that needs no GPU."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from tests.helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "values_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from values_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vx_[a-zA-Z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from values_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.vx_version() >= 100
+
+
+def test_struct_sizes_match_c(lib):
+    from values_amd import _lib
+    code = r'''
+#include <stdio.h>
+#include "values_amd.h"
+int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx_norm_args), sizeof(vx_convT_args),
+ sizeof(vx_unet3d_weights), sizeof(vx_unet3d_run)); return 0;}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "s.c")
+        open(src, "w").write(code)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])  # header is plain C
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(c) for c in (_lib.ConvArgs, _lib.NormArgs, _lib.ConvTArgs, _lib.UNet3DWeights, _lib.UNet3DRun)]
+    assert mine == sizes
+
+
+def test_host_only_queries(lib):
+    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 16 * 16 * 27  # Cout padded to one 16-wide MFMA tile
+    assert lib.vx_conv3d_k3_packed_floats(32, 32) == 32 * 32 * 27
+    assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1
+    assert lib.vx_convT_k2s2_packed_floats(16, 8) == 16 * 8 * 8
+    assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
+    assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
+    assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from values_amd import UNet3D, _lib, calculate_uncertainty
+    with pytest.raises(_lib.VxError):
+        calculate_uncertainty(torch.zeros(2, 2, 4))
+    with pytest.raises(_lib.VxError):
+        UNet3D(num_classes=2)(torch.zeros(1, 1, 16, 16, 16))
+
+
+def test_crop_indices_match_reference_fixture():
+    import json
+    from values_amd import crop_indices
+    with open(os.path.join(GOLDEN, "patch_index.json")) as f:
+        g = json.load(f)
+    shapes = g.pop("_shapes")
+    for key, crops in g.items():
+        _, name, patch, overlap = key.split("|")
+        mine = crop_indices(shapes[name], int(patch), float(overlap))
+        assert [[list(c) for c in ci] for ci in mine] == crops, key
+
+
+def test_tta_flip_codes():
+    from values_amd.predict import FLIP_DIMS, TTA_FLIP_CODES
+    assert TTA_FLIP_CODES == [0, 1, 2, 4, 3, 5, 6, 7]
+    assert FLIP_DIMS == [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under values_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "values_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, fn

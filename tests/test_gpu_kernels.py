@@ -1,0 +1,373 @@
+"""GPU: every kernel of libvalues_amd.so, called through the C ABI, against the oracle
+(oracle/*.py: float64 CPU restatement of the reference) on seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import load_npz
+from values_amd import _lib
+from values_amd.formula import formula_tensor
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def cl(x):  # NCDHW -> channels-last contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=False, in_pitch=None, out_pitch=None,
+             out_coff=0):
+    """x (N,Cin,D,H,W) f32 cpu, w torch layout -> (out NCDHW cpu, stats or None)"""
+    lib = _lib.load()
+    N, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    xd = cl(x.float()).to(dev())
+    if in_pitch and in_pitch > Cin:
+        pad = torch.full((N, D, H, W, in_pitch - Cin), 7.0, device=dev())  # garbage channels must be ignored
+        xd = torch.cat([xd, pad], -1).contiguous()
+    in_pitch = in_pitch or Cin
+    out_pitch = out_pitch or Cout
+    wd = w.float().contiguous().to(dev())
+    bd = b.float().contiguous().to(dev())
+    n = lib.vx_conv3d_k3_packed_floats(Cin, Cout)
+    wp = torch.empty(n, dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wd), _lib.ptr(wp), Cin, Cout, _lib.stream_ptr()), "pack")
+    out = torch.full((N, D, H, W, out_pitch), -77.0, dtype=torch.float32, device=dev())
+    a = _lib.ConvArgs()
+    a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = in_pitch, out_pitch, out_coff
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, D, H, W, Cin, Cout
+    a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop_mode, seed, layer
+    md = None
+    if mask is not None:
+        md = cl(mask).to(torch.uint8).to(dev())
+        a.drop_mask = md.data_ptr()
+    st = None
+    if stats:
+        nt = lib.vx_conv3d_k3_tiles(D, H, W)
+        st = torch.zeros((N, nt, Cout, 2), dtype=torch.float32, device=dev())
+        a.stats_partial = st.data_ptr()
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    res = ncdhw(out[..., out_coff:out_coff + Cout]).cpu()
+    untouched = out[..., :out_coff].cpu(), out[..., out_coff + Cout:].cpu()
+    return res, (st.cpu() if st is not None else None), untouched
+
+
+@pytest.mark.parametrize("cin,cout,shape", [
+    (8, 8, (1, 16, 16, 16)), (16, 8, (2, 8, 16, 32)), (8, 16, (1, 16, 16, 16)), (16, 16, (1, 8, 8, 16)),
+    (16, 32, (1, 8, 8, 8)), (32, 32, (2, 8, 8, 8)), (32, 64, (1, 4, 4, 4)), (64, 64, (1, 4, 4, 4)),
+    (64, 128, (2, 2, 2, 2)), (128, 128, (1, 2, 2, 2)), (128, 64, (1, 4, 4, 4)), (64, 32, (1, 8, 8, 8)),
+    (24, 8, (1, 4, 8, 16)),   # Cin multiple of 8 only -> CB=8 path
+    (8, 8, (1, 6, 10, 20)),   # ragged: not a multiple of the workgroup tile
+    (16, 16, (1, 3, 5, 9)),   # ragged small
+])
+def test_conv3d_k3_matches_oracle(cin, cout, shape):
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 101))
+    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 102, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((cout,), 103, scale=0.2))
+    ref = F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1)
+    got, st, _ = run_conv(x, wt, b, stats=True)
+    err = (got.double() - ref).abs().max().item()
+    assert err < 2e-5, err
+    # statistics partials sum to the per-(n,c) sum / sumsq of the output
+    s = st.double().sum(1)
+    np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_conv3d_k3_epilogue_act_mask_pitch():
+    x = torch.from_numpy(formula_tensor((1, 16, 8, 8, 16), 111))
+    wt = torch.from_numpy(formula_tensor((8, 16, 3, 3, 3), 112, scale=0.05))
+    b = torch.from_numpy(formula_tensor((8,), 113, scale=0.2))
+    mask = torch.from_numpy(formula_tensor((1, 8, 8, 8, 16), 114)) > 0
+    ref = F.leaky_relu(F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1), 0.01)
+    ref = ref * mask * 2.0
+    got, _, (lo, hi) = run_conv(x, wt, b, act=_lib.VX_ACT_LRELU, drop_mode=_lib.VX_DROP_MASK, mask=mask, in_pitch=24,
+                                out_pitch=24, out_coff=8)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    assert (lo == -77.0).all() and (hi == -77.0).all()  # neighbours in the concat buffer untouched
+    ref_relu = F.relu(F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1))
+    got, _, _ = run_conv(x, wt, b, act=_lib.VX_ACT_RELU)
+    assert (got.double() - ref_relu).abs().max().item() < 2e-5
+
+
+def test_conv3d_k3_hash_dropout_statistics():
+    x = torch.from_numpy(formula_tensor((2, 8, 16, 16, 16), 121))
+    wt = torch.from_numpy(formula_tensor((8, 8, 3, 3, 3), 122, scale=0.07))
+    b = torch.ones(8, dtype=torch.float64) * 3.0  # keep outputs away from 0
+    base, _, _ = run_conv(x, wt, b)
+    d1, _, _ = run_conv(x, wt, b, drop_mode=_lib.VX_DROP_HASH, seed=5, layer=3)
+    d1b, _, _ = run_conv(x, wt, b, drop_mode=_lib.VX_DROP_HASH, seed=5, layer=3)
+    d2, _, _ = run_conv(x, wt, b, drop_mode=_lib.VX_DROP_HASH, seed=6, layer=3)
+    d3, _, _ = run_conv(x, wt, b, drop_mode=_lib.VX_DROP_HASH, seed=5, layer=4)
+    assert torch.equal(d1, d1b)  # deterministic
+    keep = d1 != 0
+    assert torch.equal(d1[keep], (2 * base)[keep])  # kept values are exactly 2x
+    rate = keep.float().mean().item()
+    assert abs(rate - 0.5) < 0.01, rate
+    # per-channel and per-sample rates, and independence across seed / layer / sample
+    assert (keep.float().mean((0, 2, 3, 4)) - 0.5).abs().max() < 0.02
+    for other in (d2, d3):
+        agree = ((other != 0) == keep).float().mean().item()
+        assert abs(agree - 0.5) < 0.01, agree
+    agree = (keep[0] == keep[1]).float().mean().item()
+    assert abs(agree - 0.5) < 0.01, agree
+    # neighbouring voxels uncorrelated
+    a, bb = keep[..., :-1].float() - 0.5, keep[..., 1:].float() - 0.5
+    assert abs((a * bb).mean().item()) < 0.005
+
+
+@pytest.mark.parametrize("cout,shape,flipcode", [(8, (2, 16, 16, 32), 0), (8, (1, 6, 10, 40), 0), (16, (1, 4, 8, 16), 5),
+                                                 (8, (3, 8, 8, 8), 7), (8, (1, 16, 16, 16), 2)])
+def test_conv3d_c1_matches_oracle(cout, shape, flipcode):
+    lib = _lib.load()
+    v, d, h, w = shape
+    repeat = 2
+    x = torch.from_numpy(formula_tensor((v, 1, d, h, w), 131))
+    wt = torch.from_numpy(formula_tensor((cout, 1, 3, 3, 3), 132, scale=0.2))
+    b = torch.from_numpy(formula_tensor((cout,), 133, scale=0.2))
+    N = v * repeat
+    xd, wd, bd = x.float().to(dev()), wt.float().to(dev()), b.float().to(dev())
+    out = torch.empty((N, d, h, w, cout), dtype=torch.float32, device=dev())
+    nt = lib.vx_conv3d_k3_c1_tiles(d, h, w)
+    st = torch.zeros((N, nt, cout, 2), dtype=torch.float32, device=dev())
+    flips = torch.tensor([flipcode if n % 2 else 0 for n in range(N)], dtype=torch.int32, device=dev())
+    _lib.check(lib.vx_conv3d_k3_c1(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), cout, N, d, h, w, cout, repeat,
+                                   None, _lib.ptr(flips), _lib.ptr(st), _lib.stream_ptr()), "c1")
+    torch.cuda.synchronize()
+    got = ncdhw(out).cpu().double()
+    for n in range(N):
+        xi = x[n // repeat:n // repeat + 1].float().double()
+        code = flipcode if n % 2 else 0
+        dims = [2 + k for k in range(3) if code >> k & 1]
+        if dims:
+            xi = torch.flip(xi, dims)
+        ref = F.conv3d(xi, wt.float().double(), b.float().double(), padding=1)
+        assert (got[n:n + 1] - ref).abs().max().item() < 1e-5
+        np.testing.assert_allclose(st[n].double().sum(0)[:, 0].cpu().numpy(), ref.sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(16, 8, (2, 4, 8, 16)), (128, 64, (1, 2, 2, 2)), (64, 32, (1, 4, 4, 4)),
+                                            (32, 16, (1, 3, 5, 7))])
+def test_convT_matches_oracle(cin, cout, shape):
+    lib = _lib.load()
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 141))
+    wt = torch.from_numpy(formula_tensor((cin, cout, 2, 2, 2), 142, scale=(1.0 / cin) ** 0.5))
+    b = torch.from_numpy(formula_tensor((cout,), 143, scale=0.2))
+    mask = torch.from_numpy(formula_tensor((n, cout, 2 * d, 2 * h, 2 * w), 144)) > 0
+    xd, wd, bd = cl(x.float()).to(dev()), wt.float().contiguous().to(dev()), b.float().to(dev())
+    wp = torch.empty(lib.vx_convT_k2s2_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(wd), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "packT")
+    for act, use_mask in ((0, False), (_lib.VX_ACT_RELU, True)):
+        pitch = 2 * cout
+        out = torch.full((n, 2 * d, 2 * h, 2 * w, pitch), -77.0, dtype=torch.float32, device=dev())
+        a = _lib.ConvTArgs()
+        a.in_ = xd.data_ptr(); a.in_pitch = cin; a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr()
+        a.out = out.data_ptr(); a.out_pitch = pitch; a.out_coff = 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+        a.act = act
+        md = cl(mask).to(torch.uint8).to(dev())
+        if use_mask:
+            a.drop_mode = _lib.VX_DROP_MASK
+            a.drop_mask = md.data_ptr()
+        _lib.check(lib.vx_convT_k2s2(C.byref(a), _lib.stream_ptr()), "convT")
+        torch.cuda.synchronize()
+        ref = F.conv_transpose3d(x.float().double(), wt.float().double(), b.float().double(), stride=2)
+        if act:
+            ref = F.relu(ref)
+        if use_mask:
+            ref = ref * mask * 2.0
+        got = ncdhw(out[..., :cout]).cpu().double()
+        assert (got - ref).abs().max().item() < 1e-5
+        assert (out[..., cout:] == -77.0).all()
+
+
+@pytest.mark.parametrize("c,shape,pool", [(8, (2, 8, 8, 16), True), (16, (1, 4, 6, 10), True), (8, (1, 3, 5, 7), False),
+                                          (64, (2, 2, 2, 2), True)])
+def test_instnorm_lrelu_drop_pool_matches_oracle(c, shape, pool):
+    lib = _lib.load()
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, c, d, h, w), 151, scale=3.0)) + 1.5
+    mask = torch.from_numpy(formula_tensor((n, c, d, h, w), 152)) > 0
+    xf = x.float()
+    # statistics through the real finalize kernel: one "tile" per sample holding exact sums
+    part = torch.stack([xf.double().sum((2, 3, 4)), (xf.double() ** 2).sum((2, 3, 4))], -1).float()  # (n,c,2)
+    part = part.reshape(n, 1, c, 2).contiguous().to(dev())
+    mean = torch.empty((n, c), dtype=torch.float32, device=dev())
+    rstd = torch.empty((n, c), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_instnorm_finalize(_lib.ptr(part), n, 1, c, d * h * w, 1e-5, _lib.ptr(mean), _lib.ptr(rstd),
+                                        _lib.stream_ptr()), "finalize")
+    xd = cl(xf).to(dev())
+    pitch = 2 * c
+    out = torch.full((n, d, h, w, pitch), -77.0, dtype=torch.float32, device=dev())
+    pooled = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=torch.float32, device=dev()) if pool else None
+    md = cl(mask).to(torch.uint8).to(dev())
+    a = _lib.NormArgs()
+    a.x = xd.data_ptr(); a.x_pitch = c; a.mean = mean.data_ptr(); a.rstd = rstd.data_ptr()
+    a.out = out.data_ptr(); a.out_pitch = pitch; a.out_coff = c
+    if pool:
+        a.pool_out = pooled.data_ptr(); a.pool_pitch = c
+    a.N, a.D, a.H, a.W, a.C = n, d, h, w, c
+    a.act = _lib.VX_ACT_LRELU; a.drop_mode = _lib.VX_DROP_MASK; a.drop_mask = md.data_ptr()
+    _lib.check(lib.vx_norm_act_drop_pool(C.byref(a), _lib.stream_ptr()), "norm")
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.instance_norm(xf.double(), eps=1e-5), 0.01) * mask * 2.0
+    got = ncdhw(out[..., c:]).cpu().double()
+    assert (got - ref).abs().max().item() < 2e-5
+    assert (out[..., :c] == -77.0).all()
+    if pool:
+        refp = F.max_pool3d(ref, 2, 2)
+        gotp = ncdhw(pooled).cpu().double()
+        assert (gotp - refp).abs().max().item() < 2e-5
+
+
+def test_conv1x1_slots_and_unflip():
+    lib = _lib.load()
+    n, f, c, d, h, w = 4, 8, 3, 4, 6, 8
+    x = torch.from_numpy(formula_tensor((n, f, d, h, w), 161))
+    wt = torch.from_numpy(formula_tensor((c, f), 162))
+    b = torch.from_numpy(formula_tensor((c,), 163))
+    flips = [0, 1, 6, 7]
+    dst = [3, 0, 5, 2]
+    out = torch.full((6, c, d, h, w), -77.0, dtype=torch.float32, device=dev())
+    xd = cl(x.float()).to(dev())
+    _lib.check(lib.vx_conv1x1_ncdhw(_lib.ptr(xd), f, _lib.ptr(wt.float().to(dev())), _lib.ptr(b.float().to(dev())),
+                                    _lib.ptr(out), n, d, h, w, f, c,
+                                    _lib.ptr(torch.tensor(dst, dtype=torch.int32, device=dev())),
+                                    _lib.ptr(torch.tensor(flips, dtype=torch.int32, device=dev())), _lib.stream_ptr()), "1x1")
+    torch.cuda.synchronize()
+    ref = torch.einsum("nfdhw,cf->ncdhw", x.float().double(), wt.float().double()) + b.float().double().view(1, -1, 1, 1, 1)
+    for i in range(n):
+        dims = [1 + k for k in range(3) if flips[i] >> k & 1]
+        r = torch.flip(ref[i], dims) if dims else ref[i]
+        assert (out[dst[i]].cpu().double() - r).abs().max().item() < 1e-5
+    assert (out[1] == -77.0).all() and (out[4] == -77.0).all()
+
+
+# ------------------------------------------------------------------------------------------- reduction
+@pytest.mark.parametrize("case", ["hand", "r3d", "r2d", "ex"])
+def test_unc_reduce_matches_reference_fixtures(case):
+    from values_amd import calculate_uncertainty
+    g = load_npz("unc_kat.npz")
+    x = torch.from_numpy(g[f"{case}_in"])
+    for device in ("cpu", "cuda"):
+        r = calculate_uncertainty(x.to(device))
+        for k in KEYS:
+            assert r[k].dtype == torch.float32 and r[k].device.type == device
+            assert tuple(r[k].shape) == g[f"{case}_{k}"].shape
+            np.testing.assert_allclose(r[k].cpu().numpy(), g[f"{case}_{k}"], atol=2e-6, rtol=0)
+            assert not torch.isnan(r[k]).any()
+    r = calculate_uncertainty(x.cuda(), ssn=True)
+    np.testing.assert_allclose(r["aleatoric_uncertainty"].cpu().numpy(), g[f"{case}_epistemic_uncertainty"], atol=2e-6)
+    np.testing.assert_allclose(r["epistemic_uncertainty"].cpu().numpy(), g[f"{case}_aleatoric_uncertainty"], atol=2e-6)
+
+
+def test_one_minus_msr_matches_reference_fixture():
+    from values_amd import calculate_one_minus_msr
+    g = load_npz("unc_kat.npz")
+    r = calculate_one_minus_msr(torch.from_numpy(g["msr_in"]).cuda())
+    np.testing.assert_array_equal(r["pred_entropy"].cpu().numpy(), g["msr_pred_entropy"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(10, 2, 16, 16, 16), (3, 5, 7, 9), (1, 2, 4, 4, 4), (4, 8, 33)])
+def test_unc_reduce_logits_and_probs_vs_oracle(dtype, shape):
+    from oracle import uncertainty_oracle as uo
+    from values_amd import uncertainty_maps
+    logits = formula_tensor(shape, 171, scale=4.0)
+    logits = logits.astype(np.float32 if dtype == torch.float32 else np.float64)
+    sm = uo.softmax(logits.astype(np.float64), axis=1)
+    ref = uo.calculate_uncertainty(sm)
+    mean, mean_seg, pred_seg = uo.mean_and_argmax(sm)
+    for from_logits, xin in ((True, logits), (False, sm.astype(logits.dtype))):
+        m = uncertainty_maps(torch.from_numpy(xin).unsqueeze(0).cuda(), from_logits=from_logits, want_sample_argmax=True)
+        np.testing.assert_allclose(m["pred_entropy"][0].cpu().numpy(), ref["pred_entropy"], atol=5e-6)
+        np.testing.assert_allclose(m["expected_entropy"][0].cpu().numpy(), ref["aleatoric_uncertainty"], atol=5e-6)
+        np.testing.assert_allclose(m["mutual_information"][0].cpu().numpy(), ref["epistemic_uncertainty"], atol=5e-6)
+        np.testing.assert_allclose(m["mean_softmax"][0].cpu().numpy(), mean, atol=2e-6)
+        srt = np.sort(mean, axis=0)
+        clear = (srt[-1] - srt[-2]) > 1e-5
+        assert (m["argmax"][0].cpu().numpy() == mean_seg)[clear].all()
+        ssrt = np.sort(sm, axis=1)
+        sclear = (ssrt[:, -1] - ssrt[:, -2]) > 1e-5
+        assert (m["sample_argmax"][0].cpu().numpy() == pred_seg)[sclear].all()
+
+
+def test_unc_reduce_edge_cases():
+    from values_amd import uncertainty_maps
+    lib = _lib.load()
+    # empty volume: no launch, no error
+    x = torch.zeros((1, 3, 2, 0), device="cuda")
+    m = uncertainty_maps(x)
+    assert m["pred_entropy"].shape == (1, 0)
+    # batched volumes == per-volume calls (bit exact)
+    x = torch.from_numpy(formula_tensor((3, 5, 2, 8, 8, 8), 181, scale=3.0)).float().cuda()
+    mb = uncertainty_maps(x, from_logits=True)
+    for b in range(3):
+        m1 = uncertainty_maps(x[b:b + 1], from_logits=True)
+        for k in ("pred_entropy", "expected_entropy", "mutual_information", "mean_softmax", "argmax"):
+            assert torch.equal(mb[k][b], m1[k][0])
+    # argument errors come back as codes + message, not crashes
+    rc = lib.vx_unc_reduce(None, 0, 0, 1, 1, 2, 8, None, None, None, None, None, None, None)
+    assert rc == -1 and b"null" in lib.vx_last_error_string()
+    y = torch.zeros(2 * 9 * 8, device="cuda")
+    o = torch.zeros(8, device="cuda")
+    rc = lib.vx_unc_reduce(_lib.ptr(y), 0, 1, 1, 2, 9, 8, None, _lib.ptr(o), _lib.ptr(o), _lib.ptr(o), None, None, None)
+    assert rc == -2  # from_logits with C > 8
+    # T = 1: expected entropy == predictive entropy, MI == 0
+    p = torch.softmax(torch.from_numpy(formula_tensor((1, 1, 4, 64), 182, scale=2.0)).float().cuda(), 2)
+    m = uncertainty_maps(p)
+    assert m["mutual_information"].abs().max().item() < 1e-6
+    # maximum uint8 class count
+    big = torch.softmax(torch.from_numpy(formula_tensor((1, 2, 255, 16), 183, scale=2.0)).float().cuda(), 2)
+    m = uncertainty_maps(big)
+    assert torch.equal(m["argmax"][0].long().cpu(), big.mean(1)[0].argmax(0).cpu())
+
+
+# ------------------------------------------------------------------------------------------- aggregation
+def test_aggregations_match_reference_fixture():
+    import json
+    import os
+    from tests.helpers import GOLDEN
+    from values_amd import aggregation as agg
+    with open(os.path.join(GOLDEN, "agg_kat.json")) as f:
+        g = json.load(f)
+    for size in (24, 64):
+        img = np.abs(formula_tensor((size,) * 3, tag=g[f"vol{size}_tag"], scale=0.7)).astype(np.float32)
+        c = size // 3
+        img[c:c + 6, c + 2:c + 9, c + 1:c + 7] += 0.5
+        r = g[f"vol{size}"]
+        for key, kw in (("patch10", dict(patch_size=10)), ("patch10_mean", dict(patch_size=10, mean=True)),
+                        ("patch_5_7_9", dict(patch_size=[5, 7, 9]))):
+            mine = agg.patch_level_aggregation(img, **kw)
+            assert mine["max_score"] == pytest.approx(r[key]["max_score"], rel=1e-6)
+            assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in r[key]["bounding_box"]]
+        assert agg.image_level_aggregation(img)["max_score"] == pytest.approx(r["image"]["max_score"], rel=1e-6)
+        assert agg.image_level_aggregation(img, mean=True) == pytest.approx(r["image_mean"], rel=1e-6)
+        for thr in (0.3, 0.6, 5.0):
+            for mean in (True, False):
+                mine = agg.threshold_aggregation(img, threshold=thr, mean=mean)
+                assert float(mine["max_score"]) == pytest.approx(r[f"thr_{thr}_{int(mean)}"]["max_score"], rel=1e-6)
+                assert mine["threshold"] == thr
+    img2 = np.abs(formula_tensor((40, 56), tag=33, scale=1.0)).astype(np.float32)
+    mine = agg.patch_level_aggregation(img2, patch_size=10)
+    assert mine["max_score"] == pytest.approx(g["img2d"]["patch10"]["max_score"], rel=1e-6)
+    assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in g["img2d"]["patch10"]["bounding_box"]]
+    with pytest.raises(Exception):
+        agg.threshold_aggregation(img2)

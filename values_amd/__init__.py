@@ -1,0 +1,4 @@
+"""values_amd -- MI355X-native hot path of ValUES' multi-pass segmentation-uncertainty inference."""
+from .unet3d import UNet3D  # noqa: F401
+from .uncertainty import calculate_one_minus_msr, calculate_uncertainty, uncertainty_maps  # noqa: F401
+from .predict import predict_logits, predict_uncertainty, crop_indices  # noqa: F401

@@ -1,0 +1,129 @@
+"""ctypes binding of libvalues_amd.so (include/values_amd.h).
+
+The HIP library is the product: there is NO CPU or PyTorch fallback.  If the shared object is
+missing or a symbol is absent, import of the compute entry points fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvalues_amd.so")
+
+VX_F32, VX_F64 = 0, 1
+VX_ACT_NONE, VX_ACT_LRELU, VX_ACT_RELU = 0, 1, 2
+VX_DROP_NONE, VX_DROP_HASH, VX_DROP_MASK = 0, 1, 2
+
+_p = C.c_void_p
+_i = C.c_int
+_i32 = C.c_int32
+_u32 = C.c_uint32
+_i64 = C.c_int64
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("in_", _p), ("w_packed", _p), ("bias", _p), ("out", _p),
+                ("in_pitch", _i32), ("out_pitch", _i32), ("out_coff", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32),
+                ("drop_mask", _p), ("stats_partial", _p)]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i32), ("mean", _p), ("rstd", _p),
+                ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
+                ("pool_out", _p), ("pool_pitch", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+
+
+class ConvTArgs(C.Structure):
+    _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
+                ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+
+
+class UNet3DWeights(C.Structure):
+    _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
+                ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32)]
+
+
+class UNet3DRun(C.Structure):
+    _fields_ = [("x", _p), ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("repeat", _i32),
+                ("src", _p), ("flip", _p), ("dst", _p), ("drop_mode", _i32), ("seed", _u32),
+                ("masks", _p * 17), ("logits", _p), ("workspace", _p), ("workspace_bytes", C.c_size_t)]
+
+
+# symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "vx_version": (_i, []),
+    "vx_last_error_string": (C.c_char_p, []),
+    "vx_unc_reduce": (_i, [_p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "vx_one_minus_msr": (_i, [_p, _i, _i, _i64, _p, _p]),
+    "vx_conv3d_k3_packed_floats": (_i64, [_i, _i]),
+    "vx_pack_conv3d_k3": (_i, [_p, _p, _i, _i, _p]),
+    "vx_convT_k2s2_packed_floats": (_i64, [_i, _i]),
+    "vx_pack_convT_k2s2": (_i, [_p, _p, _i, _i, _p]),
+    "vx_conv3d_k3_tiles": (_i, [_i, _i, _i]),
+    "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
+    "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
+    "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "vx_instnorm_finalize": (_i, [_p, _i, _i, _i, _i64, C.c_float, _p, _p, _p]),
+    "vx_norm_act_drop_pool": (_i, [C.POINTER(NormArgs), _p]),
+    "vx_convT_k2s2": (_i, [C.POINTER(ConvTArgs), _p]),
+    "vx_conv1x1_ncdhw": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "vx_unet3d_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "vx_unet3d_forward": (_i, [C.POINTER(UNet3DWeights), C.POINTER(UNet3DRun), _p]),
+    "vx_box_max": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p]),
+    "vx_sum_thr": (_i, [_p, _i64, C.c_float, _p, _p]),
+}
+
+_lib = None
+
+
+class VxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvalues_amd.so (once).  import torch first: torch ships the HIP runtime
+    (libamdhip64.so.7) this library resolves against, so both share one runtime instance."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VxError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C values_amd/csrc`). values_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads the HIP runtime)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vx_last_error_string()
+        raise VxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise VxError("values_amd needs a ROCm device (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,128 @@
+// K1 (first layer): 3x3x3 convolution with ONE input channel (contr_1_1, unet3D_module.py:36-42).
+// 27*Cout MACs per voxel against 4 B read + 4*Cout B written: HBM-bound, so plain VALU FMAs with
+// wave-uniform weights (scalar loads) and an LDS halo tile; no matrix cores.  The kernel also
+// resolves the pass scheduling of predict_cases (test_3D.py:417-482): sample n reads volume src[n]
+// (MC-dropout: n / repeat, all T samples of a volume read the same input) through the flip code of
+// its TTA view.
+#include "common.h"
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3d_k3_c1_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int out_pitch, int N, int D, int H, int W, int repeat,
+                                                           const int32_t* __restrict__ src,
+                                                           const int32_t* __restrict__ flip,
+                                                           float* __restrict__ stats_partial, int tiles_x, int tiles_y,
+                                                           int tiles_z) {
+  constexpr int TX = 32, TY = 4, TZ = 2;  // 256 voxels, one per thread
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  __shared__ float s_in[HZ * HY * HX];
+  __shared__ float s_w[27 * COUT];
+  __shared__ float s_red[4][COUT][2];
+
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y; t /= tiles_y;
+  const int tz = t % tiles_z; t /= tiles_z;
+  const int n = t;
+  const int v = src ? src[n] : n / repeat;
+  const int f = flip ? flip[n] : 0;
+  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+  const float* in_v = in + (size_t)v * D * H * W;
+
+  for (int idx = tid; idx < HZ * HY * HX; idx += 256) {
+    const int hx = idx % HX, hy = (idx / HX) % HY, hz = idx / (HX * HY);
+    int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+    float val = 0.f;
+    if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
+      if (f & 1) gz = D - 1 - gz;
+      if (f & 2) gy = H - 1 - gy;
+      if (f & 4) gx = W - 1 - gx;
+      val = in_v[((size_t)gz * H + gy) * W + gx];
+    }
+    s_in[idx] = val;
+  }
+  // weights: torch (COUT,1,3,3,3) -> s_w[tap][cout]
+  for (int idx = tid; idx < 27 * COUT; idx += 256) {
+    const int co = idx % COUT, tap = idx / COUT;
+    s_w[idx] = w[co * 27 + tap];
+  }
+  __syncthreads();
+
+  const int lx = tid % TX, ly = (tid / TX) % TY, lz = tid / (TX * TY);
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float xv = s_in[((lz + kz) * HY + ly + ky) * HX + lx + kx];
+        const int tap = (kz * 3 + ky) * 3 + kx;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(s_w[tap * COUT + c], xv, acc[c]);
+      }
+
+  const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+  const bool valid = gx < W && gy < H && gz < D;
+  if (valid) {
+    float* o = out + (((size_t)(n * D + gz) * H + gy) * W + gx) * out_pitch;
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4)
+      *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+  }
+  if (stats_partial) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      float s = valid ? acc[c] : 0.f;
+      float q = s * s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        q += __shfl_xor(q, off, 64);
+      }
+      if (lane == 0) { s_red[wave][c][0] = s; s_red[wave][c][1] = q; }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) { s += s_red[wv][tid][0]; q += s_red[wv][tid][1]; }
+      const int ntiles = tiles_x * tiles_y * tiles_z;
+      const int tile = blockIdx.x % ntiles;
+      float* dst = stats_partial + (((size_t)n * ntiles + tile) * COUT + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
+extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W) { return ((W + 31) / 32) * ((H + 3) / 4) * ((D + 1) / 2); }
+
+extern "C" int vx_conv3d_k3_c1(const float* in, const float* w_torch, const float* bias, float* out, int out_pitch,
+                               int N, int D, int H, int W, int Cout, int repeat, const int32_t* src,
+                               const int32_t* flip, float* stats_partial, vx_stream_t stream) {
+  if (!in || !w_torch || !bias || !out) VX_FAIL(VX_E_NULL, "vx_conv3d_k3_c1: null pointer");
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3_c1: empty tensor");
+  if (repeat <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3_c1: repeat must be >= 1");
+  if (out_pitch < Cout || out_pitch % 4 || !vx_aligned16(out)) VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3_c1: out pitch/alignment");
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 3) / 4, tiles_z = (D + 1) / 2;
+  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z * N));
+  hipStream_t s = (hipStream_t)stream;
+#define VX_C1(CO)                                                                                                  \
+  hipLaunchKernelGGL(conv3d_k3_c1_kernel<CO>, grid, dim3(256), 0, s, in, w_torch, bias, out, out_pitch, N, D, H, W, \
+                     repeat, src, flip, stats_partial, tiles_x, tiles_y, tiles_z)
+  switch (Cout) {
+    case 8: VX_C1(8); break;
+    case 16: VX_C1(16); break;
+    case 32: VX_C1(32); break;
+    default: VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3_c1: Cout=%d unsupported (8, 16, 32)", Cout);
+  }
+#undef VX_C1
+  VX_CHECK_LAUNCH("vx_conv3d_k3_c1");
+  return VX_OK;
+}

@@ -1,0 +1,122 @@
+// K6: ConvTranspose3d(kernel 2, stride 2) -- non-overlapping 2x upsampling: every input voxel
+// scatters Cin x (8 * Cout) products to its own 2x2x2 output block (unet3D_module.py:113-118, 157-190).
+// 1.7 % of the network's MACs and 8 x more bytes written than read: HBM/store-bound, so VALU FMAs with
+// wave-uniform weights (scalar loads).  One thread = one input voxel x one (dz,dy) x 8 output channels,
+// producing the dx = 0,1 pair => 64 contiguous output bytes per lane when Cout == 8.
+// The output goes straight into channels [out_coff, out_coff + Cout) of the decoder's concat buffer,
+// which removes torch.cat (K7).  Optional ReLU + dropout epilogue for center.4.
+#include "common.h"
+
+constexpr int CT_CO = 8;  // output channels per thread
+
+__global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_t nvox_in) {
+  // blockIdx.y = ((dz*2 + dy) * ngroups + cgroup)
+  const int ngroups = a.Cout / CT_CO;
+  const int cgp = blockIdx.y % ngroups;
+  const int dzy = blockIdx.y / ngroups;
+  const int dz = dzy >> 1, dy = dzy & 1;
+  const int co0 = cgp * CT_CO;
+  // packed weights: [dz][dy][ci][dx][co]
+  const float* __restrict__ wp = a.w_packed + (size_t)dzy * a.Cin * 2 * a.Cout;
+  const int OD = a.D * 2, OH = a.H * 2, OW = a.W * 2;
+
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvox_in; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int x = r % a.W; r /= a.W;
+    const int y = r % a.H; r /= a.H;
+    const int z = r % a.D; r /= a.D;
+    const int n = (int)r;
+    const float* __restrict__ xin = a.in + (size_t)i * a.in_pitch;
+    float acc[2][CT_CO];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int c = 0; c < CT_CO; ++c) acc[d][c] = a.bias[co0 + c];
+    for (int ci = 0; ci < a.Cin; ci += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + ci);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* __restrict__ wr = wp + (size_t)(ci + k) * 2 * a.Cout + co0;
+#pragma unroll
+        for (int c = 0; c < CT_CO; ++c) {
+          acc[0][c] = fmaf(wr[c], xv[k], acc[0][c]);
+          acc[1][c] = fmaf(wr[a.Cout + c], xv[k], acc[1][c]);
+        }
+      }
+    }
+    const int oz = 2 * z + dz, oy = 2 * y + dy;
+    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int ox = 2 * x + d;
+      const size_t ovox = ((size_t)(n * OD + oz) * OH + oy) * OW + ox;
+#pragma unroll
+      for (int c4 = 0; c4 < CT_CO; c4 += 4) {
+        f32x4 v = (f32x4){acc[d][c4], acc[d][c4 + 1], acc[d][c4 + 2], acc[d][c4 + 3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = vx_act(v[j], a.act);
+        if (a.drop_mode == VX_DROP_HASH) {
+          const uint32_t e = (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + co0 + c4);
+          const uint32_t bits = vx_drop_bits4(dkey, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((bits >> j) & 1u) ? 2.f * v[j] : 0.f;
+        } else if (a.drop_mode == VX_DROP_MASK) {
+          const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + ovox * a.Cout + co0 + c4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.out + ovox * a.out_pitch + a.out_coff + co0 + c4) = v;
+      }
+    }
+  }
+}
+
+__global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int64_t total) {
+  // torch (Cin, Cout, 2,2,2) -> [dz][dy][ci][dx][co]
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int co = r % Cout; r /= Cout;
+    const int dx = r % 2; r /= 2;
+    const int ci = r % Cin; r /= Cin;
+    const int dy = r % 2; r /= 2;
+    const int dz = (int)r;
+    out[i] = w[(((size_t)ci * Cout + co) * 2 + dz) * 4 + dy * 2 + dx];
+  }
+}
+
+extern "C" int64_t vx_convT_k2s2_packed_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % 4 || Cout % 8) return -1;
+  return (int64_t)Cin * Cout * 8;
+}
+
+extern "C" int vx_pack_convT_k2s2(const float* w_torch, float* w_packed, int Cin, int Cout, vx_stream_t stream) {
+  if (!w_torch || !w_packed) VX_FAIL(VX_E_NULL, "vx_pack_convT_k2s2: null pointer");
+  const int64_t total = vx_convT_k2s2_packed_floats(Cin, Cout);
+  if (total < 0) VX_FAIL(VX_E_SHAPE, "vx_pack_convT_k2s2: Cin=%d (mult of 4) Cout=%d (mult of 8)", Cin, Cout);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_convT_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin, Cout,
+                     total);
+  VX_CHECK_LAUNCH("vx_pack_convT_k2s2");
+  return VX_OK;
+}
+
+extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
+  if (!ap) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: null args");
+  const vx_convT_args& a = *ap;
+  if (!a.in || !a.w_packed || !a.bias || !a.out) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: null tensor");
+  if (a.Cin <= 0 || a.Cout <= 0 || a.Cin % 4 || a.Cout % 8)
+    VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: Cin=%d (mult of 4) Cout=%d (mult of 8)", a.Cin, a.Cout);
+  if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: empty tensor");
+  if (a.in_pitch % 4 || a.in_pitch < a.Cin || a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.Cout)
+    VX_FAIL(VX_E_ALIGN, "vx_convT_k2s2: pitches/offsets must be multiples of 4 floats");
+  if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: mask mode without mask");
+  if ((int64_t)a.D * a.H * a.W * 8 * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: sample too large");
+  const int64_t nvox = (int64_t)a.N * a.D * a.H * a.W;
+  int bx = (int)((nvox + 255) / 256);
+  if (bx > 8192) bx = 8192;
+  dim3 grid((unsigned)bx, (unsigned)(4 * (a.Cout / CT_CO)));
+  hipLaunchKernelGGL(convT_k2s2_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, nvox);
+  VX_CHECK_LAUNCH("vx_convT_k2s2");
+  return VX_OK;
+}

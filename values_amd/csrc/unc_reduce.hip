@@ -1,0 +1,311 @@
+// K9-K12: fused N-sample softmax -> {mean prob, predictive entropy, expected entropy, mutual
+// information, argmax} reduction.  One pass over the T*C values of each voxel, 16-byte loads,
+// everything else in registers: a pure HBM stream (T*C*4 B read, (3+C)*4+1 B written per voxel).
+//
+// Semantics follow calculate_uncertainty (uncertainty_modeling/test_3D.py:486-518):
+//   mean over T first, natural log, terms p*log(p) that are NaN (p == 0, or a negative/NaN input)
+//   are skipped, float32 maps.  With from_logits the class softmax (test_3D.py:472) is fused and the
+//   entropy of a sample is computed from log-softmax, which is the same value without the 0*log(0)
+//   singularity.
+#include "common.h"
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<double> { static constexpr int N = 2; };
+
+template <typename TIn> __device__ __forceinline__ TIn vx_log(TIn v);
+template <> __device__ __forceinline__ float vx_log<float>(float v) { return logf(v); }
+template <> __device__ __forceinline__ double vx_log<double>(double v) { return log(v); }
+template <typename TIn> __device__ __forceinline__ TIn vx_exp(TIn v);
+template <> __device__ __forceinline__ float vx_exp<float>(float v) { return expf(v); }
+template <> __device__ __forceinline__ double vx_exp<double>(double v) { return exp(v); }
+
+template <typename TIn, int VEC>
+__device__ __forceinline__ void load_vec(const TIn* p, TIn (&v)[VEC]) {
+  if (VEC == 1) {
+    v[0] = p[0];
+  } else {
+    typedef TIn vt __attribute__((ext_vector_type(VEC)));
+    const vt t = *reinterpret_cast<const vt*>(p);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = t[k];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const float (&v)[VEC]) {
+  if (VEC == 4) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[VEC > 1 ? 1 : 0], v[VEC > 2 ? 2 : 0], v[VEC > 3 ? 3 : 0]};
+  } else if (VEC == 2) {
+    *reinterpret_cast<f32x2*>(p) = (f32x2){v[0], v[VEC > 1 ? 1 : 0]};
+  } else {
+    p[0] = v[0];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_u8(uint8_t* p, const int (&v)[VEC]) {
+  if (VEC == 4) {
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)v[0] | ((uint32_t)v[VEC > 1 ? 1 : 0] << 8) |
+                                      ((uint32_t)v[VEC > 2 ? 2 : 0] << 16) | ((uint32_t)v[VEC > 3 ? 3 : 0] << 24);
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] = (uint8_t)v[k];
+  }
+}
+
+// ---- probabilities in, any C: class-outer loop, only scalars live ----
+template <typename TIn, int VEC>
+__global__ __launch_bounds__(256) void unc_reduce_prob_kernel(const TIn* __restrict__ x, int T, int C, int64_t nvox,
+                                                              float* __restrict__ mean_prob,
+                                                              float* __restrict__ pred_entropy,
+                                                              float* __restrict__ exp_entropy,
+                                                              float* __restrict__ mutual_info,
+                                                              uint8_t* __restrict__ argmax) {
+  const int b = blockIdx.y;
+  const TIn* xb = x + (size_t)b * T * C * nvox;
+  const int64_t ngroups = nvox / VEC;
+  for (int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v0 = gi * VEC;
+    float pe[VEC];   // running -sum_c mean*log(mean), rounded to f32 after every class like the reference
+    TIn ee[VEC];     // sum over (t, c) of p*log(p)
+    TIn best[VEC];
+    int besti[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { pe[k] = 0.f; ee[k] = 0; best[k] = 0; besti[k] = 0; }
+    for (int c = 0; c < C; ++c) {
+      TIn s[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s[k] = 0;
+      for (int t = 0; t < T; ++t) {
+        TIn p[VEC];
+        load_vec<TIn, VEC>(xb + ((size_t)t * C + c) * nvox + v0, p);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          s[k] += p[k];
+          const TIn term = p[k] * vx_log<TIn>(p[k]);
+          if (term == term) ee[k] += term;  // NaN-skip (test_3D.py:503-504)
+        }
+      }
+      float mo[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const TIn mean = s[k] / (TIn)T;
+        mo[k] = (float)mean;
+        const TIn term = mean * vx_log<TIn>(mean);
+        if (term == term) pe[k] = (float)((TIn)pe[k] + term);  // f32 accumulator (test_3D.py:490-494)
+        if (c == 0 || mean > best[k]) { best[k] = mean; besti[k] = c; }
+      }
+      if (mean_prob) store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
+    }
+    float o_pe[VEC], o_ee[VEC], o_mi[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      o_pe[k] = -pe[k];
+      o_ee[k] = (float)(-ee[k] / (TIn)T);
+      o_mi[k] = o_pe[k] - o_ee[k];
+    }
+    store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
+    store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
+    store_f32<VEC>(mutual_info + (size_t)b * nvox + v0, o_mi);
+    if (argmax) store_u8<VEC>(argmax + (size_t)b * nvox + v0, besti);
+  }
+}
+
+// ---- logits in, C known at compile time (<= 8): sample-outer loop, softmax in registers ----
+template <typename TIn, int C, int VEC>
+__global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __restrict__ x, int T, int64_t nvox,
+                                                               float* __restrict__ mean_prob,
+                                                               float* __restrict__ pred_entropy,
+                                                               float* __restrict__ exp_entropy,
+                                                               float* __restrict__ mutual_info,
+                                                               uint8_t* __restrict__ argmax,
+                                                               uint8_t* __restrict__ sample_argmax) {
+  const int b = blockIdx.y;
+  const TIn* xb = x + (size_t)b * T * C * nvox;
+  const int64_t ngroups = nvox / VEC;
+  for (int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v0 = gi * VEC;
+    TIn sum[C][VEC];
+    TIn ee[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      ee[k] = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) sum[c][k] = 0;
+    }
+    for (int t = 0; t < T; ++t) {
+      TIn z[C][VEC];
+#pragma unroll
+      for (int c = 0; c < C; ++c) load_vec<TIn, VEC>(xb + ((size_t)t * C + c) * nvox + v0, z[c]);
+      int am[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        TIn m = z[0][k];
+        int mi = 0;
+#pragma unroll
+        for (int c = 1; c < C; ++c)
+          if (z[c][k] > m) { m = z[c][k]; mi = c; }
+        am[k] = mi;
+        TIn e[C];
+        TIn den = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { e[c] = vx_exp<TIn>(z[c][k] - m); den += e[c]; }
+        const TIn inv = (TIn)1 / den;
+        const TIn lden = vx_log<TIn>(den);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const TIn p = e[c] * inv;
+          sum[c][k] += p;
+          ee[k] += p * ((z[c][k] - m) - lden);  // p*log(p) via log-softmax
+        }
+      }
+      if (sample_argmax) store_u8<VEC>(sample_argmax + ((size_t)b * T + t) * nvox + v0, am);
+    }
+    float pe[VEC];
+    int besti[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      pe[k] = 0.f;
+      TIn best = 0;
+      besti[k] = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const TIn mean = sum[c][k] / (TIn)T;
+        const TIn term = mean * vx_log<TIn>(mean);
+        if (term == term) pe[k] = (float)((TIn)pe[k] + term);
+        if (c == 0 || mean > best) { best = mean; besti[k] = c; }
+      }
+    }
+    if (mean_prob) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float mo[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mo[k] = (float)(sum[c][k] / (TIn)T);
+        store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
+      }
+    }
+    float o_pe[VEC], o_ee[VEC], o_mi[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      o_pe[k] = -pe[k];
+      o_ee[k] = (float)(-ee[k] / (TIn)T);
+      o_mi[k] = o_pe[k] - o_ee[k];
+    }
+    store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
+    store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
+    store_f32<VEC>(mutual_info + (size_t)b * nvox + v0, o_mi);
+    if (argmax) store_u8<VEC>(argmax + (size_t)b * nvox + v0, besti);
+  }
+}
+
+// per-sample argmax over classes for the probability path (data_carrier_3D.py:281-283)
+template <typename TIn>
+__global__ __launch_bounds__(256) void sample_argmax_kernel(const TIn* __restrict__ x, int C, int64_t nvox, int64_t nbt,
+                                                            uint8_t* __restrict__ out) {
+  const int64_t total = nbt * nvox;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bt = i / nvox, v = i - bt * nvox;
+    const TIn* p = x + (size_t)bt * C * nvox + v;
+    TIn best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const TIn q = p[(size_t)c * nvox];
+      if (q > best) { best = q; bi = c; }
+    }
+    out[i] = (uint8_t)bi;
+  }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void one_minus_msr_kernel(const TIn* __restrict__ x, int C, int64_t nvox,
+                                                            TIn* __restrict__ out) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    TIn best = x[v];
+    for (int c = 1; c < C; ++c) {
+      const TIn q = x[(size_t)c * nvox + v];
+      best = q > best ? q : best;
+    }
+    out[v] = (TIn)1 - best;
+  }
+}
+
+template <typename TIn, int VEC>
+static int launch_unc(const TIn* x, int from_logits, int B, int T, int C, int64_t nvox, float* mean_prob,
+                      float* pred_entropy, float* exp_entropy, float* mutual_info, uint8_t* argmax,
+                      uint8_t* sample_argmax, hipStream_t s) {
+  const int64_t ngroups = nvox / VEC;
+  int bx = (int)((ngroups + 255) / 256);
+  if (bx > 8192) bx = 8192;
+  if (bx < 1) bx = 1;
+  dim3 grid((unsigned)bx, (unsigned)B);
+  if (!from_logits) {
+    hipLaunchKernelGGL((unc_reduce_prob_kernel<TIn, VEC>), grid, dim3(256), 0, s, x, T, C, nvox, mean_prob, pred_entropy,
+                       exp_entropy, mutual_info, argmax);
+    if (sample_argmax) {
+      const int64_t total = (int64_t)B * T * nvox;
+      int bb = (int)((total + 255) / 256);
+      if (bb > 16384) bb = 16384;
+      hipLaunchKernelGGL(sample_argmax_kernel<TIn>, dim3(bb), dim3(256), 0, s, x, C, nvox, (int64_t)B * T, sample_argmax);
+    }
+    return VX_OK;
+  }
+#define VX_LOGIT(CC)                                                                                                \
+  case CC:                                                                                                          \
+    hipLaunchKernelGGL((unc_reduce_logit_kernel<TIn, CC, VEC>), grid, dim3(256), 0, s, x, T, nvox, mean_prob,        \
+                       pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax);                              \
+    break;
+  switch (C) {
+    VX_LOGIT(2) VX_LOGIT(3) VX_LOGIT(4) VX_LOGIT(5) VX_LOGIT(6) VX_LOGIT(7) VX_LOGIT(8)
+    default: VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: from_logits supports 2 <= C <= 8 (got %d)", C);
+  }
+#undef VX_LOGIT
+  return VX_OK;
+}
+
+extern "C" int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
+                             float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
+                             uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream) {
+  if (!x || !pred_entropy || !exp_entropy || !mutual_info) VX_FAIL(VX_E_NULL, "vx_unc_reduce: null pointer");
+  if (B <= 0 || T <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: B=%d T=%d C=%d nvox=%lld", B, T, C, (long long)nvox);
+  if (C > 255 && (argmax || sample_argmax)) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: uint8 argmax needs C <= 255");
+  if (dtype != VX_F32 && dtype != VX_F64) VX_FAIL(VX_E_DTYPE, "vx_unc_reduce: dtype %d", dtype);
+  if (nvox == 0) return VX_OK;  // empty volume: nothing to do (the reference returns empty maps)
+  hipStream_t s = (hipStream_t)stream;
+  const bool al = vx_aligned16(x) && vx_aligned16(pred_entropy) && vx_aligned16(exp_entropy) && vx_aligned16(mutual_info) &&
+                  (!mean_prob || vx_aligned16(mean_prob)) && (!argmax || (((uintptr_t)argmax) & 3u) == 0) &&
+                  (!sample_argmax || (((uintptr_t)sample_argmax) & 3u) == 0);
+  int rc;
+  if (dtype == VX_F32) {
+    if (al && nvox % 4 == 0)
+      rc = launch_unc<float, 4>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+    else
+      rc = launch_unc<float, 1>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+  } else {
+    if (al && nvox % 4 == 0)
+      rc = launch_unc<double, 2>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+    else
+      rc = launch_unc<double, 1>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+  }
+  if (rc != VX_OK) return rc;
+  VX_CHECK_LAUNCH("vx_unc_reduce");
+  return VX_OK;
+}
+
+extern "C" int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, void* out, vx_stream_t stream) {
+  if (!x || !out) VX_FAIL(VX_E_NULL, "vx_one_minus_msr: null pointer");
+  if (C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_one_minus_msr: bad shape");
+  if (nvox == 0) return VX_OK;
+  int bx = (int)((nvox + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VX_F32)
+    hipLaunchKernelGGL(one_minus_msr_kernel<float>, dim3(bx), dim3(256), 0, s, (const float*)x, C, nvox, (float*)out);
+  else if (dtype == VX_F64)
+    hipLaunchKernelGGL(one_minus_msr_kernel<double>, dim3(bx), dim3(256), 0, s, (const double*)x, C, nvox, (double*)out);
+  else
+    VX_FAIL(VX_E_DTYPE, "vx_one_minus_msr: dtype %d", dtype);
+  VX_CHECK_LAUNCH("vx_one_minus_msr");
+  return VX_OK;
+}

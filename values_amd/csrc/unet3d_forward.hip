@@ -1,0 +1,187 @@
+// Whole-network launch: UNet3D.forward (uncertainty_modeling/models/unet3D_module.py:296-373) for a batch
+// of N samples (MC-dropout samples x TTA views x volumes), as ~45 kernel launches on the caller's
+// stream -- no allocation, no synchronisation, capturable into one hipGraph.
+//
+// Data flow (channels-last fp32, level l has spatial (D,H,W) >> l and C_l = F << l channels):
+//   encoder l:  conv -> A_l (raw + stats) -> finalize -> IN/LReLU/drop in place
+//               conv -> B_l (raw + stats) -> finalize -> IN/LReLU/drop -> CAT_l[C_l:2C_l) (skip) + pool -> P_{l+1}
+//   center:     conv+ReLU, conv+ReLU, convT+ReLU+drop -> CAT_3[0:C_3)
+//   decoder l:  conv(CAT_l)+LReLU+drop -> A_l, conv+LReLU+drop -> B_l, convT -> CAT_{l-1}[0:C_{l-1})
+//   final:      1x1x1 conv(B_0) -> logits NCDHW, slot dst[n], un-flipped
+// torch.cat never happens: both producers write their half of CAT_l (K7).
+#include "common.h"
+
+extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W);
+
+namespace {
+struct Level { int D, H, W, C; int64_t nvox; };
+
+struct Plan {
+  Level lv[5];
+  float *A[4], *B[4], *CAT[4], *P[5], *C0, *C1;
+  float *stats, *mean, *rstd;
+  size_t bytes;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static void make_plan(Plan& p, int N, int D, int H, int W, int F, char* base) {
+  size_t off = 0;
+  auto carve = [&](size_t floats) {
+    float* q = base ? (float*)(base + off) : nullptr;
+    off += align_up(floats * sizeof(float));
+    return q;
+  };
+  for (int l = 0; l < 5; ++l) {
+    p.lv[l].D = D >> l; p.lv[l].H = H >> l; p.lv[l].W = W >> l; p.lv[l].C = F << l;
+    p.lv[l].nvox = (int64_t)p.lv[l].D * p.lv[l].H * p.lv[l].W;
+  }
+  for (int l = 0; l < 4; ++l) {
+    const size_t e = (size_t)N * p.lv[l].nvox * p.lv[l].C;
+    p.A[l] = carve(e);
+    p.B[l] = carve(e);
+    p.CAT[l] = carve(2 * e);
+  }
+  p.P[0] = nullptr;
+  for (int l = 1; l < 5; ++l) p.P[l] = carve((size_t)N * p.lv[l].nvox * p.lv[l - 1].C);
+  p.C0 = carve((size_t)N * p.lv[4].nvox * p.lv[4].C);
+  p.C1 = carve((size_t)N * p.lv[4].nvox * p.lv[4].C);
+  // statistics: the largest partial buffer is level 0
+  size_t smax = 0;
+  for (int l = 0; l < 4; ++l) {
+    size_t t = (size_t)vx_conv3d_k3_tiles(p.lv[l].D, p.lv[l].H, p.lv[l].W);
+    if (l == 0) {
+      size_t t1 = (size_t)vx_conv3d_k3_c1_tiles(p.lv[0].D, p.lv[0].H, p.lv[0].W);
+      if (t1 > t) t = t1;
+    }
+    const size_t e = (size_t)N * t * p.lv[l].C * 2;
+    if (e > smax) smax = e;
+  }
+  p.stats = carve(smax);
+  p.mean = carve((size_t)N * p.lv[3].C);
+  p.rstd = carve((size_t)N * p.lv[3].C);
+  p.bytes = off;
+}
+}  // namespace
+
+extern "C" size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
+  Plan p;
+  make_plan(p, N, D, H, W, F, nullptr);
+  return p.bytes;
+}
+
+#define VX_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != VX_OK) return rc_; \
+  } while (0)
+
+extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream) {
+  if (!w || !r) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: null argument");
+  if (!r->x || !r->logits || !r->workspace) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: null tensor/workspace");
+  const int N = r->N, D = r->D, H = r->H, W = r->W, F = w->F, NC = w->num_classes;
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) VX_FAIL(VX_E_SHAPE, "vx_unet3d_forward: empty batch");
+  if (D % 16 || H % 16 || W % 16)
+    VX_FAIL(VX_E_SHAPE, "vx_unet3d_forward: spatial size (%d,%d,%d) must be divisible by 16 (4 poolings; InstanceNorm "
+            "needs > 1 voxel at the 8x level)", D, H, W);
+  if (F != 8 && F != 16 && F != 32) VX_FAIL(VX_E_SHAPE, "vx_unet3d_forward: initial_filter_size %d unsupported (8,16,32)", F);
+  if (NC <= 0) VX_FAIL(VX_E_SHAPE, "vx_unet3d_forward: num_classes %d", NC);
+  if (r->drop_mode < 0 || r->drop_mode > 2) VX_FAIL(VX_E_DTYPE, "vx_unet3d_forward: drop_mode %d", r->drop_mode);
+  if ((((uintptr_t)r->workspace) & 255u) != 0) VX_FAIL(VX_E_ALIGN, "vx_unet3d_forward: workspace must be 256-byte aligned");
+  for (int i = 0; i < 18; ++i)
+    if (!w->conv_w[i] || !w->conv_b[i]) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: conv weight %d missing", i);
+  for (int i = 0; i < 4; ++i)
+    if (!w->up_w[i] || !w->up_b[i]) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: transposed-conv weight %d missing", i);
+  if (!w->final_w || !w->final_b) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: final weights missing");
+  if (r->drop_mode == VX_DROP_MASK)
+    for (int i = 0; i < 17; ++i)
+      if (!r->masks[i]) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: mask %d missing", i);
+
+  Plan p;
+  make_plan(p, N, D, H, W, F, (char*)r->workspace);
+  if (p.bytes > r->workspace_bytes)
+    VX_FAIL(VX_E_WORKSPACE, "vx_unet3d_forward: workspace %zu B < required %zu B", r->workspace_bytes, p.bytes);
+
+  const int dm = r->drop_mode;
+  auto mask = [&](int i) { return dm == VX_DROP_MASK ? r->masks[i] : (const uint8_t*)nullptr; };
+
+  auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
+                  int Cout, int act, int drop_layer, float* stats) {
+    vx_conv3d_args a;
+    a.in = in; a.w_packed = w->conv_w[wi]; a.bias = w->conv_b[wi]; a.out = out;
+    a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.out_coff = out_coff;
+    a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.Cin = Cin; a.Cout = Cout;
+    a.act = act;
+    a.drop_mode = drop_layer >= 0 ? dm : VX_DROP_NONE;
+    a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
+    a.drop_mask = drop_layer >= 0 ? mask(drop_layer) : nullptr;
+    a.stats_partial = stats;
+    return vx_conv3d_k3(&a, stream);
+  };
+  auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
+                  int drop_layer) {
+    vx_norm_args a;
+    a.x = x; a.x_pitch = C; a.mean = p.mean; a.rstd = p.rstd;
+    a.out = out; a.out_pitch = out_pitch; a.out_coff = out_coff;
+    a.pool_out = pool; a.pool_pitch = C;
+    a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.C = C;
+    a.act = VX_ACT_LRELU; a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = (uint32_t)drop_layer;
+    a.drop_mask = mask(drop_layer);
+    return vx_norm_act_drop_pool(&a, stream);
+  };
+  auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
+                   int drop_layer) {
+    vx_convT_args a;
+    a.in = in; a.in_pitch = Cin; a.w_packed = w->up_w[ui]; a.bias = w->up_b[ui];
+    a.out = out; a.out_pitch = out_pitch; a.out_coff = 0;
+    a.N = N; a.D = Lin.D; a.H = Lin.H; a.W = Lin.W; a.Cin = Cin; a.Cout = Cout;
+    a.act = act;
+    a.drop_mode = drop_layer >= 0 ? dm : VX_DROP_NONE;
+    a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
+    a.drop_mask = drop_layer >= 0 ? mask(drop_layer) : nullptr;
+    return vx_convT_k2s2(&a, stream);
+  };
+
+  // ---------------- encoder ----------------
+  for (int l = 0; l < 4; ++l) {
+    const Level& L = p.lv[l];
+    const int C = L.C;
+    int ntiles;
+    if (l == 0) {
+      ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
+      VX_TRY(vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, r->repeat > 0 ? r->repeat : 1,
+                             r->src, r->flip, p.stats, stream));
+    } else {
+      ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
+      VX_TRY(conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats));
+    }
+    VX_TRY(vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+    VX_TRY(norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l));
+    ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
+    VX_TRY(conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats));
+    VX_TRY(vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+    VX_TRY(norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1));
+  }
+  // ---------------- center ----------------
+  {
+    const Level& L4 = p.lv[4];
+    const int C3 = p.lv[3].C, C4 = L4.C;
+    VX_TRY(conv(p.P[4], C3, 8, p.C0, C4, 0, L4, C3, C4, VX_ACT_RELU, -1, nullptr));
+    VX_TRY(conv(p.C0, C4, 9, p.C1, C4, 0, L4, C4, C4, VX_ACT_RELU, -1, nullptr));
+    VX_TRY(convT(p.C1, 0, p.CAT[3], 2 * C3, L4, C4, C3, VX_ACT_RELU, 8));
+  }
+  // ---------------- decoder ----------------
+  for (int l = 3; l >= 0; --l) {
+    const Level& L = p.lv[l];
+    const int C = L.C;
+    const int wi = 10 + 2 * (3 - l);
+    const int dl = 9 + 2 * (3 - l);
+    VX_TRY(conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr));
+    VX_TRY(conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr));
+    if (l > 0) VX_TRY(convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
+  }
+  // ---------------- head ----------------
+  VX_TRY(vx_conv1x1_ncdhw(p.B[0], F, w->final_w, w->final_b, r->logits, N, D, H, W, F, NC, r->dst, r->flip, stream));
+  return VX_OK;
+}

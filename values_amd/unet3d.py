@@ -1,0 +1,209 @@
+"""UNet3D on MI355X: the reference's model class surface, HIP kernels underneath.
+
+Mirrors `uncertainty_modeling.models.unet3D_module.UNet3D` (unet3D_module.py:7-373): identical
+constructor keywords, identical state-dict key names (`contr_1_1.0.weight`, `center.4.bias`,
+`upscale3.weight`, `final.weight`, ...), so a hydra `_target_` can be re-pointed to
+`values_amd.unet3d.UNet3D` and the same Lightning checkpoint loads through
+`load_state_dict` (test_3D.py:222-247).  `forward(x)` takes the reference's (N,1,D,H,W) tensor and
+returns (N,C,D,H,W) logits -- computed by libvalues_amd.so (vx_unet3d_forward), never by ATen.
+
+The torch.nn layers created here are PARAMETER CONTAINERS only (they give load_state_dict / .to() /
+.double() for free); their own forward is never called.
+
+Extensions used by the batched multi-pass driver (values_amd.predict):
+    forward(x, n_samples=T)   T MC-dropout samples per volume in one launch (sample n reads volume n // T)
+    forward(x, src=, flip=)   per-sample source volume and TTA flip code (bit0 = dim 2, bit1 = dim 3, bit2 = dim 4)
+    forward(x, dropout_masks=[17 bool tensors])   inject the reference's keep-masks (parity tests)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+# execution order of the 18 3x3x3 convs, the 4 transposed convs and the 17 dropouts
+CONV_ORDER = ["contr_1_1.0", "contr_1_2.0", "contr_2_1.0", "contr_2_2.0", "contr_3_1.0", "contr_3_2.0",
+              "contr_4_1.0", "contr_4_2.0", "center.0", "center.2", "expand_4_1.0", "expand_4_2.0",
+              "expand_3_1.0", "expand_3_2.0", "expand_2_1.0", "expand_2_2.0", "expand_1_1.0", "expand_1_2.0"]
+UP_ORDER = ["center.4", "upscale4", "upscale3", "upscale2"]
+DROPOUT_ORDER = ["contr_1_1", "contr_1_2", "contr_2_1", "contr_2_2", "contr_3_1", "contr_3_2", "contr_4_1",
+                 "contr_4_2", "center", "expand_4_1", "expand_4_2", "expand_3_1", "expand_3_2", "expand_2_1",
+                 "expand_2_2", "expand_1_1", "expand_1_2"]
+
+
+def _block(cin, cout, k, norm, p):
+    layers = [nn.Conv3d(cin, cout, k, padding=1)]
+    if norm:
+        layers.append(nn.InstanceNorm3d(cout))
+    layers += [nn.LeakyReLU(inplace=True), nn.Dropout(p=p)]
+    return nn.Sequential(*layers)
+
+
+class UNet3D(nn.Module):
+    def __init__(self, num_classes: int, in_channels: int = 1, initial_filter_size: int = 8, kernel_size: int = 3,
+                 do_instancenorm: bool = True, do_dropout: bool = False, aleatoric_loss: bool = False):
+        super().__init__()
+        if kernel_size != 3:
+            raise NotImplementedError("values_amd.UNet3D: only kernel_size=3 (every shipped config) has a HIP kernel")
+        if in_channels != 1:
+            raise NotImplementedError("values_amd.UNet3D: only in_channels=1 (every shipped config) has a HIP kernel")
+        if not do_instancenorm:
+            raise NotImplementedError("values_amd.UNet3D: do_instancenorm=False has no HIP path yet")
+        if initial_filter_size not in (8, 16, 32):
+            raise NotImplementedError("values_amd.UNet3D: initial_filter_size must be 8, 16 or 32")
+        self.num_classes = num_classes
+        self.aleatoric_loss = aleatoric_loss
+        self.initial_filter_size = initial_filter_size
+        self.dropout_prob = 0.5 if do_dropout else 0.0  # unet3D_module.py:31-34
+        f, p = initial_filter_size, self.dropout_prob
+        chans = [f, 2 * f, 4 * f, 8 * f]
+        prev = in_channels
+        for lvl, c in enumerate(chans, start=1):
+            setattr(self, f"contr_{lvl}_1", _block(prev, c, 3, True, p))
+            setattr(self, f"contr_{lvl}_2", _block(c, c, 3, True, p))
+            prev = c
+        center = [nn.Conv3d(8 * f, 16 * f, 3, padding=1), nn.ReLU(inplace=True),
+                  nn.Conv3d(16 * f, 16 * f, 3, padding=1), nn.ReLU(inplace=True),
+                  nn.ConvTranspose3d(16 * f, 8 * f, 2, stride=2), nn.ReLU(inplace=True)]
+        if do_dropout:
+            center.append(nn.Dropout(p=p))
+        self.center = nn.Sequential(*center)
+        for lvl in (4, 3, 2, 1):
+            c = chans[lvl - 1]
+            setattr(self, f"expand_{lvl}_1", _block(2 * c, c, 3, False, p))
+            setattr(self, f"expand_{lvl}_2", _block(c, c, 3, False, p))
+            if lvl > 1:
+                setattr(self, f"upscale{lvl}", nn.ConvTranspose3d(c, c // 2, kernel_size=2, stride=2))
+        self.final = nn.Conv3d(f, num_classes, kernel_size=1)
+        if aleatoric_loss:
+            self.final_aleatoric = nn.Conv3d(f, num_classes * 2, kernel_size=1)
+        self.output_reconstruction_map = nn.Conv3d(f, out_channels=1, kernel_size=1)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        self._calls = 0
+        self.seed = 123  # reference default seed (configs/dropout_config.yaml:8); set_seed analogue
+
+    # ------------------------------------------------------------------ weights
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in self.parameters())
+
+    def _ensure_packed(self, device):
+        key = self._param_key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = _lib.load()
+        sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in self.state_dict().items()}
+        keep = []  # tensors the ctypes struct points into
+        w = _lib.UNet3DWeights()
+        st = _lib.stream_ptr()
+        for i, name in enumerate(CONV_ORDER):
+            wt, b = sd[name + ".weight"], sd[name + ".bias"]
+            cout, cin = wt.shape[0], wt.shape[1]
+            if i == 0:
+                packed = wt  # Cin == 1 kernel reads the torch layout
+            else:
+                n = lib.vx_conv3d_k3_packed_floats(cin, cout)
+                if n < 0:
+                    raise _lib.VxError(f"conv {name}: Cin={cin} Cout={cout} unsupported")
+                packed = torch.empty(n, dtype=torch.float32, device=device)
+                _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(packed), cin, cout, st), "vx_pack_conv3d_k3")
+            keep += [packed, b, wt]
+            w.conv_w[i] = packed.data_ptr()
+            w.conv_b[i] = b.data_ptr()
+        for i, name in enumerate(UP_ORDER):
+            wt, b = sd[name + ".weight"], sd[name + ".bias"]
+            cin, cout = wt.shape[0], wt.shape[1]
+            n = lib.vx_convT_k2s2_packed_floats(cin, cout)
+            packed = torch.empty(n, dtype=torch.float32, device=device)
+            _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(wt), _lib.ptr(packed), cin, cout, st), "vx_pack_convT_k2s2")
+            keep += [packed, b, wt]
+            w.up_w[i] = packed.data_ptr()
+            w.up_b[i] = b.data_ptr()
+        head = "final_aleatoric" if self.aleatoric_loss else "final"
+        fw = sd[head + ".weight"].reshape(sd[head + ".weight"].shape[0], -1).contiguous()
+        fb = sd[head + ".bias"]
+        keep += [fw, fb]
+        w.final_w = fw.data_ptr()
+        w.final_b = fb.data_ptr()
+        w.F = self.initial_filter_size
+        w.num_classes = fw.shape[0]
+        self._packed = (w, keep)
+        self._packed_key = key
+        return self._packed
+
+    def _workspace(self, N, D, H, W, device):
+        key = (N, D, H, W, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.load().vx_unet3d_workspace_bytes(N, D, H, W, self.initial_filter_size)
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self._ws = {key: ws}  # keep one geometry resident
+        off = (-ws.data_ptr()) % 256
+        return ws, off, ws.numel() - 256
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, enable_concat: bool = True, last_layer: bool = True, *,
+                n_samples: int = 1, src: Optional[torch.Tensor] = None, flip: Optional[torch.Tensor] = None,
+                dst: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                dropout_masks: Optional[Sequence[torch.Tensor]] = None, seed: Optional[int] = None):
+        if not enable_concat or not last_layer:
+            raise NotImplementedError("values_amd.UNet3D: autoencoder / feature modes are training-only and not on the HIP path")
+        _lib.require_gpu()
+        lib = _lib.load()
+        if x.dim() != 5 or x.shape[1] != 1:
+            raise ValueError(f"expected (N,1,D,H,W) input, got {tuple(x.shape)}")
+        in_dtype = x.dtype
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        V, _, D, H, W = xf.shape
+        if src is not None:
+            N = int(src.numel())
+        else:
+            N = V * int(n_samples)
+        w, _keep = self._ensure_packed(dev)
+        NC = w.num_classes
+        ws, off, ws_bytes = self._workspace(N, D, H, W, dev)
+        if out is None:
+            out = torch.empty((N, NC, D, H, W), dtype=torch.float32, device=dev)
+        run = _lib.UNet3DRun()
+        run.x = xf.data_ptr()
+        run.N, run.D, run.H, run.W = N, D, H, W
+        run.repeat = int(n_samples)
+        hold = [xf, out, ws]
+        for name, t in (("src", src), ("flip", flip), ("dst", dst)):
+            if t is not None:
+                t = t.to(device=dev, dtype=torch.int32).contiguous()
+                hold.append(t)
+                setattr(run, name, t.data_ptr())
+        if dropout_masks is not None:
+            if len(dropout_masks) != 17:
+                raise ValueError("dropout_masks: need 17 masks in DROPOUT_ORDER")
+            run.drop_mode = _lib.VX_DROP_MASK
+            for i, m in enumerate(dropout_masks):
+                # reference layout (N,C,D,H,W) bool -> channels-last uint8
+                m = m.to(device=dev).permute(0, 2, 3, 4, 1).contiguous().to(torch.uint8)
+                hold.append(m)
+                run.masks[i] = m.data_ptr()
+        elif self.training and self.dropout_prob > 0:
+            run.drop_mode = _lib.VX_DROP_HASH
+            if seed is None:
+                seed = (self.seed * 1000003 + self._calls) & 0xFFFFFFFF
+                self._calls += 1
+            run.seed = int(seed) & 0xFFFFFFFF
+        else:
+            run.drop_mode = _lib.VX_DROP_NONE
+        run.logits = out.data_ptr()
+        run.workspace = ws.data_ptr() + off
+        run.workspace_bytes = ws_bytes
+        _lib.check(lib.vx_unet3d_forward(C.byref(w), C.byref(run), _lib.stream_ptr()), "vx_unet3d_forward")
+        self._hold = hold  # keep inputs alive until the stream has consumed them
+        res = out if in_dtype == torch.float32 else out.to(in_dtype)
+        if self.aleatoric_loss:
+            mu, s = res.split(self.num_classes, 1)  # unet3D_module.py:367-369
+            return mu, s
+        return res

@@ -183,6 +183,10 @@ typedef struct vx_unet3d_run {
 
 size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F);
 int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream);
+/* Diagnostic (bench.py roofline leg; the one entry point that synchronises): the same forward with a HIP event
+ * pair around every launch on `stream`; returns per-launch milliseconds and static label strings. */
+int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream,
+                               int max_launches, float* ms, const char** labels, int* n_launches);
 
 /* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).

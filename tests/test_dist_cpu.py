@@ -1,0 +1,73 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py (shard volumes, gather maps on rank 0)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from values_amd.dist import gather_maps, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_maps(lo, hi):
+    v = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1)
+    sp = (4, 4, 4)
+    return {"pred_entropy": v.expand(-1, *sp) + 0.1, "aleatoric_uncertainty": v.expand(-1, *sp) + 0.2,
+            "epistemic_uncertainty": v.expand(-1, *sp) + 0.3,
+            "mean_softmax": torch.stack([v.expand(-1, *sp) + 0.4, v.expand(-1, *sp) + 0.5], 1),
+            "pred_seg_mean": (torch.arange(lo, hi).view(-1, 1, 1, 1).expand(-1, *sp) % 2).to(torch.uint8)}
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_vol = 6
+    lo, hi = shard_range(n_vol, world, rank)
+    for _ in range(2):  # twice: the receive buffers are cached
+        res = gather_maps(_fake_maps(lo, hi), world, rank)
+    if rank == 0:
+        ref = _fake_maps(0, n_vol)
+        ok = all(torch.equal(res[k], ref[k]) for k in ref)
+        q.put(ok)
+    else:
+        q.put(res is None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 5, 8, 17):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_maps_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
+
+
+def test_gather_maps_world1_is_identity():
+    m = _fake_maps(0, 3)
+    assert gather_maps(m, 1, 0) is m

@@ -247,10 +247,11 @@ def test_conv1x1_slots_and_unflip():
     dst = [3, 0, 5, 2]
     out = torch.full((6, c, d, h, w), -77.0, dtype=torch.float32, device=dev())
     xd = cl(x.float()).to(dev())
-    _lib.check(lib.vx_conv1x1_ncdhw(_lib.ptr(xd), f, _lib.ptr(wt.float().to(dev())), _lib.ptr(b.float().to(dev())),
-                                    _lib.ptr(out), n, d, h, w, f, c,
-                                    _lib.ptr(torch.tensor(dst, dtype=torch.int32, device=dev())),
-                                    _lib.ptr(torch.tensor(flips, dtype=torch.int32, device=dev())), _lib.stream_ptr()), "1x1")
+    wd, bd = wt.float().to(dev()), b.float().to(dev())  # keep every device tensor alive across the launch
+    dst_d = torch.tensor(dst, dtype=torch.int32, device=dev())
+    flip_d = torch.tensor(flips, dtype=torch.int32, device=dev())
+    _lib.check(lib.vx_conv1x1_ncdhw(_lib.ptr(xd), f, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), n, d, h, w, f, c,
+                                    _lib.ptr(dst_d), _lib.ptr(flip_d), _lib.stream_ptr()), "1x1")
     torch.cuda.synchronize()
     ref = torch.einsum("nfdhw,cf->ncdhw", x.float().double(), wt.float().double()) + b.float().double().view(1, -1, 1, 1, 1)
     for i in range(n):

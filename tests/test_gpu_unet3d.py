@@ -175,20 +175,38 @@ def test_full_size_properties_64_T10():
     assert (a["mean_softmax"] - c["mean_softmax"]).abs().mean().item() < 0.05
 
 
-def test_hash_dropout_matches_oracle_statistics_32():
-    """With T large the MC-dropout mean probability from OUR bit generator must agree with the mean the
-    reference's masks produce (golden, T=4) to within sampling error: same distribution, different stream."""
-    from values_amd import predict_uncertainty
-    g = load_npz("unet3d_32.npz")
+def test_hash_dropout_is_the_same_distribution_as_torch_dropout_16():
+    """Our dropout bit generator cannot reproduce torch's CPU bernoulli stream ("Dropout RNG parity"),
+    so compare DISTRIBUTIONS: the oracle with T_ref independent numpy-drawn Bernoulli(0.5) masks vs our hash
+    dropout with T_ours samples.  Per voxel the two sample means differ by sampling error only:
+    E[(m_ours - m_ref)^2] = var_v * (1/T_ours + 1/T_ref); the ratio of observed to predicted must be ~1."""
+    from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
+    from oracle import uncertainty_oracle as uo
+    from values_amd import predict_logits
+    g = load_npz("unet3d_16.npz")
+    T_ref, T_ours = 48, 768
+    sd = formula_sd_torch()
+    x = torch.from_numpy(g["input"]).double()
+    rng = np.random.default_rng(1234)
+    shapes = {n: tuple(int(v) for v in g[f"maskshape_{n}"]) for n in DROPOUT_ORDER}
+    ref_p = []
+    with torch.no_grad():
+        for _ in range(T_ref):
+            mk = {n: torch.from_numpy(rng.random(shapes[n]) < 0.5) for n in DROPOUT_ORDER}
+            ref_p.append(uo.softmax(unet3d_forward(sd, x, masks=mk).numpy(), axis=1)[0, 1])
+    ref_p = np.stack(ref_p)
     model = make_model(do_dropout=True)
-    x = torch.from_numpy(g["input"]).cuda()
-    out = predict_uncertainty([model], x, n_pred=64, seeds=[5])
-    ours = out["mean_softmax"][0, 1].cpu().numpy()
-    ref = g["mean_softmax"][1]
-    # voxelwise sd of a T=4 mean is ~ sd/2; compare global statistics instead
-    assert abs(ours.mean() - ref.mean()) < 0.01
-    assert abs(out["aleatoric_uncertainty"][0].mean().item() - g["aleatoric_uncertainty"].mean()) < 0.01
-    assert np.corrcoef(ours.ravel(), ref.ravel())[0, 1] > 0.8
+    lg = predict_logits([model], x.float().cuda(), n_pred=T_ours, seeds=[9])
+    ours_p = torch.softmax(lg[0].double(), 1)[:, 1].cpu().numpy()
+    var = ours_p.var(axis=0) + 1e-12
+    d2 = (ours_p.mean(0) - ref_p.mean(0)) ** 2
+    ratio = float((d2 / var).mean() / (1.0 / T_ours + 1.0 / T_ref))
+    assert 0.7 < ratio < 1.4, ratio
+    # second moment too: per-voxel variances agree (F-ratio averaged over voxels ~ 1)
+    vr = float((ref_p.var(axis=0, ddof=1) / ours_p.var(axis=0, ddof=1)).mean())
+    assert 0.85 < vr < 1.15, vr
+    # and the reference's own T=4 golden maps sit inside the same distribution
+    assert abs(ours_p.mean() - g["mean_softmax"][1].mean()) < 0.01
 
 
 def test_aleatoric_head_and_errors():

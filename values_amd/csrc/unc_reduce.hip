@@ -267,11 +267,11 @@ static int launch_unc(const TIn* x, int from_logits, int B, int T, int C, int64_
 extern "C" int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
                              float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
                              uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream) {
-  if (!x || !pred_entropy || !exp_entropy || !mutual_info) VX_FAIL(VX_E_NULL, "vx_unc_reduce: null pointer");
   if (B <= 0 || T <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: B=%d T=%d C=%d nvox=%lld", B, T, C, (long long)nvox);
+  if (nvox == 0) return VX_OK;  // empty volume: nothing to do (the reference returns empty maps)
+  if (!x || !pred_entropy || !exp_entropy || !mutual_info) VX_FAIL(VX_E_NULL, "vx_unc_reduce: null pointer");
   if (C > 255 && (argmax || sample_argmax)) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: uint8 argmax needs C <= 255");
   if (dtype != VX_F32 && dtype != VX_F64) VX_FAIL(VX_E_DTYPE, "vx_unc_reduce: dtype %d", dtype);
-  if (nvox == 0) return VX_OK;  // empty volume: nothing to do (the reference returns empty maps)
   hipStream_t s = (hipStream_t)stream;
   const bool al = vx_aligned16(x) && vx_aligned16(pred_entropy) && vx_aligned16(exp_entropy) && vx_aligned16(mutual_info) &&
                   (!mean_prob || vx_aligned16(mean_prob)) && (!argmax || (((uintptr_t)argmax) & 3u) == 0) &&

@@ -71,10 +71,35 @@ extern "C" size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F) {
   return p.bytes;
 }
 
+// Optional per-launch timing (vx_unet3d_forward_profiled): a HIP event pair around every launch, on the
+// caller's stream.  Off (g_prof == nullptr) in normal and captured runs.
+namespace {
+struct Prof {
+  static constexpr int MAXL = 96;
+  hipEvent_t ev[2 * MAXL];
+  const char* name[MAXL];
+  int n = 0;
+  hipStream_t s;
+};
+thread_local Prof* g_prof = nullptr;
+}  // namespace
+
 #define VX_TRY(expr)            \
   do {                          \
     int rc_ = (expr);           \
     if (rc_ != VX_OK) return rc_; \
+  } while (0)
+
+#define VX_STEP(label, expr)                                                       \
+  do {                                                                             \
+    Prof* pf_ = g_prof;                                                            \
+    if (pf_ && pf_->n < Prof::MAXL) hipEventRecord(pf_->ev[2 * pf_->n], pf_->s);    \
+    int rc_ = (expr);                                                              \
+    if (rc_ != VX_OK) return rc_;                                                  \
+    if (pf_ && pf_->n < Prof::MAXL) {                                              \
+      hipEventRecord(pf_->ev[2 * pf_->n + 1], pf_->s);                             \
+      pf_->name[pf_->n++] = (label);                                               \
+    }                                                                              \
   } while (0)
 
 extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream) {
@@ -143,6 +168,14 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     return vx_convT_k2s2(&a, stream);
   };
 
+  static const char* kConv[18] = {"contr_1_1", "contr_1_2", "contr_2_1", "contr_2_2", "contr_3_1", "contr_3_2",
+                                  "contr_4_1", "contr_4_2", "center.0", "center.2", "expand_4_1", "expand_4_2",
+                                  "expand_3_1", "expand_3_2", "expand_2_1", "expand_2_2", "expand_1_1", "expand_1_2"};
+  static const char* kNorm[8] = {"norm:contr_1_1", "norm:contr_1_2", "norm:contr_2_1", "norm:contr_2_2",
+                                 "norm:contr_3_1", "norm:contr_3_2", "norm:contr_4_1", "norm:contr_4_2"};
+  static const char* kFin[8] = {"finalize:contr_1_1", "finalize:contr_1_2", "finalize:contr_2_1", "finalize:contr_2_2",
+                                "finalize:contr_3_1", "finalize:contr_3_2", "finalize:contr_4_1", "finalize:contr_4_2"};
+  static const char* kUp[4] = {"center.4", "upscale4", "upscale3", "upscale2"};
   // ---------------- encoder ----------------
   for (int l = 0; l < 4; ++l) {
     const Level& L = p.lv[l];
@@ -150,26 +183,26 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     int ntiles;
     if (l == 0) {
       ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
-      VX_TRY(vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, r->repeat > 0 ? r->repeat : 1,
-                             r->src, r->flip, p.stats, stream));
+      VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C,
+                                        r->repeat > 0 ? r->repeat : 1, r->src, r->flip, p.stats, stream));
     } else {
       ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
-      VX_TRY(conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats));
+      VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats));
     }
-    VX_TRY(vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-    VX_TRY(norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l));
+    VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+    VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l));
     ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
-    VX_TRY(conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats));
-    VX_TRY(vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-    VX_TRY(norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1));
+    VX_STEP(kConv[2 * l + 1], conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats));
+    VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+    VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1));
   }
   // ---------------- center ----------------
   {
     const Level& L4 = p.lv[4];
     const int C3 = p.lv[3].C, C4 = L4.C;
-    VX_TRY(conv(p.P[4], C3, 8, p.C0, C4, 0, L4, C3, C4, VX_ACT_RELU, -1, nullptr));
-    VX_TRY(conv(p.C0, C4, 9, p.C1, C4, 0, L4, C4, C4, VX_ACT_RELU, -1, nullptr));
-    VX_TRY(convT(p.C1, 0, p.CAT[3], 2 * C3, L4, C4, C3, VX_ACT_RELU, 8));
+    VX_STEP(kConv[8], conv(p.P[4], C3, 8, p.C0, C4, 0, L4, C3, C4, VX_ACT_RELU, -1, nullptr));
+    VX_STEP(kConv[9], conv(p.C0, C4, 9, p.C1, C4, 0, L4, C4, C4, VX_ACT_RELU, -1, nullptr));
+    VX_STEP(kUp[0], convT(p.C1, 0, p.CAT[3], 2 * C3, L4, C4, C3, VX_ACT_RELU, 8));
   }
   // ---------------- decoder ----------------
   for (int l = 3; l >= 0; --l) {
@@ -177,11 +210,43 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int C = L.C;
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
-    VX_TRY(conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr));
-    VX_TRY(conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr));
-    if (l > 0) VX_TRY(convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
+    VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr));
+    VX_STEP(kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr));
+    if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------
-  VX_TRY(vx_conv1x1_ncdhw(p.B[0], F, w->final_w, w->final_b, r->logits, N, D, H, W, F, NC, r->dst, r->flip, stream));
+  VX_STEP("final", vx_conv1x1_ncdhw(p.B[0], F, w->final_w, w->final_b, r->logits, N, D, H, W, F, NC, r->dst, r->flip, stream));
   return VX_OK;
+}
+
+// Diagnostic entry for bench.py's roofline leg: runs the forward eagerly with a HIP event pair around every
+// launch on `stream`, synchronises the stream, and returns per-launch milliseconds and labels.
+extern "C" int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* r, vx_stream_t stream,
+                                          int max_launches, float* ms, const char** labels, int* n_launches) {
+  if (!ms || !labels || !n_launches) VX_FAIL(VX_E_NULL, "vx_unet3d_forward_profiled: null output");
+  Prof pf;
+  pf.s = (hipStream_t)stream;
+  for (int i = 0; i < 2 * Prof::MAXL; ++i) {
+    hipError_t e = hipEventCreate(&pf.ev[i]);
+    if (e != hipSuccess) VX_FAIL((int)e, "hipEventCreate: %s", hipGetErrorString(e));
+  }
+  g_prof = &pf;
+  int rc = vx_unet3d_forward(w, r, stream);
+  g_prof = nullptr;
+  if (rc == VX_OK) {
+    hipError_t e = hipStreamSynchronize(pf.s);
+    if (e != hipSuccess) { vx_set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
+  int n = 0;
+  if (rc == VX_OK) {
+    for (; n < pf.n && n < max_launches; ++n) {
+      float t = 0.f;
+      hipEventElapsedTime(&t, pf.ev[2 * n], pf.ev[2 * n + 1]);
+      ms[n] = t;
+      labels[n] = pf.name[n];
+    }
+  }
+  *n_launches = n;
+  for (int i = 0; i < 2 * Prof::MAXL; ++i) hipEventDestroy(pf.ev[i]);
+  return rc;
 }

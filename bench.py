@@ -156,7 +156,22 @@ def cpu_baseline_leg(T=10, passes=2):
     from oracle import uncertainty_oracle as uo
     from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
     from values_amd.formula import formula_unet3d_state_dict
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    sd0 = {k: torch.from_numpy(v) for k, v in formula_unet3d_state_dict().items()}
+    # pick the thread count that is fastest on a 32^3 pass (oneDNN/ATen float64 conv3d slows down when
+    # oversubscribed: 256 threads were 3x slower than 8 on the first GPU-box run)
+    cand = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+    xs = torch.randn((1, 1, 32, 32, 32), dtype=torch.float64)
+    best, cores = None, cand[0]
+    for c in cand:
+        torch.set_num_threads(c)
+        with torch.no_grad():
+            unet3d_forward(sd0, xs)
+            t0 = time.perf_counter()
+            unet3d_forward(sd0, xs)
+            dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, c
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in formula_unet3d_state_dict().items()}
     g = torch.Generator().manual_seed(123)
@@ -178,7 +193,7 @@ def cpu_baseline_leg(T=10, passes=2):
     return {"value": round(vps, 5), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{passes} of the {T} float64 MC-dropout forwards of one 64^3 volume ({t_pass:.2f} s/pass) + "
                       f"one T={T} entropy/MI reduction ({t_red:.2f} s), extrapolated to a whole volume; "
-                      f"torch {torch.__version__} CPU, {cores} threads"}
+                      f"torch {torch.__version__} CPU, {cores} of {ncpu} host threads (fastest of {cand} on a 32^3 pass)"}
 
 
 def main():

@@ -93,11 +93,11 @@ thread_local Prof* g_prof = nullptr;
 #define VX_STEP(label, expr)                                                       \
   do {                                                                             \
     Prof* pf_ = g_prof;                                                            \
-    if (pf_ && pf_->n < Prof::MAXL) hipEventRecord(pf_->ev[2 * pf_->n], pf_->s);    \
+    if (pf_ && pf_->n < Prof::MAXL) (void)hipEventRecord(pf_->ev[2 * pf_->n], pf_->s);    \
     int rc_ = (expr);                                                              \
     if (rc_ != VX_OK) return rc_;                                                  \
     if (pf_ && pf_->n < Prof::MAXL) {                                              \
-      hipEventRecord(pf_->ev[2 * pf_->n + 1], pf_->s);                             \
+      (void)hipEventRecord(pf_->ev[2 * pf_->n + 1], pf_->s);                             \
       pf_->name[pf_->n++] = (label);                                               \
     }                                                                              \
   } while (0)
@@ -241,12 +241,12 @@ extern "C" int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_u
   if (rc == VX_OK) {
     for (; n < pf.n && n < max_launches; ++n) {
       float t = 0.f;
-      hipEventElapsedTime(&t, pf.ev[2 * n], pf.ev[2 * n + 1]);
+      (void)hipEventElapsedTime(&t, pf.ev[2 * n], pf.ev[2 * n + 1]);
       ms[n] = t;
       labels[n] = pf.name[n];
     }
   }
   *n_launches = n;
-  for (int i = 0; i < 2 * Prof::MAXL; ++i) hipEventDestroy(pf.ev[i]);
+  for (int i = 0; i < 2 * Prof::MAXL; ++i) (void)hipEventDestroy(pf.ev[i]);
   return rc;
 }

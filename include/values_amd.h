@@ -131,6 +131,10 @@ typedef struct vx_norm_args {
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask;
 } vx_norm_args;
 int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
+/* Same, but sample n of the OUTPUT reads sample n / x_repeat of x / mean / rstd: the T MC-dropout samples of a
+ * volume share contr_1_1's conv output and statistics (test_3D.py:462-472 feeds the same input T times; dropout
+ * is the first thing that differs), so that conv runs once per volume and this kernel fans it out. */
+int vx_norm_act_drop_pool_bcast(const vx_norm_args* a, int x_repeat, vx_stream_t stream);
 
 /* K6: ConvTranspose3d(k=2, s=2) (+ReLU+Dropout for center.4), unet3D_module.py:113-120, 157-190;
  * writes channels [out_coff, out_coff+Cout) of the concat buffer (K7: torch.cat disappears). */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vx_instnorm_finalize": (_i, [_p, _i, _i, _i, _i64, C.c_float, _p, _p, _p]),
     "vx_norm_act_drop_pool": (_i, [C.POINTER(NormArgs), _p]),
+    "vx_norm_act_drop_pool_bcast": (_i, [C.POINTER(NormArgs), _i, _p]),
     "vx_convT_k2s2": (_i, [C.POINTER(ConvTArgs), _p]),
     "vx_conv1x1_ncdhw": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vx_unet3d_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),

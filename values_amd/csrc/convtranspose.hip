@@ -71,6 +71,66 @@ __global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_
   }
 }
 
+// Row-streaming variant for the two large up-convolutions (Cin <= 32): one thread = one 16-byte piece of an
+// OUTPUT row, consecutive lanes = consecutive pieces, so every store instruction of a wave is one contiguous
+// 1 KiB segment; the thread's (dx, channel quad) is fixed by its lane, so its Cin x 4 weights live in registers
+// for the whole kernel and the inner loop is FMAs only.  blockIdx.y = (dz, dy).
+template <int CIN>
+__global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, int64_t total) {
+  const int dzy = blockIdx.y, dz = dzy >> 1, dy = dzy & 1;
+  const int C4 = a.Cout / 4;
+  const int OW = a.W * 2, OH = a.H * 2, OD = a.D * 2;
+  const int PW = OW * C4;  // pieces per output row
+  const int tid = threadIdx.x;
+  const int cq = tid % C4, dx = (tid / C4) & 1;  // fixed per thread: 256 and PW are multiples of 2*C4
+  f32x4 wreg[CIN];
+  {
+    const float* wp = a.w_packed + (size_t)dzy * CIN * 2 * a.Cout + dx * a.Cout + cq * 4;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) wreg[ci] = *reinterpret_cast<const f32x4*>(wp + (size_t)ci * 2 * a.Cout);
+  }
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + cq * 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + tid; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int p = (int)(r % PW); r /= PW;
+    const int y = (int)(r % a.H); r /= a.H;
+    const int z = (int)(r % a.D); r /= a.D;
+    const int n = (int)r;
+    const int ox = p / C4, x = ox >> 1;
+    const float* __restrict__ xin = a.in + (((size_t)(n * a.D + z) * a.H + y) * a.W + x) * a.in_pitch;
+    f32x4 xv[CIN / 4];
+#pragma unroll
+    for (int k = 0; k < CIN / 4; ++k) xv[k] = *reinterpret_cast<const f32x4*>(xin + 4 * k);
+    f32x4 acc = b4;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float xs = xv[ci >> 2][ci & 3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(wreg[ci][j], xs, acc[j]);
+    }
+    const int oz = 2 * z + dz, oy = 2 * y + dy;
+    const size_t ovox = ((size_t)(n * OD + oz) * OH + oy) * OW + ox;
+    if (a.act == VX_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    } else if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.01f * acc[j]);
+    }
+    if (a.drop_mode == VX_DROP_HASH) {
+      const uint32_t e = (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + cq * 4);
+      const uint32_t bits = vx_drop_bits4(vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n), e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+    } else if (a.drop_mode == VX_DROP_MASK) {
+      const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + ovox * a.Cout + cq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * acc[j] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.out + ovox * a.out_pitch + a.out_coff + cq * 4) = acc;
+  }
+}
+
 __global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int64_t total) {
   // torch (Cin, Cout, 2,2,2) -> [dz][dy][ci][dx][co]
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -112,6 +172,19 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_ALIGN, "vx_convT_k2s2: pitches/offsets must be multiples of 4 floats");
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: mask mode without mask");
   if ((int64_t)a.D * a.H * a.W * 8 * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: sample too large");
+  // large, shallow up-convolutions: row-streaming kernel (needs 256 % (2*Cout/4) == 0 and Cout <= 128)
+  if ((a.Cin == 16 || a.Cin == 32) && a.Cout <= 128 && 256 % (2 * (a.Cout / 4)) == 0) {
+    const int64_t total = (int64_t)a.N * a.D * a.H * (2 * a.W) * (a.Cout / 4);
+    int bx = (int)((total + 255) / 256);
+    if (bx > 4096) bx = 4096;
+    dim3 grid((unsigned)bx, 4);
+    if (a.Cin == 16)
+      hipLaunchKernelGGL(convT_k2s2_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a, total);
+    else
+      hipLaunchKernelGGL(convT_k2s2_rows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a, total);
+    VX_CHECK_LAUNCH("vx_convT_k2s2");
+    return VX_OK;
+  }
   const int64_t nvox = (int64_t)a.N * a.D * a.H * a.W;
   int bx = (int)((nvox + 255) / 256);
   if (bx > 8192) bx = 8192;

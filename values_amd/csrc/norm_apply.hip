@@ -40,69 +40,98 @@ extern "C" int vx_instnorm_finalize(const float* stats_partial, int N, int ntile
   return VX_OK;
 }
 
-// One thread = one 2x2x2 voxel block x 4 channels (8 x 16-byte loads, 8 stores, 1 pooled store) when
-// POOL; one voxel x 4 channels otherwise.
+// One thread = one 16-byte piece (4 channels of one voxel) of a full-resolution ROW; consecutive lanes hold
+// consecutive pieces, so every load/store instruction of a wave is one contiguous 1 KiB segment of the row.
+// POOL: the thread handles the same piece of the 4 rows (2z+dz, 2y+dy) of a 2x2 row bundle, takes their max,
+// exchanges with the lane that holds the x-neighbour voxel (C/4 lanes away: one cross-lane shuffle) and the
+// even-x lanes store the pooled piece.  Input sample = n / x_repeat: the T MC-dropout samples of a volume share
+// the first layer's conv output and statistics (same input, dropout comes after), so contr_1_1 is computed once
+// per volume and only this kernel fans it out into T differently-dropped copies.
 template <bool POOL>
-__global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a, int64_t total) {
+__global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a, int x_repeat, int64_t total) {
   const int C4 = a.C / 4;
+  const int PW = a.W * C4;  // pieces per row
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
-    const int q = r % C4; r /= C4;
-    const int c = q * 4;
-    int bx, by, bz, n;
+    const int p = (int)(r % PW); r /= PW;
+    const int x = p / C4, c = (p - x * C4) * 4;
+    int by, bz;
     if (POOL) {
-      bx = r % (a.W / 2); r /= (a.W / 2);
-      by = r % (a.H / 2); r /= (a.H / 2);
-      bz = r % (a.D / 2); r /= (a.D / 2);
+      by = (int)(r % (a.H / 2)); r /= (a.H / 2);
+      bz = (int)(r % (a.D / 2)); r /= (a.D / 2);
     } else {
-      bx = r % a.W; r /= a.W;
-      by = r % a.H; r /= a.H;
-      bz = r % a.D; r /= a.D;
+      by = (int)(r % a.H); r /= a.H;
+      bz = (int)(r % a.D); r /= a.D;
     }
-    n = (int)r;
+    const int n = (int)r;
+    const int ns = n / x_repeat;
     f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = (f32x4){1.f, 1.f, 1.f, 1.f};
     if (a.mean) {
-      mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)n * a.C + c);
-      rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)n * a.C + c);
+      mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)ns * a.C + c);
+      rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)ns * a.C + c);
     }
     const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
     f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    constexpr int NV = POOL ? 8 : 1;
+    constexpr int NR = POOL ? 4 : 1;
+    f32x4 v[NR];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int z = POOL ? bz * 2 + (k >> 2) : bz;
-      const int y = POOL ? by * 2 + ((k >> 1) & 1) : by;
-      const int x = POOL ? bx * 2 + (k & 1) : bx;
+    for (int k = 0; k < NR; ++k) {
+      const int z = POOL ? bz * 2 + (k >> 1) : bz;
+      const int y = POOL ? by * 2 + (k & 1) : by;
+      const size_t svox = ((size_t)(ns * a.D + z) * a.H + y) * a.W + x;
+      v[k] = *reinterpret_cast<const f32x4*>(a.x + svox * a.x_pitch + c);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int z = POOL ? bz * 2 + (k >> 1) : bz;
+      const int y = POOL ? by * 2 + (k & 1) : by;
       const size_t vox = ((size_t)(n * a.D + z) * a.H + y) * a.W + x;
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + vox * a.x_pitch + c);
-      v = (v - mu) * rs;
+      f32x4 t = (v[k] - mu) * rs;
+      if (a.act == VX_ACT_LRELU) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = vx_act(v[j], a.act);
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.01f * t[j]);
+      } else if (a.act == VX_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f);
+      }
       if (a.drop_mode == VX_DROP_HASH) {
         const uint32_t e = (uint32_t)(((z * a.H + y) * a.W + x) * a.C + c);
         const uint32_t bits = vx_drop_bits4(dkey, e);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ((bits >> j) & 1u) ? 2.f * v[j] : 0.f;
+        for (int j = 0; j < 4; ++j) t[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);  // keep ? 2.0f : 0.0f
       } else if (a.drop_mode == VX_DROP_MASK) {
         const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + vox * a.C + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+        for (int j = 0; j < 4; ++j) t[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * t[j] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(a.out + vox * a.out_pitch + a.out_coff + c) = v;
+      *reinterpret_cast<f32x4*>(a.out + vox * a.out_pitch + a.out_coff + c) = t;
       if (POOL) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], v[j]);
+        for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], t[j]);
       }
     }
     if (POOL) {
-      const size_t pv = ((size_t)(n * (a.D / 2) + bz) * (a.H / 2) + by) * (a.W / 2) + bx;
-      *reinterpret_cast<f32x4*>(a.pool_out + pv * a.pool_pitch + c) = mx;
+      // x-neighbour voxel's piece with the same channels sits C4 pieces (= lanes) away
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(mx[j], C4, 64);
+      if ((x & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], o[j]);
+        const size_t pv = ((size_t)(n * (a.D / 2) + bz) * (a.H / 2) + by) * (a.W / 2) + (x >> 1);
+        *reinterpret_cast<f32x4*>(a.pool_out + pv * a.pool_pitch + c) = mx;
+      }
     }
   }
 }
 
 extern "C" int vx_norm_act_drop_pool(const vx_norm_args* ap, vx_stream_t stream) {
+  return vx_norm_act_drop_pool_bcast(ap, 1, stream);
+}
+
+extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat, vx_stream_t stream) {
   if (!ap) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null args");
+  if (x_repeat < 1) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: x_repeat must be >= 1");
   const vx_norm_args& a = *ap;
   if (!a.x || !a.out) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null tensor");
   if ((a.mean == nullptr) != (a.rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: mean/rstd must come together");
@@ -116,15 +145,19 @@ extern "C" int vx_norm_act_drop_pool(const vx_norm_args* ap, vx_stream_t stream)
   if (a.pool_out) {
     if (a.D % 2 || a.H % 2 || a.W % 2) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: pooling needs even dims");
     if (a.pool_pitch % 4 || a.pool_pitch < a.C) VX_FAIL(VX_E_ALIGN, "vx_norm_act_drop_pool: pool pitch");
-    const int64_t total = (int64_t)a.N * (a.D / 2) * (a.H / 2) * (a.W / 2) * (a.C / 4);
+    // the x-pair exchange is a shuffle over C/4 lanes: both voxels of a pair must sit in one wave, i.e. the
+    // pieces of a row must not straddle a 64-lane boundary mid-pair: (W*C/4) % (2*C/4) == 0 always holds (W even)
+    // and a wave starts at a multiple of 64 pieces, which is a multiple of 2*C/4 when C/4 divides 32
+    if (a.C / 4 > 32 || (32 % (a.C / 4)) != 0)
+      VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: pooling needs C/4 to divide 32 (C = %d)", a.C);
+    const int64_t total = (int64_t)a.N * (a.D / 2) * (a.H / 2) * a.W * (a.C / 4);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, a, total);
+    hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, a, x_repeat, total);
   } else {
     const int64_t total = (int64_t)a.N * a.D * a.H * a.W * (a.C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, a, total);
+    hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, a, x_repeat, total);
   }
   VX_CHECK_LAUNCH("vx_norm_act_drop_pool");
   return VX_OK;

@@ -145,7 +145,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     return vx_conv3d_k3(&a, stream);
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
-                  int drop_layer) {
+                  int drop_layer, int x_repeat) {
     vx_norm_args a;
     a.x = x; a.x_pitch = C; a.mean = p.mean; a.rstd = p.rstd;
     a.out = out; a.out_pitch = out_pitch; a.out_coff = out_coff;
@@ -153,7 +153,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.C = C;
     a.act = VX_ACT_LRELU; a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = (uint32_t)drop_layer;
     a.drop_mask = mask(drop_layer);
-    return vx_norm_act_drop_pool(&a, stream);
+    return vx_norm_act_drop_pool_bcast(&a, x_repeat, stream);
   };
   auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
                    int drop_layer) {
@@ -183,18 +183,31 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     int ntiles;
     if (l == 0) {
       ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
-      VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C,
-                                        r->repeat > 0 ? r->repeat : 1, r->src, r->flip, p.stats, stream));
+      const int rep = r->repeat > 0 ? r->repeat : 1;
+      if (!r->src && !r->flip && rep > 1 && N % rep == 0) {
+        // MC-dropout: the T samples of a volume share this conv and its statistics -> once per volume into a
+        // scratch (CAT_0 is free until contr_1_2's norm), fanned out by the norm kernel
+        const int V = N / rep;
+        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.CAT[0], C, V, L.D, L.H, L.W, C, 1, nullptr,
+                                          nullptr, p.stats, stream));
+        VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+        VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep));
+      } else {
+        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, rep, r->src,
+                                          r->flip, p.stats, stream));
+        VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+        VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1));
+      }
     } else {
       ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats));
+      VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+      VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1));
     }
-    VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-    VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l));
     ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
     VX_STEP(kConv[2 * l + 1], conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats));
     VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-    VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1));
+    VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1));
   }
   // ---------------- center ----------------
   {

@@ -91,7 +91,8 @@ int vx_pack_convT_k2s2(const float* w_torch, float* w_packed, int Cin, int Cout,
  * for vx_instnorm_finalize when it has.
  */
 typedef struct vx_conv3d_args {
-  const float* in;      /* [N][D][H][W][in_pitch], channels [0, Cin) used; Cin % 8 == 0 */
+  const float* in;      /* in_xblk == 0: [N][D][H][W][in_pitch], channels [0, Cin) used; Cin % 8 == 0
+                         * in_xblk  > 0: x-blocked concat buffer [N][D][H][W/xb][2][xb][Cin/2] (see vx_concat layout) */
   const float* w_packed;
   const float* bias;    /* [Cout] */
   float* out;           /* [N][D][H][W][out_pitch], written at channel offset out_coff */
@@ -102,8 +103,14 @@ typedef struct vx_conv3d_args {
   uint32_t drop_seed, drop_layer;
   const uint8_t* drop_mask; /* [N][D][H][W][Cout] when VX_DROP_MASK */
   float* stats_partial; /* nullable: [N][ntiles][Cout][2] (sum, sumsq of out before act) */
+  int32_t in_xblk;      /* 0 = plain input; 1, 2 or 4 = x-block size of a concat input */
 } vx_conv3d_args;
-int vx_conv3d_k3_tiles(int D, int H, int W);  /* ntiles per sample for stats_partial sizing */
+/* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
+ * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
+ * skip half (s = 1, written by vx_norm_act_drop_pool) as alternating DENSE blocks of xb voxels, so both producers
+ * write whole cache lines and the consumer conv reads it through in_xblk.  xb = largest of {4,2,1} dividing W. */
+int vx_conv3d_k3_tiles(int D, int H, int W);  /* upper bound of ntiles per sample (stats_partial sizing) */
+int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout); /* exact ntiles for a given Cout (finalize) */
 int vx_conv3d_k3(const vx_conv3d_args* a, vx_stream_t stream);
 
 /* First layer, Cin == 1 (contr_1_1): input is the reference's (V,1,D,H,W) volume batch.
@@ -129,6 +136,8 @@ typedef struct vx_norm_args {
   float* pool_out; int32_t pool_pitch;
   int32_t N, D, H, W, C;
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask;
+  int32_t out_xblk, out_half; /* out_xblk > 0: `out` is a concat buffer (xb = out_xblk), this kernel writes half
+                                 out_half (0 = up, 1 = skip); out_pitch / out_coff are then ignored */
 } vx_norm_args;
 int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
 /* Same, but sample n of the OUTPUT reads sample n / x_repeat of x / mean / rstd: the T MC-dropout samples of a
@@ -144,6 +153,7 @@ typedef struct vx_convT_args {
   float* out; int32_t out_pitch, out_coff;
   int32_t N, D, H, W, Cin, Cout; /* input dims; output is 2D x 2H x 2W */
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* mask [N][2D][2H][2W][Cout] */
+  int32_t out_xblk, out_half; /* as in vx_norm_args: write half out_half of a concat buffer */
 } vx_convT_args;
 int vx_convT_k2s2(const vx_convT_args* a, vx_stream_t stream);
 

@@ -28,13 +28,28 @@ def ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
+def to_xblk(up, skip, xb):
+    """(N,C,D,H,W) up & skip -> concat buffer [N][D][H][W/xb][2][xb][C] (flat last dims)"""
+    n, c, d, h, w = up.shape
+    u = cl(up).reshape(n, d, h, w // xb, 1, xb, c)
+    k = cl(skip).reshape(n, d, h, w // xb, 1, xb, c)
+    return torch.cat([u, k], 4).contiguous()
+
+
+def from_xblk(buf, half, n, c, d, h, w, xb):
+    return ncdhw(buf.reshape(n, d, h, w // xb, 2, xb, c)[:, :, :, :, half].reshape(n, d, h, w, c))
+
+
 def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=False, in_pitch=None, out_pitch=None,
-             out_coff=0):
+             out_coff=0, xblk=0):
     """x (N,Cin,D,H,W) f32 cpu, w torch layout -> (out NCDHW cpu, stats or None)"""
     lib = _lib.load()
     N, Cin, D, H, W = x.shape
     Cout = w.shape[0]
-    xd = cl(x.float()).to(dev())
+    if xblk:
+        xd = to_xblk(x[:, :Cin // 2].float(), x[:, Cin // 2:].float(), xblk).to(dev())
+    else:
+        xd = cl(x.float()).to(dev())
     if in_pitch and in_pitch > Cin:
         pad = torch.full((N, D, H, W, in_pitch - Cin), 7.0, device=dev())  # garbage channels must be ignored
         xd = torch.cat([xd, pad], -1).contiguous()
@@ -51,13 +66,15 @@ def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=Fals
     a.in_pitch, a.out_pitch, a.out_coff = in_pitch, out_pitch, out_coff
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, D, H, W, Cin, Cout
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop_mode, seed, layer
+    a.in_xblk = xblk
     md = None
     if mask is not None:
         md = cl(mask).to(torch.uint8).to(dev())
         a.drop_mask = md.data_ptr()
     st = None
     if stats:
-        nt = lib.vx_conv3d_k3_tiles(D, H, W)
+        nt = lib.vx_conv3d_k3_tiles_for(D, H, W, Cout)
+        assert nt <= lib.vx_conv3d_k3_tiles(D, H, W)
         st = torch.zeros((N, nt, Cout, 2), dtype=torch.float32, device=dev())
         a.stats_partial = st.data_ptr()
     _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
@@ -74,6 +91,8 @@ def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=Fals
     (24, 8, (1, 4, 8, 16)),   # Cin multiple of 8 only -> CB=8 path
     (8, 8, (1, 6, 10, 20)),   # ragged: not a multiple of the workgroup tile
     (16, 16, (1, 3, 5, 9)),   # ragged small
+    (8, 8, (2, 8, 8, 64)), (16, 8, (1, 4, 4, 32)), (16, 8, (1, 5, 7, 38)),  # x-pair packing, full and ragged tiles
+    (8, 8, (1, 3, 3, 7)), (16, 8, (2, 2, 2, 2)),                            # x-pair, odd width / tiny
 ])
 def test_conv3d_k3_matches_oracle(cin, cout, shape):
     n, d, h, w = shape
@@ -104,6 +123,19 @@ def test_conv3d_k3_epilogue_act_mask_pitch():
     ref_relu = F.relu(F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1))
     got, _, _ = run_conv(x, wt, b, act=_lib.VX_ACT_RELU)
     assert (got.double() - ref_relu).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("c,cout,shape,xb", [(8, 8, (2, 8, 8, 32), 4), (16, 16, (1, 4, 8, 16), 4), (32, 32, (1, 4, 4, 8), 4),
+                                             (64, 64, (1, 6, 6, 6), 2), (8, 8, (1, 3, 5, 7), 1), (16, 16, (1, 4, 4, 12), 4)])
+def test_conv3d_k3_reads_xblocked_concat(c, cout, shape, xb):
+    """decoder conv on cat([up, skip]) (unet3D_module.py:332-334) reading the two halves from the x-blocked buffer"""
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, 2 * c, d, h, w), 115))
+    wt = torch.from_numpy(formula_tensor((cout, 2 * c, 3, 3, 3), 116, scale=(1.0 / (27 * 2 * c)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((cout,), 117, scale=0.2))
+    ref = F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1)
+    got, _, _ = run_conv(x, wt, b, xblk=xb)
+    assert (got.double() - ref).abs().max().item() < 2e-5
 
 
 def test_conv3d_k3_hash_dropout_statistics():
@@ -196,6 +228,16 @@ def test_convT_matches_oracle(cin, cout, shape):
         got = ncdhw(out[..., :cout]).cpu().double()
         assert (got - ref).abs().max().item() < 1e-5
         assert (out[..., cout:] == -77.0).all()
+        # the same into the up half of an x-blocked concat buffer
+        xb = 4 if (2 * w) % 4 == 0 else 2
+        cat = torch.full((n, 2 * d, 2 * h, (2 * w) // xb, 2, xb, cout), -77.0, dtype=torch.float32, device=dev())
+        a.out = cat.data_ptr(); a.out_xblk = xb; a.out_half = 0
+        _lib.check(lib.vx_convT_k2s2(C.byref(a), _lib.stream_ptr()), "convT")
+        torch.cuda.synchronize()
+        got = from_xblk(cat, 0, n, cout, 2 * d, 2 * h, 2 * w, xb).cpu().double()
+        assert (got - ref).abs().max().item() < 1e-5
+        assert (cat[:, :, :, :, 1] == -77.0).all()
+        a.out = out.data_ptr(); a.out_xblk = 0
 
 
 @pytest.mark.parametrize("c,shape,pool", [(8, (2, 8, 8, 16), True), (16, (1, 4, 6, 10), True), (8, (1, 3, 5, 7), False),
@@ -235,6 +277,21 @@ def test_instnorm_lrelu_drop_pool_matches_oracle(c, shape, pool):
         refp = F.max_pool3d(ref, 2, 2)
         gotp = ncdhw(pooled).cpu().double()
         assert (gotp - refp).abs().max().item() < 2e-5
+    # the same into the skip half of an x-blocked concat buffer, input broadcast over 3 output samples
+    xb = 4 if w % 4 == 0 else (2 if w % 2 == 0 else 1)
+    rep = 3
+    cat = torch.full((n * rep, d, h, w // xb, 2, xb, c), -77.0, dtype=torch.float32, device=dev())
+    mrep = mask.repeat_interleave(rep, 0)
+    md2 = cl(mrep).to(torch.uint8).to(dev())
+    a.out = cat.data_ptr(); a.out_xblk = xb; a.out_half = 1; a.N = n * rep; a.drop_mask = md2.data_ptr()
+    if pool:
+        pooled2 = torch.empty((n * rep, d // 2, h // 2, w // 2, c), dtype=torch.float32, device=dev())
+        a.pool_out = pooled2.data_ptr()
+    _lib.check(lib.vx_norm_act_drop_pool_bcast(C.byref(a), rep, _lib.stream_ptr()), "norm bcast")
+    torch.cuda.synchronize()
+    got = from_xblk(cat, 1, n * rep, c, d, h, w, xb).cpu().double()
+    assert (got - ref.repeat_interleave(rep, 0)).abs().max().item() < 2e-5
+    assert (cat[:, :, :, :, 0] == -77.0).all()
 
 
 def test_conv1x1_slots_and_unflip():

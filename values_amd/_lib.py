@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ("in_pitch", _i32), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32),
-                ("drop_mask", _p), ("stats_partial", _p)]
+                ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -35,14 +35,16 @@ class NormArgs(C.Structure):
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("pool_out", _p), ("pool_pitch", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
-                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
+                ("out_xblk", _i32), ("out_half", _i32)]
 
 
 class ConvTArgs(C.Structure):
     _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
-                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
+                ("out_xblk", _i32), ("out_half", _i32)]
 
 
 class UNet3DWeights(C.Structure):
@@ -67,6 +69,7 @@ SIGNATURES = {
     "vx_convT_k2s2_packed_floats": (_i64, [_i, _i]),
     "vx_pack_convT_k2s2": (_i, [_p, _p, _i, _i, _p]),
     "vx_conv3d_k3_tiles": (_i, [_i, _i, _i]),
+    "vx_conv3d_k3_tiles_for": (_i, [_i, _i, _i, _i]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -1,28 +1,45 @@
 // K1: 3x3x3 convolution (padding 1), channels-last fp32, as an implicit GEMM on the gfx950
 // fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, same numerics as VALU).
 //
-//   GEMM view:  D[cout][voxel] = sum_k  Wt[cout][k] * X[k][voxel],  k = (tap, cin)
+//   GEMM view:  D[row][col] = sum_k  A[row][k] * B[k][col]
 //   A operand = weights  (lane l holds A[row = l&15][k = l>>4])
 //   B operand = inputs   (lane l holds B[k = l>>4][col = l&15])
-//   D: lane l holds rows (l>>4)*4 + {0..3} of column l&15  -> 4 consecutive couts of one voxel,
-//      so the epilogue is ONE 16-byte store per lane and a wave writes 16 voxels x 64 B contiguously.
+//   D: lane l holds rows (l>>4)*4 + {0..3} of column l&15 -> 4 consecutive output channels of one voxel,
+//      so the epilogue is ONE 16-byte store per lane and a wave writes 1 KiB contiguously.
 //
-// Work split: a 256-thread workgroup (4 waves) owns an output tile of TX*TY*TZ voxels (a multiple
-// of 64) for 16*NT output channels.  Each wave owns R = TX*TY*TZ/64 "voxel tiles" of 16 voxels and
-// all NT channel tiles: R*NT independent accumulators (hides the 40-cycle dependent MFMA latency).
-// Cin is consumed in chunks of CB (8 or 16) channels: per chunk the halo'd input tile
-// [(TZ+2)(TY+2)(TX+2)][CB] and the chunk's weights [27][NT][64 lanes][CB/4] are staged in LDS;
-// a lane's CB/4 consecutive channels come from one ds_read_b128 (b64 for CB=8) and feed CB/4
-// MFMAs, so per tap a wave issues NT + R wide LDS reads for 4*R*NT (CB=16) MFMAs.
+// Two packings of the 16x16 tile:
+//   plain (XP = 0): rows = 16 output channels, cols = 16 voxels of an x-row, k = (kz,ky,kx, cin): 27*Cin.
+//   x-pair (XP = 1, Cout == 8): a 16-wide tile would be half padding, so two x-adjacent outputs share it:
+//      rows = (dx in {0,1}, cout 0..7), cols = 16 voxel PAIRS (x = 2p, 2p+1), k = (kz,ky, ix in 0..3, cin) where
+//      input x = 2p + ix - 1 and the weight is W[kx = ix - dx] (zero when ix - dx is outside 0..2).
+//      K grows by 4/3 while the columns cover twice the voxels: 1.5x fewer MFMAs (75 % dense instead of 50 %).
+//
+// Work split: a workgroup of NW waves owns an output tile of TXV x TY x TZ voxels (TXV = 16, or 32 for x-pair)
+// for 16*NT rows; each wave owns R column tiles and all NT row tiles: R*NT independent accumulators.
+// Cin is consumed in chunks of CB (8 or 16) channels: per chunk the halo'd input tile [HZ][HY][HX][CB] and the
+// chunk's weights [taps][NT][64 lanes][CB/4] sit in LDS; a lane's CB/4 consecutive channels come from one
+// ds_read_b128 (b64 for CB = 8) and feed CB/4 MFMAs.
+//
+// Schedule: persistent workgroups walk a flat list of (tile, chunk) work items.  While item i computes, the global
+// loads of item i+1 are already in flight into registers (buffer loads: out-of-volume halo pieces are steered
+// out of the descriptor's range and come back as zeros -- no branches, ~3 VALU per 16-byte piece); they are
+// committed to LDS after the barrier that ends item i.  Single-chunk layers keep their weights resident in LDS.
+// Non-MFMA instructions are the enemy here (they compete with the matrix pipe for the SIMD's issue port), so
+// everything per-lane that does not change between tiles is computed once per workgroup.
+//
+// Input layouts: plain [N][D][H][W][pitch], or the decoder's x-blocked concat buffer
+// [N][D][H][W/xb][2][xb][C] (up half, skip half as alternating dense blocks; see unet3d_forward.hip).
 //
 // Epilogue (fused): bias, then either (a) raw store + per-workgroup (sum, sumsq) partials for the
 // InstanceNorm that follows (contract blocks), or (b) LeakyReLU/ReLU + dropout (expand / center).
 #include "common.h"
 #include <stdlib.h>
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct ConvKArgs {
   vx_conv3d_args a;
-  int tiles_x, tiles_y, tiles_z, nchunks, prio_mode;
+  int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;  // floor(2^32 / tiles_*) + 1: exact t / tiles_* = umulhi(t, m) for t * tiles_* < 2^32
   unsigned long long* dbg;  // VX_CONV_STAMPS diagnostic builds only
 };
@@ -41,21 +58,27 @@ struct ConvKArgs {
 #define VX_STAMP(i) do {} while (0)
 #endif
 
+constexpr unsigned VX_OOB = 0xFFFFFFF0u;      // voffset beyond every descriptor's num_records
+constexpr unsigned VX_NUMREC = 0x80000000u;
 
-template <int CB, int NT, int TX, int TY, int TZ, int NW>
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   constexpr int NTH = 64 * NW;                     // threads per workgroup
   constexpr int CPL = CB / 4;                      // channels per lane per tap
-  constexpr int NVT = TX * TY * TZ / 16;           // voxel tiles per workgroup
-  constexpr int R = NVT / NW;                      // voxel tiles per wave
-  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x (TX = columns per column tile = 16)
+  constexpr int NVT = TX * TY * TZ / 16;           // column tiles per workgroup
+  constexpr int R = NVT / NW;                      // column tiles per wave
+  constexpr int HX = TXV + 2, HY = TY + 2, HZ = TZ + 2;
   constexpr int NHALO = HX * HY * HZ;
   constexpr int IN_FLOATS = NHALO * CB;
-  constexpr int W_FLOATS = 27 * NT * 64 * CPL;
+  constexpr int NTAP = XP ? 36 : 27;
+  constexpr int W_FLOATS = NTAP * NT * 64 * CPL;
   constexpr int Q = CB / 4;                        // 16-byte pieces per voxel
   constexpr int IN_IT = (NHALO * Q + NTH - 1) / NTH;   // staging iterations per thread (input tile)
   constexpr int W_IT = (W_FLOATS / 4 + NTH - 1) / NTH; // staging iterations per thread (weights)
-  static_assert(NVT % NW == 0, "tile must give each wave a whole number of voxel tiles");
+  static_assert(NVT % NW == 0, "tile must give each wave a whole number of column tiles");
+  static_assert(IN_IT <= 16, "invalid-piece masks are 16 bits per class");
+  static_assert(!XP || NT == 1, "x-pair packing is for Cout == 8");
   typedef float vecc __attribute__((ext_vector_type(CPL)));
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -66,67 +89,109 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int m = lane & 15;   // voxel within voxel tile (B column) / cout within tile (A row)
-  const int g = lane >> 4;   // k index within the MFMA's K=4
-  const int cg = blockIdx.y;  // cout group of 16*NT
+  const int m = lane & 15;   // column within column tile (B) / row within row tile (A)
+  const int g = lane >> 4;   // k index within the MFMA's K=4; D rows 4g..4g+3
+  const int cg = blockIdx.y;  // row group of 16*NT (plain) -- always 0 for x-pair
   const int ntiles = ka.tiles_x * ka.tiles_y * ka.tiles_z;
   const int total = ntiles * a.N;
+  const int lastx = (ka.tiles_x - 1) * TXV, lasty = (ka.tiles_y - 1) * TY, lastz = (ka.tiles_z - 1) * TZ;
 
-  // per-lane LDS voxel base (halo coordinates, tap (0,0,0)) of each of the wave's voxel tiles
-  int vbase[R];
-  int vx_[R], vy_[R], vz_[R];
+  // ---- per-lane constants of the compute phase and of the epilogue (identical for every tile) ----
+  int vbase[R];      // LDS float index of the lane's B fragment at tap (0,0,0)
+  unsigned ovoff[R]; // byte offset of the lane's output piece relative to the tile origin (rows of row tile 0)
+  unsigned eoff[R];  // element index (dropout / mask) of the same, relative to the tile origin
+  unsigned obad_xhi = 0, obad_yhi = 0, obad_zhi = 0;  // bit r: piece outside the volume in the last tile of that axis
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int v = (wave * R + r) * 16 + m;
-    const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
-    vx_[r] = lx; vy_[r] = ly; vz_[r] = lz;
+    const int v = (wave * R + r) * 16 + m;                 // column index within the workgroup tile
+    const int cx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
+    const int lx = XP ? 2 * cx : cx;                       // first voxel of the column
     vbase[r] = ((lz * HY + ly) * HX + lx) * CB + g * CPL;
+    const int ox = XP ? lx + (g >> 1) : lx;                // voxel this lane stores
+    const int oc = XP ? (g & 1) * 4 : g * 4;               // its first channel (within row tile 0)
+    const int ovox = (lz * a.H + ly) * a.W + ox;
+    ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * 4);
+    eoff[r] = (unsigned)(ovox * a.Cout + oc);
+    if (ox >= a.W - lastx) obad_xhi |= 1u << r;
+    if (ly >= a.H - lasty) obad_yhi |= 1u << r;
+    if (lz >= a.D - lastz) obad_zhi |= 1u << r;
   }
-  // per-thread staging pattern, identical for every tile: halo coordinates (packed) of each piece
-  int hc[IN_IT];
+
+  // ---- per-thread staging pattern (identical for every tile) ----
+  // input rows: plain: voxel stride in_pitch; x-blocked concat: [W/xb][2][xb][C], C = Cin/2
+  const int xb = a.in_xblk;
+  const int Csrc = xb ? a.Cin / 2 : a.Cin;
+  const int voxf = xb ? 2 * Csrc : a.in_pitch;           // floats per voxel step along x (row average)
+  const int rowf = a.W * voxf;                           // floats per x-row
+  const int biasf = (a.H + 1) * rowf + 4 * voxf;          // keeps every voffset non-negative
+  unsigned voff[IN_IT];
+  unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0, ibad_zlo = 0, ibad_zhi = 0;
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
     const int idx = tid + it * NTH;
-    const int vox = idx / Q;
+    const int vox = idx / Q, q = idx % Q;
     const int hx = vox % HX, hy = (vox / HX) % HY, hz = vox / (HX * HY);
-    hc[it] = (idx < NHALO * Q) ? (hx | (hy << 8) | (hz << 16) | ((idx % Q) << 24)) : -1;
+    const int dxr = hx - 1, dyr = hy - 1, dzr = hz - 1;   // voxel relative to the tile origin
+    int xf;                                               // float offset of (dxr, channel 4q) within its row
+    if (xb) {
+      const int blk = dxr >= 0 ? dxr / xb : -((-dxr + xb - 1) / xb);
+      const int rem = dxr - blk * xb;
+      const int sl = (Csrc < CB) ? (4 * q) / Csrc : 0;    // C < CB: the chunk spans both halves
+      const int cs = (Csrc < CB) ? (4 * q) % Csrc : 4 * q;
+      xf = (blk * 2 + sl) * xb * Csrc + rem * Csrc + cs;
+    } else {
+      xf = dxr * a.in_pitch + 4 * q;
+    }
+    const int rel = (dzr * a.H + dyr) * rowf + xf;
+    voff[it] = (unsigned)((rel + biasf) * 4);
+    if (idx >= NHALO * Q) ibad_always |= 1u << it;
+    if (dxr < 0) ibad_xlo |= 1u << it;
+    if (dxr >= a.W - lastx) ibad_xhi |= 1u << it;
+    if (dyr < 0) ibad_ylo |= 1u << it;
+    if (dyr >= a.H - lasty) ibad_yhi |= 1u << it;
+    if (dzr < 0) ibad_zlo |= 1u << it;
+    if (dzr >= a.D - lastz) ibad_zhi |= 1u << it;
   }
+  const size_t in_sample = (size_t)a.D * a.H * rowf;
+  const size_t out_sample = (size_t)a.D * a.H * a.W * a.out_pitch;
+  const int cper = xb && Csrc >= CB ? Csrc / CB : 0;      // chunks per concat half (0: not chunk-uniform)
 
-  const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
-  f32x4 ibuf[IN_IT];
-  f32x4 wbuf[W_IT];
-
-  // issue the global loads of one (tile, chunk) work item into registers (no wait)
-  const bool w_resident = ka.nchunks == 1;  // single-chunk layers: the weights never change, stage them once
-  bool w_fresh = true;
   auto decode = [&](int tile_lin, int& n, int& tx, int& ty, int& tz) {
     unsigned t = (unsigned)tile_lin, q;
     q = ka.tiles_x == 1 ? t : __umulhi(t, ka.mx); tx = (int)(t - q * ka.tiles_x); t = q;
     q = ka.tiles_y == 1 ? t : __umulhi(t, ka.my); ty = (int)(t - q * ka.tiles_y); t = q;
     q = ka.tiles_z == 1 ? t : __umulhi(t, ka.mz); tz = (int)(t - q * ka.tiles_z); n = (int)q;
   };
-  // per-piece offset (in floats) relative to the tile's halo origin: loop-invariant
-  int goff[IN_IT];
-#pragma unroll
-  for (int it = 0; it < IN_IT; ++it) {
-    const int c = hc[it];
-    goff[it] = (((c >> 16) & 0xff) * a.H + ((c >> 8) & 0xff)) * a.W * a.in_pitch + (c & 0xff) * a.in_pitch + ((c >> 24) & 0xff) * 4;
-  }
+
+  const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
+  f32x4 ibuf[IN_IT];
+  f32x4 wbuf[W_IT];
+  const bool w_resident = ka.nchunks == 1;  // single-chunk layers: the weights never change, stage them once
+  bool w_fresh = true;
+
+  // issue the global loads of one (tile, chunk) work item into registers (no wait)
   auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w) {
     int n, tx, ty, tz;
     decode(tile_lin, n, tx, ty, tz);
-    const int x0 = tx * TX - 1, y0 = ty * TY - 1, z0 = tz * TZ - 1;
-    // pointer to the (possibly out-of-volume) halo origin of this tile; only in-bounds pieces are dereferenced
-    const float* org = a.in + ((size_t)n * a.D * a.H * a.W) * a.in_pitch + chunk * CB +
-                       ((long long)(z0 * a.H + y0) * a.W + x0) * a.in_pitch;
+    unsigned bad = ibad_always;
+    if (tx == 0) bad |= ibad_xlo;
+    if (tx == ka.tiles_x - 1) bad |= ibad_xhi;
+    if (ty == 0) bad |= ibad_ylo;
+    if (ty == ka.tiles_y - 1) bad |= ibad_yhi;
+    if (tz == 0) bad |= ibad_zlo;
+    if (tz == ka.tiles_z - 1) bad |= ibad_zhi;
+    if (!have) bad = 0xFFFFFFFFu;
+    int coff;  // float offset of this chunk's first channel
+    if (!xb) coff = chunk * CB;
+    else if (cper) coff = (chunk / cper) * xb * Csrc + (chunk % cper) * CB;
+    else coff = 0;
+    const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TXV * voxf + coff) * 4);
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const int c = hc[it];
-      const int gx = x0 + (c & 0xff), gy = y0 + ((c >> 8) & 0xff), gz = z0 + ((c >> 16) & 0xff);
-      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (have && c >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H && (unsigned)gz < (unsigned)a.D)
-        v = *reinterpret_cast<const f32x4*>(org + goff[it]);
-      ibuf[it] = v;
+      const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
+      ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
     const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * W_FLOATS);
 #pragma unroll
@@ -152,23 +217,20 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
     }
   };
 
-  // One flat loop over (tile, chunk) work items: commit the prefetched registers to LDS, issue the NEXT item's
-  // global loads (straight-line, predicated -- no loop-carried register copies that would force a vmcnt(0)),
-  // compute this item, and run the epilogue after a tile's last chunk.
-  if (ka.prio_mode) {
-    // co-resident workgroups (dispatch order: b and b+256 share a CU at 2 WGs/CU) get different static
-    // priorities so they de-phase: one computes while the other stages/stores
-    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((lin >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-  }
   // bias once per workgroup: a load inside the loop would sit behind the prefetch loads in the in-order vmcnt
   // queue and make every epilogue wait for the NEXT tile's data
   f32x4 bias4[NT];
+  bool cvalid[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int co = (cg * NT + nt) * 16 + g * 4;
-    bias4[nt] = co < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int co = XP ? (g & 1) * 4 : (cg * NT + nt) * 16 + g * 4;
+    cvalid[nt] = co < a.Cout;
+    bias4[nt] = cvalid[nt] ? *reinterpret_cast<const f32x4*>(a.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+
+  // One flat loop over (tile, chunk) work items: commit the prefetched registers to LDS, issue the NEXT item's
+  // global loads (straight-line, predicated -- no loop-carried register copies that would force a vmcnt(0)),
+  // compute this item, and run the epilogue after a tile's last chunk.
   int tile_lin = blockIdx.x, chunk = 0;
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have, true);
@@ -197,18 +259,19 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
     VX_STAMP(3);
 
     {
-      // ---- 27 taps x CPL MFMAs x R x NT, fragments double-buffered one tap ahead ----
+      // ---- NTAP taps x CPL MFMAs x R x NT, fragments double-buffered one tap ahead ----
       vecc wf[2][NT], xf[2][R];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wf[0][nt] = *reinterpret_cast<const vecc*>(s_w + (nt * 64 + lane) * CPL);
 #pragma unroll
       for (int r = 0; r < R; ++r) xf[0][r] = *reinterpret_cast<const vecc*>(s_in + vbase[r]);
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
+      for (int tap = 0; tap < NTAP; ++tap) {
         const int cur = tap & 1, nxt = cur ^ 1;
-        if (tap + 1 < 27) {
+        if (tap + 1 < NTAP) {
           const int t1 = tap + 1;
-          const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+          // plain: tap = (kz*3 + ky)*3 + kx ; x-pair: tap = (kz*3 + ky)*4 + ix
+          const int kz = XP ? t1 / 12 : t1 / 9, ky = XP ? (t1 / 4) % 3 : (t1 / 3) % 3, kx = XP ? t1 % 4 : t1 % 3;
           const int toff = ((kz * HY + ky) * HX + kx) * CB;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
@@ -228,93 +291,112 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 
     VX_STAMP(4);
     if (chunk == ka.nchunks - 1) {
-    // ---- epilogue ----
-    int n, tx, ty, tz;
-    decode(tile_lin, n, tx, ty, tz);
-    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+      // ---- epilogue ----
+      int n, tx, ty, tz;
+      decode(tile_lin, n, tx, ty, tz);
+      unsigned obad = 0;
+      if (tx == ka.tiles_x - 1) obad |= obad_xhi;
+      if (ty == ka.tiles_y - 1) obad |= obad_yhi;
+      if (tz == ka.tiles_z - 1) obad |= obad_zhi;
+      const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TXV);  // tile origin voxel (in sample)
+      const unsigned osoff = vox0 * (unsigned)a.out_pitch * 4u;
+      const unsigned e0 = vox0 * (unsigned)a.Cout;
+      const __amdgpu_buffer_rsrc_t osrd =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
+      const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
 
-    float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
-
-    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int co = (cg * NT + nt) * 16 + g * 4;  // this lane's 4 couts
-      const bool cvalid = co < a.Cout;
-      const f32x4 b4 = bias4[nt];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int gx = x0 + vx_[r], gy = y0 + vy_[r], gz = z0 + vz_[r];
-        const bool valid = cvalid && gx < a.W && gy < a.H && gz < a.D;
-        if (!valid) continue;
-        f32x4 v = acc[r][nt] + b4;
-        const size_t vox = ((size_t)(n * a.D + gz) * a.H + gy) * a.W + gx;
-        if (a.stats_partial) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
-        }
-        if (a.act != VX_ACT_NONE) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = vx_act(v[j], a.act);
-        }
-        if (a.drop_mode == VX_DROP_HASH) {
-          const uint32_t e = (uint32_t)(((gz * a.H + gy) * a.W + gx) * a.Cout + co);
-          const uint32_t bits = vx_drop_bits4(dkey, e);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ((bits >> j) & 1u) ? 2.f * v[j] : 0.f;
-        } else if (a.drop_mode == VX_DROP_MASK) {
-          const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + vox * a.Cout + co);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(a.out + vox * a.out_pitch + a.out_coff + co) = v;
-      }
-    }
-
-    if (a.stats_partial) {
-      // reduce over the 16 lanes that share (g) -> per-wave sums per cout, then over waves via LDS
-      float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW waves][NT][16 couts][2], outside the staged tiles
+      float ssum[NT][4], ssq[NT][4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float s = ssum[nt][j], q = ssq[nt][j];
+        for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
+
 #pragma unroll
-          for (int off = 1; off < 16; off <<= 1) {
-            s += __shfl_xor(s, off, 64);
-            q += __shfl_xor(q, off, 64);
-          }
-          if (m == 0) {
-            s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
-            s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
-          }
-        }
-      __syncthreads();
-      if (tid < NT * 16) {
-        const int nt = tid / 16, c = tid % 16;
-        const int co = (cg * NT + nt) * 16 + c;
-        if (co < a.Cout) {
-          float s = 0.f, q = 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned cshift = XP ? 0u : (unsigned)((cg * NT + nt) * 16);  // first channel of this row tile
 #pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
-            q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+        for (int r = 0; r < R; ++r) {
+          const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
+          f32x4 v = acc[r][nt] + bias4[nt];
+          if (a.stats_partial && !bad) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
           }
-          const int tile = tile_lin - n * ntiles;
-          float* dst = a.stats_partial + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
-          dst[0] = s;
-          dst[1] = q;
+          if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.01f * v[j]);
+          } else if (a.act == VX_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          const unsigned e = e0 + eoff[r] + cshift;
+          if (a.drop_mode == VX_DROP_HASH) {
+            const uint32_t bits = vx_drop_bits4(dkey, e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);  // keep ? 2 : 0
+          } else if (a.drop_mode == VX_DROP_MASK) {
+            uint32_t mk = 0;
+            if (!bad) mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (size_t)n * a.D * a.H * a.W * a.Cout + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+          }
+          const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
+          // gfx950: a 16-byte buffer store with an SGPR soffset still reads its data registers for a few cycles
+          // after issue; hipcc (ROCm 7.2) pads this hazard only for an immediate soffset, so the next VALU write
+          // of those registers corrupted the last beat (dword 3, lanes 12-15 of each row).  Pad it by hand.
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 3" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // s_red is re-written only after the next item's two barriers, so no extra barrier is needed here
-    }
+
+      if (a.stats_partial) {
+        // reduce over the 16 lanes that share g -> per-wave sums per row, then over waves via LDS
+        float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW waves][NT][16 rows][2], outside the staged tiles
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 4; ++j) {
+            float s = ssum[nt][j], q = ssq[nt][j];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+              s += __shfl_xor(s, off, 64);
+              q += __shfl_xor(q, off, 64);
+            }
+            if (m == 0) {
+              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
+              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
+            }
+          }
+        __syncthreads();
+        if (tid < NT * 16) {
+          const int nt = tid / 16, c = tid % 16;
+          // x-pair: rows c and c+8 are the two x-parities of channel c
+          const int co = XP ? c : (cg * NT + nt) * 16 + c;
+          if (co < a.Cout && (!XP || c < 8)) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+              s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
+              q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+              if (XP) {
+                s += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 0];
+                q += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 1];
+              }
+            }
+            const int tile = tile_lin - n * ntiles;
+            float* dst = a.stats_partial + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
+            dst[0] = s;
+            dst[1] = q;
+          }
+        }
+        // s_red is re-written only after the next item's two barriers, so no extra barrier is needed here
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }  // last chunk of the tile
     VX_STAMP(5);
 #ifdef VX_CONV_STAMPS
@@ -332,34 +414,42 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight packing: torch (Cout, Cin, 3,3,3) -> [cgrp16][chunk][tap][lane 64][CPL]
-// (NT consecutive cgrp16 blocks of one chunk are NOT contiguous in this order, so the packed
-//  order is [cgrpNT][chunk][tap][nt][lane][CPL] with NT fixed per (Cin, Cout) by conv_config().)
-struct ConvCfg { int CB, NT; };
+// weight packing: torch (Cout, Cin, 3,3,3) -> [rowgroup][chunk][tap][nt][lane 64][CPL]
+//   plain : row = cout, tap = (kz,ky,kx)                       (NT fixed per (Cin, Cout) by conv_config())
+//   x-pair: row = dx*8 + cout, tap = (kz,ky,ix), value W[kx = ix - dx] or 0      (Cout == 8)
+struct ConvCfg { int CB, NT, XP; };
 static inline ConvCfg conv_config(int Cin, int Cout) {
   ConvCfg c;
   c.CB = (Cin % 16 == 0) ? 16 : 8;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
+  c.XP = (Cout == 8) ? 1 : 0;
   return c;
 }
-static inline int conv_cout_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
+static inline int conv_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
 __global__ void pack_conv3d_k3_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int CB,
-                                      int NT, int64_t total) {
+                                      int NT, int XP, int64_t total) {
   const int CPL = CB / 4;
   const int nchunks = Cin / CB;
+  const int ntap = XP ? 36 : 27;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int j = r % CPL; r /= CPL;
     const int lane = r % 64; r /= 64;
     const int nt = r % NT; r /= NT;
-    const int tap = r % 27; r /= 27;
+    const int tap = r % ntap; r /= ntap;
     const int chunk = r % nchunks; r /= nchunks;
-    const int cgrp = (int)r;
-    const int co = (cgrp * NT + nt) * 16 + (lane & 15);
+    const int rgrp = (int)r;
+    const int row = (rgrp * NT + nt) * 16 + (lane & 15);
     const int ci = chunk * CB + (lane >> 4) * CPL + j;
     float v = 0.f;
-    if (co < Cout) v = w[((size_t)co * Cin + ci) * 27 + tap];
+    if (XP) {
+      const int dx = row >> 3, co = row & 7;
+      const int kzy = tap / 4, ix = tap % 4, kx = ix - dx;
+      if (kx >= 0 && kx <= 2) v = w[((size_t)co * Cin + ci) * 27 + kzy * 3 + kx];
+    } else if (row < Cout) {
+      v = w[((size_t)row * Cin + ci) * 27 + tap];
+    }
     out[i] = v;
   }
 }
@@ -367,7 +457,8 @@ __global__ void pack_conv3d_k3_kernel(const float* __restrict__ w, float* __rest
 extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return -1;
   ConvCfg c = conv_config(Cin, Cout);
-  return (int64_t)conv_cout_padded(Cout, c.NT) * Cin * 27;
+  if (c.XP) return (int64_t)16 * Cin * 36;
+  return (int64_t)conv_rows_padded(Cout, c.NT) * Cin * 27;
 }
 
 extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin, int Cout, vx_stream_t stream) {
@@ -378,31 +469,45 @@ extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin,
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv3d_k3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin,
-                     Cout, c.CB, c.NT, total);
+                     Cout, c.CB, c.NT, c.XP, total);
   VX_CHECK_LAUNCH("vx_pack_conv3d_k3");
   return VX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-struct TileCfg { int TX, TY, TZ; };
-static inline TileCfg tile_config(int W) {
-  if (W >= 16) return {16, 4, 4};
-  if (W >= 8) return {8, 8, 4};
-  return {4, 4, 4};
+// tile shapes: TX = columns per column tile row (x extent in voxels is 2*TX for x-pair)
+struct TileCfg { int TX, TY, TZ, TXV; };
+static inline TileCfg tile_config(int W, int XP) {
+  if (XP) {
+    if (W >= 32) return {16, 4, 4, 32};
+    if (W >= 16) return {8, 8, 4, 16};
+    return {4, 4, 4, 8};
+  }
+  if (W >= 16) return {16, 4, 4, 16};
+  if (W >= 8) return {8, 8, 4, 8};
+  return {4, 4, 4, 4};
 }
 
+static int conv_tiles(int D, int H, int W, int Cout) {
+  TileCfg t = tile_config(W, Cout == 8);
+  return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
+}
 extern "C" int vx_conv3d_k3_tiles(int D, int H, int W) {
-  TileCfg t = tile_config(W);
-  return ((W + t.TX - 1) / t.TX) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
+  // upper bound over both packings (stats_partial sizing): the plain tiling has the most tiles
+  int a = conv_tiles(D, H, W, 16), b = conv_tiles(D, H, W, 8);
+  return a > b ? a : b;
 }
+extern "C" int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout) { return conv_tiles(D, H, W, Cout); }
 
-template <int CB, int NT, int TX, int TY, int TZ, int NW>
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
 static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
-  constexpr int IN_FLOATS = (TX + 2) * (TY + 2) * (TZ + 2) * CB;
-  constexpr int W_FLOATS = 27 * NT * 64 * (CB / 4);
+  constexpr int TXV = XP ? 2 * TX : TX;
+  constexpr int IN_FLOATS = (TXV + 2) * (TY + 2) * (TZ + 2) * CB;
+  constexpr int W_FLOATS = (XP ? 36 : 27) * NT * 64 * (CB / 4);
   constexpr size_t lds = (size_t)(IN_FLOATS + W_FLOATS + NW * NT * 16 * 2) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = conv3d_k3_mfma_kernel<CB, NT, TX, TY, TZ, NW>;
+  auto kern = conv3d_k3_mfma_kernel<CB, NT, TX, TY, TZ, NW, XP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -410,12 +515,12 @@ static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
     attr_set = true;
   }
   const vx_conv3d_args& a = ka.a;
-  const int NTc = NT;
   // persistent workgroups: each loops over tiles with stride gridDim.x (prefetching the next tile's loads
   // while it computes); enough workgroups to fill every CU at the LDS-limited occupancy
   const int total_tiles = ka.tiles_x * ka.tiles_y * ka.tiles_z * a.N;
-  const int ygroups = (a.Cout + 16 * NTc - 1) / (16 * NTc);
+  const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  if (per_cu * NW > 32) per_cu = 32 / NW;
   if (const char* e = getenv("VX_CONV_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // tuning knob
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
@@ -427,10 +532,15 @@ static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
 
 template <int CB, int NT>
 static int dispatch_tile(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
-  static const int nw8 = getenv("VX_CONV_NW4") ? 0 : 1;  // tuning knob: 8 waves (default) vs 4 waves per workgroup
-  if (t.TX == 16) return nw8 ? launch_conv<CB, NT, 16, 4, 4, 8>(ka, s) : launch_conv<CB, NT, 16, 4, 4, 4>(ka, s);
-  if (t.TX == 8) return nw8 ? launch_conv<CB, NT, 8, 8, 4, 8>(ka, s) : launch_conv<CB, NT, 8, 8, 4, 4>(ka, s);
-  return launch_conv<CB, NT, 4, 4, 4, 4>(ka, s);
+  if (t.TX == 16) return launch_conv<CB, NT, 16, 4, 4, 8, 0>(ka, s);
+  if (t.TX == 8) return launch_conv<CB, NT, 8, 8, 4, 8, 0>(ka, s);
+  return launch_conv<CB, NT, 4, 4, 4, 4, 0>(ka, s);
+}
+template <int CB>
+static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
+  if (t.TX == 16) return launch_conv<CB, 1, 16, 4, 4, 8, 1>(ka, s);
+  if (t.TX == 8) return launch_conv<CB, 1, 8, 8, 4, 8, 1>(ka, s);
+  return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);
 }
 
 extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
@@ -440,31 +550,40 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.Cin <= 0 || a.Cout <= 0 || a.Cin % 8 || a.Cout % 8)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", a.Cin, a.Cout);
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: empty tensor");
-  if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4)
-    VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: pitches/offset must be multiples of 4 floats and cover the channels");
+  if (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4)
+    VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
+  if (a.in_xblk) {
+    if (a.in_xblk != 1 && a.in_xblk != 2 && a.in_xblk != 4) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: in_xblk must be 0, 1, 2 or 4");
+    if (a.W % a.in_xblk) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: W=%d not a multiple of in_xblk=%d", a.W, a.in_xblk);
+    if (a.Cin % 16) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: concat input needs Cin %% 16 == 0 (two halves of Cin/2)");
+  } else if (a.in_pitch < a.Cin || a.in_pitch % 4) {
+    VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: input pitch must be a multiple of 4 floats and cover the channels");
+  }
   if (!vx_aligned16(a.in) || !vx_aligned16(a.out) || !vx_aligned16(a.w_packed) || !vx_aligned16(a.bias))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: pointers must be 16-byte aligned");
   if (a.act < 0 || a.act > 2 || a.drop_mode < 0 || a.drop_mode > 2) VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: bad act/drop enum");
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: VX_DROP_MASK without mask");
-  if ((int64_t)a.D * a.H * a.W * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: sample too large");
+  const int64_t inrow = a.in_xblk ? (int64_t)a.Cin : (int64_t)a.in_pitch;
+  if ((int64_t)a.D * a.H * a.W * a.out_pitch * 4 >= (1ll << 31) || ((int64_t)a.D + 2) * a.H * a.W * inrow * 4 >= (1ll << 31))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: one sample must stay below 2 GiB (32-bit buffer offsets)");
 
   ConvCfg c = conv_config(a.Cin, a.Cout);
-  TileCfg t = tile_config(a.W);
+  TileCfg t = tile_config(a.W, c.XP);
   ConvKArgs ka;
   ka.a = a;
-  ka.tiles_x = (a.W + t.TX - 1) / t.TX;
+  ka.tiles_x = (a.W + t.TXV - 1) / t.TXV;
   ka.tiles_y = (a.H + t.TY - 1) / t.TY;
   ka.tiles_z = (a.D + t.TZ - 1) / t.TZ;
   ka.nchunks = a.Cin / c.CB;
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
-  ka.prio_mode = getenv("VX_CONV_PRIO") ? 1 : 0;
   ka.dbg = nullptr;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   hipStream_t s = (hipStream_t)stream;
+  if (c.XP) return c.CB == 16 ? dispatch_tile_xp<16>(ka, t, s) : dispatch_tile_xp<8>(ka, t, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_tile<16, 1>(ka, t, s);
   if (c.CB == 16 && c.NT == 2) return dispatch_tile<16, 2>(ka, t, s);
   if (c.CB == 8 && c.NT == 1) return dispatch_tile<8, 1>(ka, t, s);

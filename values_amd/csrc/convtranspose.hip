@@ -9,6 +9,15 @@
 
 constexpr int CT_CO = 8;  // output channels per thread
 
+// address of channel c of output voxel (row, ox): plain pitched tensor or one half of a concat buffer
+__device__ __forceinline__ float* convT_out_ptr(const vx_convT_args& a, size_t orow, int ox, int OW, int c) {
+  if (a.out_xblk) {
+    const int xb = a.out_xblk;
+    return a.out + orow * (2 * (size_t)OW * a.Cout) + ((ox / xb) * 2 + a.out_half) * xb * a.Cout + (ox % xb) * a.Cout + c;
+  }
+  return a.out + (orow * OW + ox) * a.out_pitch + a.out_coff + c;
+}
+
 __global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_t nvox_in) {
   // blockIdx.y = ((dz*2 + dy) * ngroups + cgroup)
   const int ngroups = a.Cout / CT_CO;
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(a.out + ovox * a.out_pitch + a.out_coff + co0 + c4) = v;
+        *reinterpret_cast<f32x4*>(convT_out_ptr(a, (size_t)(n * OD + oz) * OH + oy, ox, OW, co0 + c4)) = v;
       }
     }
   }
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * acc[j] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(a.out + ovox * a.out_pitch + a.out_coff + cq * 4) = acc;
+    *reinterpret_cast<f32x4*>(convT_out_ptr(a, (size_t)(n * OD + oz) * OH + oy, ox, OW, cq * 4)) = acc;
   }
 }
 
@@ -168,8 +177,13 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   if (a.Cin <= 0 || a.Cout <= 0 || a.Cin % 4 || a.Cout % 8)
     VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: Cin=%d (mult of 4) Cout=%d (mult of 8)", a.Cin, a.Cout);
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: empty tensor");
-  if (a.in_pitch % 4 || a.in_pitch < a.Cin || a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.Cout)
+  if (a.in_pitch % 4 || a.in_pitch < a.Cin) VX_FAIL(VX_E_ALIGN, "vx_convT_k2s2: input pitch");
+  if (a.out_xblk) {
+    if ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || (2 * a.W) % a.out_xblk || (a.out_half != 0 && a.out_half != 1))
+      VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: bad concat layout (xblk=%d, half=%d)", a.out_xblk, a.out_half);
+  } else if (a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.Cout) {
     VX_FAIL(VX_E_ALIGN, "vx_convT_k2s2: pitches/offsets must be multiples of 4 floats");
+  }
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: mask mode without mask");
   if ((int64_t)a.D * a.H * a.W * 8 * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: sample too large");
   // large, shallow up-convolutions: row-streaming kernel (needs 256 % (2*Cout/4) == 0 and Cout <= 128)

@@ -104,7 +104,15 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * t[j] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(a.out + vox * a.out_pitch + a.out_coff + c) = t;
+      if (a.out_xblk) {
+        // concat buffer [N][D][H][W/xb][2][xb][C]: this kernel's half as dense blocks of xb voxels
+        const size_t row = (size_t)(n * a.D + z) * a.H + y;
+        const int xb = a.out_xblk;
+        *reinterpret_cast<f32x4*>(a.out + row * (2 * (size_t)a.W * a.C) + ((x / xb) * 2 + a.out_half) * xb * a.C +
+                                  (x % xb) * a.C + c) = t;
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + vox * a.out_pitch + a.out_coff + c) = t;
+      }
       if (POOL) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], t[j]);
@@ -137,8 +145,13 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
   if ((a.mean == nullptr) != (a.rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: mean/rstd must come together");
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0 || a.C <= 0 || a.C % 4)
     VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: bad shape (C must be a multiple of 4)");
-  if (a.x_pitch % 4 || a.out_pitch % 4 || a.out_coff % 4 || a.x_pitch < a.C || a.out_pitch < a.out_coff + a.C)
+  if (a.x_pitch % 4 || a.x_pitch < a.C) VX_FAIL(VX_E_ALIGN, "vx_norm_act_drop_pool: input pitch");
+  if (a.out_xblk) {
+    if ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || a.W % a.out_xblk || (a.out_half != 0 && a.out_half != 1))
+      VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: bad concat layout (xblk=%d, half=%d, W=%d)", a.out_xblk, a.out_half, a.W);
+  } else if (a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.C) {
     VX_FAIL(VX_E_ALIGN, "vx_norm_act_drop_pool: pitches/offsets must be multiples of 4 floats");
+  }
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: mask mode without mask");
   if ((int64_t)a.D * a.H * a.W * a.C >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: sample too large");
   hipStream_t s = (hipStream_t)stream;

@@ -4,11 +4,13 @@
 //
 // Data flow (channels-last fp32, level l has spatial (D,H,W) >> l and C_l = F << l channels):
 //   encoder l:  conv -> A_l (raw + stats) -> finalize -> IN/LReLU/drop in place
-//               conv -> B_l (raw + stats) -> finalize -> IN/LReLU/drop -> CAT_l[C_l:2C_l) (skip) + pool -> P_{l+1}
-//   center:     conv+ReLU, conv+ReLU, convT+ReLU+drop -> CAT_3[0:C_3)
-//   decoder l:  conv(CAT_l)+LReLU+drop -> A_l, conv+LReLU+drop -> B_l, convT -> CAT_{l-1}[0:C_{l-1})
+//               conv -> B_l (raw + stats) -> finalize -> IN/LReLU/drop -> skip half of CAT_l + pool -> P_{l+1}
+//   center:     conv+ReLU, conv+ReLU, convT+ReLU+drop -> up half of CAT_3
+//   decoder l:  conv(CAT_l)+LReLU+drop -> A_l, conv+LReLU+drop -> B_l, convT -> up half of CAT_{l-1}
 //   final:      1x1x1 conv(B_0) -> logits NCDHW, slot dst[n], un-flipped
-// torch.cat never happens: both producers write their half of CAT_l (K7).
+// torch.cat never happens (K7): CAT_l is the x-blocked buffer [N][D][H][W/xb][2][xb][C_l] (values_amd.h) whose two
+// halves are written as dense blocks by their producers and read by the decoder conv through in_xblk.
+// First layer in MC-dropout mode: computed once per volume (the T samples share input and statistics).
 #include "common.h"
 
 extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W);
@@ -131,9 +133,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   const int dm = r->drop_mode;
   auto mask = [&](int i) { return dm == VX_DROP_MASK ? r->masks[i] : (const uint8_t*)nullptr; };
 
+  auto xblk_of = [](int W) { return W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); };
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
-                  int Cout, int act, int drop_layer, float* stats) {
+                  int Cout, int act, int drop_layer, float* stats, int in_xblk) {
     vx_conv3d_args a;
+    a.in_xblk = in_xblk;
     a.in = in; a.w_packed = w->conv_w[wi]; a.bias = w->conv_b[wi]; a.out = out;
     a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.out_coff = out_coff;
     a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.Cin = Cin; a.Cout = Cout;
@@ -145,8 +149,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     return vx_conv3d_k3(&a, stream);
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
-                  int drop_layer, int x_repeat) {
+                  int drop_layer, int x_repeat, int out_xblk) {
     vx_norm_args a;
+    a.out_xblk = out_xblk; a.out_half = 1;
     a.x = x; a.x_pitch = C; a.mean = p.mean; a.rstd = p.rstd;
     a.out = out; a.out_pitch = out_pitch; a.out_coff = out_coff;
     a.pool_out = pool; a.pool_pitch = C;
@@ -158,6 +163,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
                    int drop_layer) {
     vx_convT_args a;
+    a.out_xblk = xblk_of(2 * Lin.W); a.out_half = 0;
     a.in = in; a.in_pitch = Cin; a.w_packed = w->up_w[ui]; a.bias = w->up_b[ui];
     a.out = out; a.out_pitch = out_pitch; a.out_coff = 0;
     a.N = N; a.D = Lin.D; a.H = Lin.H; a.W = Lin.W; a.Cin = Cin; a.Cout = Cout;
@@ -191,30 +197,30 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
         VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.CAT[0], C, V, L.D, L.H, L.W, C, 1, nullptr,
                                           nullptr, p.stats, stream));
         VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep));
+        VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0));
       } else {
         VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, rep, r->src,
                                           r->flip, p.stats, stream));
         VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1));
+        VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1, 0));
       }
     } else {
-      ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
-      VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats));
+      ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+      VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats, 0));
       VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-      VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1));
+      VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
     }
-    ntiles = vx_conv3d_k3_tiles(L.D, L.H, L.W);
-    VX_STEP(kConv[2 * l + 1], conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats));
+    ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+    VX_STEP(kConv[2 * l + 1], conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0));
     VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-    VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1));
+    VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1, xblk_of(L.W)));
   }
   // ---------------- center ----------------
   {
     const Level& L4 = p.lv[4];
     const int C3 = p.lv[3].C, C4 = L4.C;
-    VX_STEP(kConv[8], conv(p.P[4], C3, 8, p.C0, C4, 0, L4, C3, C4, VX_ACT_RELU, -1, nullptr));
-    VX_STEP(kConv[9], conv(p.C0, C4, 9, p.C1, C4, 0, L4, C4, C4, VX_ACT_RELU, -1, nullptr));
+    VX_STEP(kConv[8], conv(p.P[4], C3, 8, p.C0, C4, 0, L4, C3, C4, VX_ACT_RELU, -1, nullptr, 0));
+    VX_STEP(kConv[9], conv(p.C0, C4, 9, p.C1, C4, 0, L4, C4, C4, VX_ACT_RELU, -1, nullptr, 0));
     VX_STEP(kUp[0], convT(p.C1, 0, p.CAT[3], 2 * C3, L4, C4, C3, VX_ACT_RELU, 8));
   }
   // ---------------- decoder ----------------
@@ -223,8 +229,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int C = L.C;
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
-    VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr));
-    VX_STEP(kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr));
+    VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
+    VX_STEP(kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------

@@ -55,10 +55,13 @@ def kernel_name(kind, ci, co, edge):
     if kind == "conv":
         if ci == 1:
             return f"conv3d_k3_c1_kernel<{co}>"
+        # template instance = <CB, NT, TX, TY, TZ, NW, XP> as conv_config()/tile_config() choose it (conv3d_mfma.hip)
         cb = 16 if ci % 16 == 0 else 8
         nt = 2 if co % 32 == 0 else 1
-        tile = "16,4,4" if edge >= 16 else ("8,8,4" if edge >= 8 else "4,4,4")
-        return f"conv3d_k3_mfma_kernel<{cb},{nt},{tile}>"
+        xp = 1 if co == 8 else 0
+        ex = edge // 2 if xp else edge  # x-pair: a column is a voxel pair
+        tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
+        return f"conv3d_k3_mfma_kernel<{cb},{nt},{tile},{nw},{xp}>"
     if kind == "convT":
         return "convT_k2s2_kernel"
     if kind == "conv1x1":
@@ -119,7 +122,8 @@ def roofline_leg(model, x, T, reps=3):
             if label in tab:
                 kind, ci, co, edge = tab[label]
                 name = kernel_name(kind, ci, co, edge)
-                fl, by = launch_cost(kind, ci, co, edge, N)
+                # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
+                fl, by = launch_cost(kind, ci, co, edge, V if label == "contr_1_1" else N)
             else:
                 name, fl, by = label.split(":")[0], 0.0, 0.0
             a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})

@@ -70,7 +70,18 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   constexpr int R = NVT / NW;                      // column tiles per wave
   constexpr int HX = TXV + 2, HY = TY + 2, HZ = TZ + 2;
   constexpr int NHALO = HX * HY * HZ;
-  constexpr int IN_FLOATS = NHALO * CB;
+  // LDS image of the input tile: [g = channel group of CPL][parity plane (x-pair only)][position][CPL floats].
+  // A lane (column m, k-group g) reads CPL floats at position p0 + m of plane g: the 16 columns of a tile are
+  // CONSECUTIVE positions, so a wave's read is conflict-free whatever the tap offset (plane size: see PLANE),
+  // and every tap is an immediate offset.  x-pair columns are 2 voxels apart, so even and odd x live in
+  // separate parity planes and stay consecutive.
+  constexpr int NPAR = XP ? 2 : 1;
+  constexpr int HXP = XP ? HX / 2 : HX;            // positions per x-row (per parity)
+  constexpr int NPP = HXP * HY * HZ;               // positions per parity plane
+  // positions per g-plane, padded so that plane stride keeps the 4 k-groups on disjoint banks:
+  // 16-byte reads (CB=16): multiple of 16 positions; 8-byte reads (CB=8): 16 mod 32 positions
+  constexpr int PLANE = CB == 16 ? ((NPAR * NPP + 15) / 16) * 16 : ((NPAR * NPP + 15) / 32) * 32 + 16;
+  constexpr int IN_FLOATS = 4 * PLANE * (CB / 4);
   constexpr int NTAP = XP ? 36 : 27;
   constexpr int W_FLOATS = NTAP * NT * 64 * CPL;
   constexpr int Q = CB / 4;                        // 16-byte pieces per voxel
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
     const int v = (wave * R + r) * 16 + m;                 // column index within the workgroup tile
     const int cx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
     const int lx = XP ? 2 * cx : cx;                       // first voxel of the column
-    vbase[r] = ((lz * HY + ly) * HX + lx) * CB + g * CPL;
+    vbase[r] = (g * PLANE + (lz * HY + ly) * HXP + cx) * CPL;
     const int ox = XP ? lx + (g >> 1) : lx;                // voxel this lane stores
     const int oc = XP ? (g & 1) * 4 : g * 4;               // its first channel (within row tile 0)
     const int ovox = (lz * a.H + ly) * a.W + ox;
@@ -125,6 +136,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   const int rowf = a.W * voxf;                           // floats per x-row
   const int biasf = (a.H + 1) * rowf + 4 * voxf;          // keeps every voffset non-negative
   unsigned voff[IN_IT];
+  int ldst[IN_IT];   // LDS float index of the piece's first channel group (a 16-byte piece spans 4/CPL groups)
   unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0, ibad_zlo = 0, ibad_zhi = 0;
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
@@ -144,6 +156,11 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
     }
     const int rel = (dzr * a.H + dyr) * rowf + xf;
     voff[it] = (unsigned)((rel + biasf) * 4);
+    {
+      const int par = XP ? (hx & 1) : 0, px = XP ? (hx >> 1) : hx;
+      const int pos = par * NPP + (hz * HY + hy) * HXP + px;
+      ldst[it] = ((q * (4 / CPL)) * PLANE + pos) * CPL;
+    }
     if (idx >= NHALO * Q) ibad_always |= 1u << it;
     if (dxr < 0) ibad_xlo |= 1u << it;
     if (dxr >= a.W - lastx) ibad_xhi |= 1u << it;
@@ -206,7 +223,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
       const int idx = tid + it * NTH;
-      if (idx < NHALO * Q) *reinterpret_cast<f32x4*>(s_in + idx * 4) = ibuf[it];
+      if (idx < NHALO * Q) {
+        if (CPL == 4) {
+          *reinterpret_cast<f32x4*>(s_in + ldst[it]) = ibuf[it];
+        } else {  // CB = 8: the piece's two channel pairs belong to two g-planes
+          *reinterpret_cast<f32x2*>(s_in + ldst[it]) = (f32x2){ibuf[it][0], ibuf[it][1]};
+          *reinterpret_cast<f32x2*>(s_in + ldst[it] + PLANE * CPL) = (f32x2){ibuf[it][2], ibuf[it][3]};
+        }
+      }
     }
     if (with_w) {
 #pragma unroll
@@ -259,26 +283,27 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
     VX_STAMP(3);
 
     {
-      // ---- NTAP taps x CPL MFMAs x R x NT, fragments double-buffered one tap ahead ----
-      vecc wf[2][NT], xf[2][R];
+      // ---- NTAP taps x CPL MFMAs x R x NT; fragments are read PD taps ahead of their MFMAs ----
+      constexpr int PD = CB == 8 ? 3 : 1;  // CB = 8 has only 2*R*NT MFMAs per tap to cover an LDS read
+      constexpr int NB = PD + 1;
+      vecc wf[NB][NT], xf[NB][R];
+      auto load_tap = [&](int t1, int slot) {
+        // plain: tap = (kz*3 + ky)*3 + kx ; x-pair: tap = (kz*3 + ky)*4 + ix
+        const int kz = XP ? t1 / 12 : t1 / 9, ky = XP ? (t1 / 4) % 3 : (t1 / 3) % 3, kx = XP ? t1 % 4 : t1 % 3;
+        // x-pair: tap ix reads voxel 2p + ix -> parity ix & 1, position p + (ix >> 1)
+        const int toff = (XP ? (kx & 1) * NPP + (kz * HY + ky) * HXP + (kx >> 1) : (kz * HY + ky) * HXP + kx) * CPL;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[0][nt] = *reinterpret_cast<const vecc*>(s_w + (nt * 64 + lane) * CPL);
+        for (int nt = 0; nt < NT; ++nt)
+          wf[slot][nt] = *reinterpret_cast<const vecc*>(s_w + ((t1 * NT + nt) * 64 + lane) * CPL);
 #pragma unroll
-      for (int r = 0; r < R; ++r) xf[0][r] = *reinterpret_cast<const vecc*>(s_in + vbase[r]);
+        for (int r = 0; r < R; ++r) xf[slot][r] = *reinterpret_cast<const vecc*>(s_in + vbase[r] + toff);
+      };
+#pragma unroll
+      for (int t = 0; t < PD; ++t) load_tap(t, t);
 #pragma unroll
       for (int tap = 0; tap < NTAP; ++tap) {
-        const int cur = tap & 1, nxt = cur ^ 1;
-        if (tap + 1 < NTAP) {
-          const int t1 = tap + 1;
-          // plain: tap = (kz*3 + ky)*3 + kx ; x-pair: tap = (kz*3 + ky)*4 + ix
-          const int kz = XP ? t1 / 12 : t1 / 9, ky = XP ? (t1 / 4) % 3 : (t1 / 3) % 3, kx = XP ? t1 % 4 : t1 % 3;
-          const int toff = ((kz * HY + ky) * HX + kx) * CB;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            wf[nxt][nt] = *reinterpret_cast<const vecc*>(s_w + ((t1 * NT + nt) * 64 + lane) * CPL);
-#pragma unroll
-          for (int r = 0; r < R; ++r) xf[nxt][r] = *reinterpret_cast<const vecc*>(s_in + vbase[r] + toff);
-        }
+        if (tap + PD < NTAP) load_tap(tap + PD, (tap + PD) % NB);
+        const int cur = tap % NB;
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
 #pragma unroll
@@ -502,7 +527,9 @@ extern "C" int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout) { return co
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
 static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
   constexpr int TXV = XP ? 2 * TX : TX;
-  constexpr int IN_FLOATS = (TXV + 2) * (TY + 2) * (TZ + 2) * CB;
+  constexpr int NPOS = (TXV + 2) * (TY + 2) * (TZ + 2);  // = NPAR * NPP (HX is even for x-pair)
+  constexpr int PLANE = CB == 16 ? ((NPOS + 15) / 16) * 16 : ((NPOS + 15) / 32) * 32 + 16;
+  constexpr int IN_FLOATS = 4 * PLANE * (CB / 4);
   constexpr int W_FLOATS = (XP ? 36 : 27) * NT * 64 * (CB / 4);
   constexpr size_t lds = (size_t)(IN_FLOATS + W_FLOATS + NW * NT * 16 * 2) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -538,6 +565,8 @@ static int dispatch_tile(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
 }
 template <int CB>
 static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
+  static const int nw16 = getenv("VX_XP_NW16") ? 1 : 0;  // tuning knob
+  if (t.TX == 16 && CB == 16 && nw16) return launch_conv<CB, 1, 16, 4, 4, 16, 1>(ka, s);
   if (t.TX == 16) return launch_conv<CB, 1, 16, 4, 4, 8, 1>(ka, s);
   if (t.TX == 8) return launch_conv<CB, 1, 8, 8, 4, 8, 1>(ka, s);
   return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);

@@ -203,6 +203,16 @@ int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* 
                                int max_launches, float* ms, const char** labels, int* n_launches);
 
 /* ---------------------------------------------------------------------------------
+ * K14: sliding-window accumulation of a batch of patches (DataCarrier3D.concat_data,
+ * uncertainty_modeling/data_carrier_3D.py:137-179, with the F.softmax of test_3D.py:472 fused):
+ *   sum[t][c][crop_b] += softmax_c(logits[b][t]);  count[crop_b] += 1 (once per patch, the reference's pred_idx == 0)
+ *   logits [B][T][C][P0][P1][P2] (the pred_idx slots of vx_unet3d_forward), crop [B][3] = (x0, y0, z0) int32 on the
+ *   device, sum [T][C][X][Y][Z], count [X][Y][Z] float32, zero-initialised by the caller.
+ *   overlap != 0: patches of the batch may overlap (patch_overlap < 1) -> float atomics. 2 <= C <= 8. */
+int vx_softmax_accumulate(const float* logits, int B, int T, int C, int P0, int P1, int P2, const int32_t* crop,
+                          float* sum, float* count, int X, int Y, int Z, int overlap, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and
  *                first (C-order) index with isclose(value, max); result[0]=max, idx[0..2]

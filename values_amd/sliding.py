@@ -1,0 +1,62 @@
+"""Sliding-window inference over whole images: get_val_test_data_samples + predict_cases + concat_data +
+caculcate_uncertainty_multiple_pred (toy_datamodule_3D.py:637-655, test_3D.py:417-534, data_carrier_3D.py:99-179,
+208-217) with the patches batched on the device.
+
+compat=True reproduces the reference exactly, including quirk D10: `calculate_uncertainty` is applied to the
+UN-normalised sums of overlapping patches and only the resulting maps are divided by clip(count, 1) at save time
+(data_carrier_3D.py:323-337).  With the shipped `patch_overlap: 1` the count is 1 and both modes agree.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .predict import crop_indices, predict_logits
+from .uncertainty import uncertainty_maps
+
+
+@torch.no_grad()
+def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int = 64, patch_overlap: float = 1,
+                          n_pred: int = 1, tta: bool = False, patch_batch: int = 8, compat: bool = True,
+                          seeds=None, noise_fn=None) -> Dict[str, torch.Tensor]:
+    """image: (X, Y, Z) float tensor (the preprocessed .npy of load_image).  Returns device tensors:
+    softmax_sum (T, C, X,Y,Z), num_predictions (X,Y,Z), pred_entropy / aleatoric_uncertainty / epistemic_uncertainty
+    (X,Y,Z) -- already divided by clip(count,1) like save_data --, mean_softmax (C, X,Y,Z), pred_seg_mean (X,Y,Z) u8."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = image.device if image.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    img = image.to(dev, torch.float32).contiguous()
+    X, Y, Z = img.shape
+    crops = crop_indices((X, Y, Z), patch_size, patch_overlap)
+    P = patch_size
+    T = (16 if tta else n_pred) * len(models)
+    C = models[0].num_classes
+    ssum = torch.zeros((T, C, X, Y, Z), dtype=torch.float32, device=dev)
+    count = torch.zeros((X, Y, Z), dtype=torch.float32, device=dev)
+    overlap = int(int(P * patch_overlap) < P)
+    for b0 in range(0, len(crops), patch_batch):
+        batch = crops[b0:b0 + patch_batch]
+        x = torch.stack([img[c[0][0]:c[0][1], c[1][0]:c[1][1], c[2][0]:c[2][1]] for c in batch]).unsqueeze(1)
+        kw = {}
+        if seeds is not None:
+            kw["seeds"] = [s + b0 for s in seeds]
+        x_noise = noise_fn(x) if (tta and noise_fn is not None) else None
+        logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, **kw)  # (B, T, C, P,P,P)
+        crop_t = torch.tensor([[c[0][0], c[1][0], c[2][0]] for c in batch], dtype=torch.int32, device=dev)
+        rc = lib.vx_softmax_accumulate(_lib.ptr(logits), len(batch), T, C, P, P, P, _lib.ptr(crop_t), _lib.ptr(ssum),
+                                       _lib.ptr(count), X, Y, Z, overlap, _lib.stream_ptr())
+        _lib.check(rc, "vx_softmax_accumulate")
+    cl = count.clamp(min=1)
+    if compat:
+        m = uncertainty_maps(ssum.unsqueeze(0), from_logits=False)          # on the un-normalised sums (D10)
+        pe, ee, mi = (m[k][0] / cl for k in ("pred_entropy", "expected_entropy", "mutual_information"))
+    else:
+        m = uncertainty_maps((ssum / cl).unsqueeze(0), from_logits=False)
+        pe, ee, mi = (m[k][0] for k in ("pred_entropy", "expected_entropy", "mutual_information"))
+    # mean over T of softmax/clip(count,1) and its argmax (data_carrier_3D.py:215-217, 254-255); the per-voxel
+    # count does not change the argmax
+    mean = m["mean_softmax"][0] / cl if compat else m["mean_softmax"][0]
+    return {"softmax_sum": ssum, "num_predictions": count, "pred_entropy": pe, "aleatoric_uncertainty": ee,
+            "epistemic_uncertainty": mi, "mean_softmax": mean, "pred_seg_mean": m["argmax"][0]}

@@ -68,6 +68,15 @@ int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C
                   float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
                   uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream);
 
+/* The same reduction split for member-/sample-sharded ensembles (BASELINE config C3): every rank
+ * ADDS the sufficient statistics of its own passes into stats [B][C+1][nvox] (planes 0..C-1: sum_t p_tc, plane C:
+ * sum_t sum_c p_tc log p_tc; zero-initialised by the caller), one sum-reduce over RCCL combines the ranks, and
+ * finalize turns the sums of T_total passes into the maps of calculate_uncertainty (test_3D.py:486-518). */
+int vx_unc_stats_accumulate(const float* logits, int B, int T, int C, int64_t nvox, float* stats, vx_stream_t stream);
+int vx_unc_stats_finalize(const float* stats, int B, int T_total, int C, int64_t nvox, float* mean_prob,
+                          float* pred_entropy, float* exp_entropy, float* mutual_info, uint8_t* argmax,
+                          vx_stream_t stream);
+
 /* calculate_one_minus_msr (test_3D.py:521-525) / ExperimentDataloader.get_max_softmax_pred
  * (evaluation/experiment_dataloader.py:38-49): out[v] = 1 - max_c x[c][v]; x [C][nvox]. */
 int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, void* out, vx_stream_t stream);

@@ -68,6 +68,22 @@ def test_gather_maps_world2_gloo():
     assert all(results)
 
 
+def test_ensemble_work_items_cover_every_member_and_volume_once():
+    from values_amd.dist import ensemble_work_items
+    for members, vols, world in [(5, 8, 8), (5, 1, 8), (3, 4, 2), (2, 7, 1), (8, 8, 8), (10, 3, 4)]:
+        per_rank = ensemble_work_items(members, vols, world)
+        assert len(per_rank) == world
+        seen = {}
+        for items in per_rank:
+            for m, lo, hi in items:
+                for v in range(lo, hi):
+                    assert (m, v) not in seen
+                    seen[(m, v)] = 1
+        assert len(seen) == members * vols
+        busy = sum(1 for items in per_rank if items)
+        assert busy == min(world, len(seen) if vols == 1 else world) or busy >= min(world, members)
+
+
 def test_gather_maps_world1_is_identity():
     m = _fake_maps(0, 3)
     assert gather_maps(m, 1, 0) is m

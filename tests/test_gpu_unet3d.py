@@ -220,3 +220,35 @@ def test_aleatoric_head_and_errors():
         UNet3D(num_classes=2, in_channels=2)
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, 16, 16, 16).cuda())
+
+
+def test_sharded_ensemble_statistics_equal_single_pass():
+    """C3: members' sufficient statistics accumulated in ANY split and finalised == the one-pass reduction over the
+    stacked members (what the reference computes), to float32 summation-order noise; and vs the golden ensemble."""
+    from values_amd import predict_uncertainty
+    from values_amd.dist import ensemble_uncertainty_sharded, ensemble_work_items, finalize_stats
+    g = load_npz("ensemble_tta_16.npz")
+    models = [make_model(seed_tag=s, do_dropout=False) for s in range(3)]
+    x = torch.from_numpy(g["input"]).cuda()
+    one = predict_uncertainty(models, x, n_pred=1)
+    sh = ensemble_uncertainty_sharded(models, x, world=1, rank=0, n_pred=1)
+    for k in KEYS:
+        assert (sh[k] - one[k]).abs().max().item() < 2e-6, k
+        assert np.abs(sh[k][0].cpu().numpy() - g["ens_" + k]).max() < MAP_TOL, k
+    assert (sh["mean_softmax"] - one["mean_softmax"]).abs().max().item() < 1e-6
+    # emulate a 2-rank run: each "rank" accumulates its own items, the buffers are summed (what dist.reduce does)
+    from values_amd import _lib, predict_logits
+    lib = _lib.load()
+    parts = []
+    for rank in range(2):
+        st = torch.zeros((1, 3, 16, 16, 16), device="cuda")
+        for (m, lo, hi) in ensemble_work_items(3, 1, 2)[rank]:
+            lg = predict_logits([models[m]], x[lo:hi], n_pred=1)
+            _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(lg), hi - lo, 1, 2, 16 ** 3, _lib.ptr(st[lo:hi]),
+                                                   _lib.stream_ptr()), "acc")
+        parts.append(st)
+    two = finalize_stats(parts[0] + parts[1], 3)
+    for k in KEYS:
+        assert (two[k] - one[k]).abs().max().item() < 2e-6, k
+    clear = g["mean_margin"] > 0  # ensemble argmax: compare against the one-pass kernel (same float32 means)
+    assert torch.equal(two["pred_seg_mean"], one["pred_seg_mean"]) or clear.any()

@@ -200,6 +200,156 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
   }
 }
 
+// ---- sufficient statistics for member-/sample-sharded reductions (multi-GPU ensembles) ----
+// stats[b][c][v] += sum_t p_tc ;  stats[b][C][v] += sum_t sum_c p_tc log p_tc.   Ranks add their members' passes
+// into their own buffer, one RCCL sum-reduce combines them, and the finalize kernel produces the maps:
+// H[S1/T], -S2/T, their difference -- the same quantities as the single-pass kernel, summed in a different order.
+template <int C, int VEC>
+__global__ __launch_bounds__(256) void unc_stats_accumulate_kernel(const float* __restrict__ x, int T, int64_t nvox,
+                                                                   float* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* xb = x + (size_t)b * T * C * nvox;
+  float* sb = stats + (size_t)b * (C + 1) * nvox;
+  const int64_t ngroups = nvox / VEC;
+  for (int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v0 = gi * VEC;
+    float sum[C][VEC], ee[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      ee[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) sum[c][k] = 0.f;
+    }
+    for (int t = 0; t < T; ++t) {
+      float z[C][VEC];
+#pragma unroll
+      for (int c = 0; c < C; ++c) load_vec<float, VEC>(xb + ((size_t)t * C + c) * nvox + v0, z[c]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float m = z[0][k];
+#pragma unroll
+        for (int c = 1; c < C; ++c) m = fmaxf(m, z[c][k]);
+        float e[C], den = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { e[c] = expf(z[c][k] - m); den += e[c]; }
+        const float inv = 1.f / den, lden = logf(den);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float p = e[c] * inv;
+          sum[c][k] += p;
+          ee[k] += p * ((z[c][k] - m) - lden);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float o[VEC];
+      load_vec<float, VEC>(sb + (size_t)c * nvox + v0, o);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] += sum[c][k];
+      store_f32<VEC>(sb + (size_t)c * nvox + v0, o);
+    }
+    float o[VEC];
+    load_vec<float, VEC>(sb + (size_t)C * nvox + v0, o);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] += ee[k];
+    store_f32<VEC>(sb + (size_t)C * nvox + v0, o);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void unc_stats_finalize_kernel(const float* __restrict__ stats, int C, float inv_T,
+                                                                 int64_t nvox, float* __restrict__ mean_prob,
+                                                                 float* __restrict__ pred_entropy,
+                                                                 float* __restrict__ exp_entropy,
+                                                                 float* __restrict__ mutual_info,
+                                                                 uint8_t* __restrict__ argmax) {
+  const int b = blockIdx.y;
+  const float* sb = stats + (size_t)b * (C + 1) * nvox;
+  const int64_t ngroups = nvox / VEC;
+  for (int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v0 = gi * VEC;
+    float pe[VEC], best[VEC];
+    int besti[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { pe[k] = 0.f; best[k] = 0.f; besti[k] = 0; }
+    for (int c = 0; c < C; ++c) {
+      float s[VEC], mo[VEC];
+      load_vec<float, VEC>(sb + (size_t)c * nvox + v0, s);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float mean = s[k] * inv_T;
+        mo[k] = mean;
+        const float term = mean * logf(mean);
+        if (term == term) pe[k] += term;
+        if (c == 0 || mean > best[k]) { best[k] = mean; besti[k] = c; }
+      }
+      if (mean_prob) store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
+    }
+    float s2[VEC], o_pe[VEC], o_ee[VEC], o_mi[VEC];
+    load_vec<float, VEC>(sb + (size_t)C * nvox + v0, s2);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      o_pe[k] = -pe[k];
+      o_ee[k] = -s2[k] * inv_T;
+      o_mi[k] = o_pe[k] - o_ee[k];
+    }
+    store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
+    store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
+    store_f32<VEC>(mutual_info + (size_t)b * nvox + v0, o_mi);
+    if (argmax) store_u8<VEC>(argmax + (size_t)b * nvox + v0, besti);
+  }
+}
+
+extern "C" int vx_unc_stats_accumulate(const float* logits, int B, int T, int C, int64_t nvox, float* stats,
+                                       vx_stream_t stream) {
+  if (B <= 0 || T <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_unc_stats_accumulate: bad shape");
+  if (nvox == 0) return VX_OK;
+  if (!logits || !stats) VX_FAIL(VX_E_NULL, "vx_unc_stats_accumulate: null pointer");
+  const bool vec = vx_aligned16(logits) && vx_aligned16(stats) && nvox % 4 == 0;
+  const int64_t ngroups = vec ? nvox / 4 : nvox;
+  int bx = (int)((ngroups + 255) / 256);
+  if (bx > 8192) bx = 8192;
+  dim3 grid((unsigned)bx, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+#define VX_SA(CC)                                                                                              \
+  case CC:                                                                                                     \
+    if (vec) hipLaunchKernelGGL((unc_stats_accumulate_kernel<CC, 4>), grid, dim3(256), 0, s, logits, T, nvox, stats); \
+    else hipLaunchKernelGGL((unc_stats_accumulate_kernel<CC, 1>), grid, dim3(256), 0, s, logits, T, nvox, stats);     \
+    break;
+  switch (C) {
+    VX_SA(2) VX_SA(3) VX_SA(4) VX_SA(5) VX_SA(6) VX_SA(7) VX_SA(8)
+    default: VX_FAIL(VX_E_SHAPE, "vx_unc_stats_accumulate: 2 <= C <= 8 (got %d)", C);
+  }
+#undef VX_SA
+  VX_CHECK_LAUNCH("vx_unc_stats_accumulate");
+  return VX_OK;
+}
+
+extern "C" int vx_unc_stats_finalize(const float* stats, int B, int T_total, int C, int64_t nvox, float* mean_prob,
+                                     float* pred_entropy, float* exp_entropy, float* mutual_info, uint8_t* argmax,
+                                     vx_stream_t stream) {
+  if (B <= 0 || T_total <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_unc_stats_finalize: bad shape");
+  if (nvox == 0) return VX_OK;
+  if (!stats || !pred_entropy || !exp_entropy || !mutual_info) VX_FAIL(VX_E_NULL, "vx_unc_stats_finalize: null pointer");
+  const bool vec = vx_aligned16(stats) && vx_aligned16(pred_entropy) && vx_aligned16(exp_entropy) &&
+                   vx_aligned16(mutual_info) && (!mean_prob || vx_aligned16(mean_prob)) &&
+                   (!argmax || (((uintptr_t)argmax) & 3u) == 0) && nvox % 4 == 0;
+  const int64_t ngroups = vec ? nvox / 4 : nvox;
+  int bx = (int)((ngroups + 255) / 256);
+  if (bx > 8192) bx = 8192;
+  dim3 grid((unsigned)bx, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(unc_stats_finalize_kernel<4>, grid, dim3(256), 0, s, stats, C, 1.f / (float)T_total, nvox, mean_prob,
+                       pred_entropy, exp_entropy, mutual_info, argmax);
+  else
+    hipLaunchKernelGGL(unc_stats_finalize_kernel<1>, grid, dim3(256), 0, s, stats, C, 1.f / (float)T_total, nvox, mean_prob,
+                       pred_entropy, exp_entropy, mutual_info, argmax);
+  VX_CHECK_LAUNCH("vx_unc_stats_finalize");
+  return VX_OK;
+}
+
 // per-sample argmax over classes for the probability path (data_carrier_3D.py:281-283)
 template <typename TIn>
 __global__ __launch_bounds__(256) void sample_argmax_kernel(const TIn* __restrict__ x, int C, int64_t nvox, int64_t nbt,

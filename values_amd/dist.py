@@ -54,3 +54,68 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
     if rank != dst:
         return None
     return unpack_maps(torch.cat(lists[0], 0), torch.cat(lists[1], 0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Member-sharded ensembles (BASELINE config C3: 5 members over 8 GPUs).  Work items are (member, volume-block) pairs
+# dealt round-robin over the ranks; a rank adds the sufficient statistics of its items into one buffer
+# [V][C+1][vox]; ONE sum-reduce to rank 0 (RCCL) combines members that ran on different ranks; rank 0 finalises.
+def ensemble_work_items(n_members: int, n_volumes: int, world: int):
+    """[(member, v_lo, v_hi)] per rank.  With fewer members than ranks the volumes are split into
+    ceil(world / n_members) blocks so every rank has work (5 members x 2 volume blocks = 10 items on 8 ranks)."""
+    blocks = max(1, -(-world // n_members))
+    blocks = min(blocks, max(1, n_volumes))
+    items = []
+    for m in range(n_members):
+        for b in range(blocks):
+            lo, hi = shard_range(n_volumes, blocks, b)
+            if hi > lo:
+                items.append((m, lo, hi))
+    return [items[r::world] for r in range(world)]
+
+
+def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int, n_pred: int = 1, dst: int = 0,
+                                 seeds=None, group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """models: the FULL member list (every rank holds all checkpoints; only its items run).  x: (V,1,D,H,W), the
+    same on every rank.  Returns the maps on `dst` (None elsewhere)."""
+    import ctypes as C_
+    from . import _lib
+    from .predict import predict_logits
+    lib = _lib.load()
+    dev = x.device
+    V = x.shape[0]
+    Cc = models[0].num_classes
+    spatial = tuple(x.shape[2:])
+    nvox = 1
+    for s_ in spatial:
+        nvox *= s_
+    stats = torch.zeros((V, Cc + 1) + spatial, dtype=torch.float32, device=dev)
+    for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
+        kw = {"seeds": [seeds[m]]} if seeds is not None else {}
+        logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, **kw)  # (hi-lo, n_pred, C, ...)
+        _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(logits), hi - lo, n_pred, Cc, nvox, _lib.ptr(stats[lo:hi]),
+                                               _lib.stream_ptr()), "vx_unc_stats_accumulate")
+    if world > 1:
+        import torch.distributed as dist
+        dist.reduce(stats, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if rank != dst:
+            return None
+    return finalize_stats(stats, len(models) * n_pred)
+
+
+def finalize_stats(stats: torch.Tensor, t_total: int) -> Dict[str, torch.Tensor]:
+    from . import _lib
+    lib = _lib.load()
+    V, C1 = stats.shape[:2]
+    Cc = C1 - 1
+    spatial = tuple(stats.shape[2:])
+    dev = stats.device
+    nvox = stats[0, 0].numel()
+    out = {k: torch.empty((V,) + spatial, dtype=torch.float32, device=dev) for k in MAP_KEYS}
+    out["mean_softmax"] = torch.empty((V, Cc) + spatial, dtype=torch.float32, device=dev)
+    out["pred_seg_mean"] = torch.empty((V,) + spatial, dtype=torch.uint8, device=dev)
+    _lib.check(lib.vx_unc_stats_finalize(_lib.ptr(stats), V, t_total, Cc, nvox, _lib.ptr(out["mean_softmax"]),
+                                         _lib.ptr(out["pred_entropy"]), _lib.ptr(out["aleatoric_uncertainty"]),
+                                         _lib.ptr(out["epistemic_uncertainty"]), _lib.ptr(out["pred_seg_mean"]),
+                                         _lib.stream_ptr()), "vx_unc_stats_finalize")
+    return out

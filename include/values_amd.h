@@ -221,6 +221,12 @@ int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* 
 int vx_softmax_accumulate(const float* logits, int B, int T, int C, int P0, int P1, int P2, const int32_t* crop,
                           float* sum, float* count, int X, int Y, int Z, int overlap, vx_stream_t stream);
 
+/* Aleatoric-head sampling (predict_cases, test_3D.py:458-469): mu_s [N][2C][nvox] = final_aleatoric output
+ * (mu = first C channels, s = last C, unet3D_module.py:367-369); out [N][T][C][nvox] = mu + exp(s/2) * eps_t with
+ * eps [N][T][C][nvox] injected (nullable: generated from `seed`, N(0,1)); sigma [N][C][nvox] nullable output. */
+int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int N, int T, int C, int64_t nvox,
+                        float* out, float* sigma, vx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and

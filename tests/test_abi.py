@@ -58,11 +58,13 @@ int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx
 
 
 def test_host_only_queries(lib):
-    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 16 * 16 * 27  # Cout padded to one 16-wide MFMA tile
+    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 16 * 16 * 36  # Cout == 8: x-pair packing, 16 rows x (9*4 taps)
+    assert lib.vx_conv3d_k3_packed_floats(16, 16) == 16 * 16 * 27
     assert lib.vx_conv3d_k3_packed_floats(32, 32) == 32 * 32 * 27
     assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1
     assert lib.vx_convT_k2s2_packed_floats(16, 8) == 16 * 8 * 8
     assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
+    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 16 * 16  # x-pair tiles are 32 voxels wide
     assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 

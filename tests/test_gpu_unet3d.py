@@ -252,3 +252,32 @@ def test_sharded_ensemble_statistics_equal_single_pass():
         assert (two[k] - one[k]).abs().max().item() < 2e-6, k
     clear = g["mean_margin"] > 0  # ensemble argmax: compare against the one-pass kernel (same float32 means)
     assert torch.equal(two["pred_seg_mean"], one["pred_seg_mean"]) or clear.any()
+
+
+def test_aleatoric_head_sampling_matches_reference_formula():
+    """test_3D.py:458-469 restated: output = mu + exp(s/2) * eps, softmax, calculate_uncertainty -- with the SAME eps."""
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import unet3d_forward
+    from values_amd import UNet3D, predict_uncertainty
+    from values_amd.formula import formula_tensor
+    sd = formula_unet3d_state_dict(seed_tag=4, aleatoric_loss=True)
+    model = UNet3D(num_classes=2, aleatoric_loss=True)
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    model = model.cuda()
+    x = torch.from_numpy(formula_volume((1, 1, 16, 16, 16), tag=44))
+    Ts = 5
+    eps = torch.from_numpy(formula_tensor((1, Ts, 2, 16, 16, 16), 45, scale=1.7))
+    out = predict_uncertainty([model], x.float().cuda(), n_aleatoric_samples=Ts, eps=[eps])
+    with torch.no_grad():
+        mu, s = unet3d_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x, aleatoric_loss=True, num_classes=2)
+    samples = mu.numpy()[0][None] + np.exp(s.numpy()[0][None] / 2) * eps.numpy()[0]  # (Ts, 2, ...)
+    assert np.abs(out["logits"][0].cpu().numpy() - samples).max() < LOGIT_TOL
+    ref = uo.calculate_uncertainty(uo.softmax(samples, axis=1))
+    for k in KEYS:
+        assert np.abs(out[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
+    # generated noise: standard normal (mean 0, variance 1, no correlation between samples)
+    lg = predict_uncertainty([model], x.float().cuda(), n_aleatoric_samples=64, seeds=[3])["logits"][0]
+    z = ((lg - torch.from_numpy(mu.numpy()[0]).float().cuda()) / torch.exp(torch.from_numpy(s.numpy()[0]).float().cuda() / 2))
+    assert abs(z.mean().item()) < 0.01 and abs(z.var().item() - 1) < 0.02
+    assert abs((z[0] * z[1]).mean().item()) < 0.02
+    assert abs(((z ** 4).mean().item()) - 3.0) < 0.1  # kurtosis of a Gaussian

@@ -85,6 +85,7 @@ SIGNATURES = {
     "vx_unet3d_forward_profiled": (_i, [C.POINTER(UNet3DWeights), C.POINTER(UNet3DRun), _p, _i, C.POINTER(C.c_float),
                                         C.POINTER(C.c_char_p), C.POINTER(_i)]),
     "vx_softmax_accumulate": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vx_aleatoric_sample": (_i, [_p, _p, _u32, _i, _i, _i, _i64, _p, _p, _p]),
     "vx_box_max": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p]),
     "vx_sum_thr": (_i, [_p, _i64, C.c_float, _p, _p]),
 }

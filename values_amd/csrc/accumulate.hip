@@ -66,3 +66,50 @@ extern "C" int vx_softmax_accumulate(const float* logits, int B, int T, int C, i
   VX_CHECK_LAUNCH("vx_softmax_accumulate");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Aleatoric-head sampling (predict_cases, test_3D.py:458-469): one forward gives (mu, s) = split(final_aleatoric);
+// sigma = exp(s / 2); sample t: logits_t = mu + sigma * eps_t, eps ~ N(0, 1).  eps is either injected (parity with
+// the reference's torch.randn stream is impossible otherwise) or generated here: Box-Muller on two avalanche
+// hashes of (seed, sample, element).
+__device__ __forceinline__ float vx_gauss(uint32_t seed, uint32_t a, uint32_t b) {
+  const uint32_t h1 = vx_mix32(a * 0x9E3779B1u ^ vx_mix32(seed ^ (b * 0x85EBCA6Bu + 0x165667B1u)));
+  const uint32_t h2 = vx_mix32(h1 ^ 0x27D4EB2Fu ^ (a * 0xC2B2AE35u));
+  const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+  const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+__global__ __launch_bounds__(256) void aleatoric_sample_kernel(const float* __restrict__ mu_s, const float* __restrict__ eps,
+                                                               uint32_t seed, int N, int T, int C, int64_t nvox,
+                                                               float* __restrict__ out, float* __restrict__ sigma) {
+  const int64_t per = (int64_t)C * nvox;
+  const int64_t total = (int64_t)N * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per);
+    const int64_t r = i - (int64_t)n * per;  // c * nvox + v
+    const float mu = mu_s[(size_t)n * 2 * per + r];
+    const float sg = expf(0.5f * mu_s[(size_t)n * 2 * per + per + r]);
+    if (sigma) sigma[i] = sg;
+    for (int t = 0; t < T; ++t) {
+      const size_t o = ((size_t)n * T + t) * per + r;
+      const float e = eps ? eps[o] : vx_gauss(seed, (uint32_t)r, (uint32_t)(n * T + t));
+      out[o] = fmaf(sg, e, mu);
+    }
+  }
+}
+
+extern "C" int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int N, int T, int C, int64_t nvox,
+                                   float* out, float* sigma, vx_stream_t stream) {
+  if (N <= 0 || T <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_aleatoric_sample: bad shape");
+  if (nvox == 0) return VX_OK;
+  if (!mu_s || !out) VX_FAIL(VX_E_NULL, "vx_aleatoric_sample: null pointer");
+  if ((int64_t)C * nvox >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_aleatoric_sample: sample too large");
+  const int64_t total = (int64_t)N * C * nvox;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(aleatoric_sample_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, mu_s, eps, seed, N, T, C, nvox,
+                     out, sigma);
+  VX_CHECK_LAUNCH("vx_aleatoric_sample");
+  return VX_OK;
+}

@@ -31,17 +31,40 @@ def gaussian_noise_view(x: torch.Tensor, generator: Optional[torch.Generator] = 
 
 
 @torch.no_grad()
+def _predict_logits_aleatoric(models, x, n_samples, eps=None, seeds=None):
+    lib = _lib.load()
+    V, _, D, H, W = x.shape
+    C = models[0].num_classes
+    nvox = D * H * W
+    out = torch.empty((V, n_samples * len(models), C, D, H, W), dtype=torch.float32, device=x.device)
+    for mi, model in enumerate(models):
+        mu, s = model(x)                                   # (V, C, ...) each, views of one (V, 2C, ...) tensor
+        mu_s = torch.cat([mu, s], 1).contiguous()
+        part = torch.empty((V, n_samples, C, D, H, W), dtype=torch.float32, device=x.device)
+        e = None if eps is None else eps[mi].to(x.device, torch.float32).contiguous()
+        seed = int(seeds[mi]) if seeds is not None else 1234 + mi
+        _lib.check(lib.vx_aleatoric_sample(_lib.ptr(mu_s), _lib.ptr(e), seed & 0xFFFFFFFF, V, n_samples, C, nvox,
+                                           _lib.ptr(part), None, _lib.stream_ptr()), "vx_aleatoric_sample")
+        out[:, mi * n_samples:(mi + 1) * n_samples] = part
+    return out
+
+
 def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
-                   x_noise: Optional[torch.Tensor] = None, dropout_masks=None, seeds=None) -> torch.Tensor:
+                   x_noise: Optional[torch.Tensor] = None, dropout_masks=None, seeds=None,
+                   n_aleatoric_samples: int = 10, eps=None) -> torch.Tensor:
     """x: (V,1,D,H,W).  Returns logits (V, n_total, C, D,H,W) f32 on the device, n_total = passes per volume in
     pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests)."""
     _lib.require_gpu()
     dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
     x = x.to(dev, torch.float32)
     V, _, D, H, W = x.shape
+    aleatoric = bool(getattr(models[0], "aleatoric_loss", False)) and not tta
+    if aleatoric:
+        # test_3D.py:458-469: ONE forward -> (mu, s); n_pred := n_aleatoric_samples draws of mu + exp(s/2) * eps
+        return _predict_logits_aleatoric(models, x, n_aleatoric_samples, eps=eps, seeds=seeds)
     per_model = 16 if tta else n_pred
     n_total = per_model * len(models)
-    C = models[0].num_classes * (2 if getattr(models[0], "aleatoric_loss", False) else 1)
+    C = models[0].num_classes
     logits = torch.empty((V, n_total, C, D, H, W), dtype=torch.float32, device=dev)
     flat = logits.view(V * n_total, C, D, H, W)
     vidx = torch.arange(V, device=dev, dtype=torch.int32)

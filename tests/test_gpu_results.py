@@ -1,0 +1,76 @@
+"""GPU: inference -> results directory -> ExperimentDataloader -> aggregate_uncertainties, end to end."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from values_amd.formula import formula_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def test_end_to_end_results_and_aggregation(tmp_path):
+    from oracle import aggregation_oracle as ao
+    from tests.test_gpu_unet3d import make_model
+    from values_amd import nifti, predict_image_sliding
+    from values_amd.experiment import ExperimentDataloader, ExperimentVersion, aggregate_uncertainties
+    from values_amd.results import results_dir, save_case
+    model = make_model(do_dropout=True)
+    d = results_dir(str(tmp_path), "Dropout", "fold0_seed123", "id")
+    keep = {}
+    for i in range(2):
+        img = torch.from_numpy(formula_volume((32, 32, 32), tag=60 + i))
+        out = predict_image_sliding([model], img, patch_size=32, n_pred=4, seeds=[i])
+        save_case(d, f"case{i}", out["softmax_sum"], out, data=img, num_predictions=out["num_predictions"])
+        keep[f"case{i}"] = out
+    ev = ExperimentVersion(base_path=tmp_path, naming_scheme_version="fold{fold}_seed{seed}", pred_model="Dropout",
+                           image_ending=".nii.gz", unc_ending=".nii.gz",
+                           unc_types=["predictive_uncertainty", "epistemic_uncertainty"], aggregations=None,
+                           n_reference_segs=0, fold=0, seed=123)
+    dl = ExperimentDataloader(ev, "id")
+    assert dl.image_ids == ["case0", "case1"]
+    m = dl.get_unc_map("case1", "epistemic_uncertainty")
+    np.testing.assert_array_equal(m, keep["case1"]["epistemic_uncertainty"].cpu().numpy())
+    np.testing.assert_array_equal(dl.get_mean_pred_seg("case0"), keep["case0"]["pred_seg_mean"].cpu().numpy())
+    ref = "evaluation.uncertainty_aggregation.aggregate_uncertainties."
+    aggs = {"patch_level": {"_target_": ref + "patch_level_aggregation", "patch_size": 10},
+            "image_level": {"_target_": ref + "image_level_aggregation"},
+            "threshold": {"_target_": ref + "threshold_aggregation", "threshold": 0.01}}
+    aggregate_uncertainties(dl, aggs)
+    for unc, key in (("predictive_uncertainty", "pred_entropy"), ("epistemic_uncertainty", "epistemic_uncertainty")):
+        j = json.load(open(dl.dataset_path / f"aggregated_{unc}.json"))
+        for cid in ("case0", "case1"):
+            img = keep[cid][key].cpu().numpy()
+            r = j[f"{cid}.nii.gz"]
+            o = ao.patch_level_aggregation(img, patch_size=10)
+            assert r["patch_level"]["max_score"] == pytest.approx(o["max_score"], rel=1e-9)
+            assert [list(b) for b in r["patch_level"]["bounding_box"]] == [list(b) for b in o["bounding_box"]]
+            assert r["image_level"]["max_score"] == pytest.approx(ao.image_level_aggregation(img)["max_score"], rel=1e-9)
+            assert r["threshold"]["max_score"] == pytest.approx(float(ao.threshold_aggregation(img, 0.01)["max_score"]), rel=1e-6)
+    assert set(dl.get_aggregated_unc_files_dict()) == {"predictive_uncertainty", "epistemic_uncertainty"}
+
+
+def test_softmax_model_gets_one_minus_msr_maps(tmp_path):
+    """ExperimentDataloader._setup_pred_entropy_softmax (experiment_dataloader.py:51-61): a plain Softmax model has
+    no uncertainty maps; pred_entropy := 1 - max softmax is created from pred_prob on first use."""
+    from tests.test_gpu_unet3d import make_model
+    from values_amd import nifti, predict_uncertainty
+    from values_amd.experiment import ExperimentDataloader, ExperimentVersion
+    from values_amd.results import results_dir, save_case
+    model = make_model(do_dropout=False)
+    x = torch.from_numpy(formula_volume((1, 1, 16, 16, 16), tag=70)).float().cuda()
+    out = predict_uncertainty([model], x, n_pred=1)
+    sm = torch.softmax(out["logits"][0], 1)  # (1, C, ...)
+    d = results_dir(str(tmp_path), "Softmax", "fold0_seed123", "id")
+    save_case(d, "c0", sm)
+    assert not os.path.exists(os.path.join(d, "pred_entropy"))
+    ev = ExperimentVersion(base_path=tmp_path, naming_scheme_version="fold{fold}_seed{seed}", pred_model="Softmax",
+                           image_ending=".nii.gz", unc_ending=".nii.gz", unc_types=["predictive_uncertainty"],
+                           aggregations=None, n_reference_segs=0, fold=0, seed=123)
+    dl = ExperimentDataloader(ev, "id")
+    got = dl.get_unc_map("c0", "predictive_uncertainty")
+    ref = 1 - sm[0].double().cpu().numpy().max(0)
+    np.testing.assert_allclose(got, ref, atol=1e-12)
+    assert dl.get_mean_pred_seg("c0").shape == (16, 16, 16)  # Softmax models use the _01 segmentation

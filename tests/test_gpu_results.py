@@ -47,7 +47,7 @@ def test_end_to_end_results_and_aggregation(tmp_path):
             o = ao.patch_level_aggregation(img, patch_size=10)
             assert r["patch_level"]["max_score"] == pytest.approx(o["max_score"], rel=1e-9)
             assert [list(b) for b in r["patch_level"]["bounding_box"]] == [list(b) for b in o["bounding_box"]]
-            assert r["image_level"]["max_score"] == pytest.approx(ao.image_level_aggregation(img)["max_score"], rel=1e-9)
+            assert r["image_level"]["max_score"] == pytest.approx(ao.image_level_aggregation(img)["max_score"], rel=1e-6)  # reference sums in f32
             assert r["threshold"]["max_score"] == pytest.approx(float(ao.threshold_aggregation(img, 0.01)["max_score"]), rel=1e-6)
     assert set(dl.get_aggregated_unc_files_dict()) == {"predictive_uncertainty", "epistemic_uncertainty"}
 

@@ -169,3 +169,51 @@ def test_aggregations_match_reference():
     mine = agg.patch_level_aggregation(img2, patch_size=10)
     assert mine["max_score"] == pytest.approx(g["img2d"]["patch10"]["max_score"], rel=1e-6)
     assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in g["img2d"]["patch10"]["bounding_box"]]
+
+
+def _hrnet_fixture():
+    import json as _json
+    from values_amd.formula import formula_state_dict_from_shapes
+    g = load_npz("hrnet_small.npz")
+    shapes = _json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    return g, shapes, sd
+
+
+def hrnet_masks(g, t):
+    out = []
+    for i in range(4):
+        shape = tuple(int(v) for v in g[f"maskshape_{i}"])
+        n = int(np.prod(shape))
+        out.append(np.unpackbits(g[f"mask_{t}_{i}"])[:n].astype(bool).reshape(shape))
+    return out
+
+
+def test_hrnet_oracle_matches_reference():
+    """tests/golden/hrnet_small.npz: the reference HighResolutionNet (training-mode BN, DROPOUT_FINAL, float32 as
+    test_2D.py runs it) with its own F.dropout masks captured; process_output's zero-channel + calculate_uncertainty."""
+    from oracle.hrnet_oracle import hrnet_forward
+    from values_amd.formula import HRNET_SMALL_EXTRA
+    g, shapes, sd = _hrnet_fixture()
+    x = torch.from_numpy(g["input"])
+    np.testing.assert_array_equal(g["input"], formula_tensor((2, 3, 64, 96), tag=81, scale=1.5).astype(np.float32))
+    T = g["logits"].shape[0]
+    with torch.no_grad():
+        for t in range(T):
+            masks = [torch.from_numpy(m) for m in hrnet_masks(g, t)]
+            y = hrnet_forward(HRNET_SMALL_EXTRA, sd, x, dropout_masks=masks).numpy()
+            assert np.abs(y - g["logits"][t]).max() < 2e-5  # float32 both sides, same ATen kernels
+        extra = dict(HRNET_SMALL_EXTRA, DROPOUT_FINAL=False)
+        y = hrnet_forward(extra, sd, x).numpy()
+        assert np.abs(y - g["logits_nodrop"]).max() < 2e-5
+        # float64 oracle vs float32 reference: what float32 rounding costs on this net (bounds the GPU tolerance)
+        sd64 = {k: v.double() for k, v in sd.items()}
+        y64 = hrnet_forward(HRNET_SMALL_EXTRA, sd64, x.double(),
+                            dropout_masks=[torch.from_numpy(m) for m in hrnet_masks(g, 0)]).numpy()
+        assert np.abs(y64 - g["logits"][0]).max() < 1e-3
+    sm = torch.softmax(torch.from_numpy(g["logits"]), dim=2)
+    sm1 = torch.cat([sm, torch.zeros(T, 2, 1, 64, 96)], dim=2).numpy()
+    for b in range(2):
+        r = unc.calculate_uncertainty(sm1[:, b])
+        for k in KEYS:
+            np.testing.assert_allclose(r[k], g[f"{k}_{b}"], atol=1e-6)

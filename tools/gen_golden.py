@@ -320,8 +320,78 @@ def gen_agg():
     print("G6 agg_kat.json", res["vol24"]["patch10"])
 
 
+# ----------------------------------------------------------------------------- G5
+class _Cfg(dict):
+    """attribute + item access, like the yacs/omegaconf object HighResolutionNet expects (hrnet_module.py:343-346)."""
+    def __getattr__(self, k):
+        v = self[k]
+        return _Cfg(v) if isinstance(v, dict) else v
+
+
+def gen_hrnet():
+    import copy
+    import uncertainty_modeling.models.hrnet_module as ref_hr
+    from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
+    extra = copy.deepcopy(HRNET_SMALL_EXTRA)
+    ncls = 4
+    cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+                "DATASET": {"NUM_CLASSES": ncls}})
+    torch.manual_seed(7)
+    model = ref_hr.HighResolutionNet(cfg)  # stays in training mode like the reference (SURVEY D5)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = formula_state_dict_from_shapes(shapes)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v).float()
+    model.load_state_dict(full)
+    x = torch.from_numpy(formula_tensor((2, 3, 64, 96), tag=81, scale=1.5)).float()
+    # capture the 4 F.dropout keep-masks of every pass
+    masks = []
+    orig = F.dropout
+
+    def spy(inp, p=0.5, training=True, inplace=False):
+        out = orig(inp, p, training, inplace)
+        masks.append(((out != 0) | (inp == 0)).clone())
+        return out
+
+    ref_hr.F.dropout = spy
+    out = {"input": x.numpy(), "shapes_json": np.frombuffer(json.dumps({k: list(v) for k, v in shapes.items()}).encode(), dtype=np.uint8)}
+    T = 3
+    logits = []
+    torch.set_grad_enabled(False)  # test_2D.py:329
+    for t in range(T):
+        masks.clear()
+        y = model.forward(x)
+        logits.append(y.numpy().copy())
+        for i, m in enumerate(masks):
+            out[f"mask_{t}_{i}"] = np.packbits(m.numpy().astype(np.uint8).ravel())
+            out[f"maskshape_{i}"] = np.array(m.shape)
+    ref_hr.F.dropout = orig
+    logits = np.stack(logits)  # (T, B, C, H, W)
+    out["logits"] = logits
+    sm = F.softmax(torch.from_numpy(logits), dim=2)
+    # process_output (test_2D.py:205-248): zero channel appended, per-image calculate_uncertainty on (T, C+1, H, W) f32
+    sm1 = torch.cat([sm, torch.zeros(T, 2, 1, 64, 96)], dim=2)
+    for b in range(2):
+        unc = _t(ref_t3.calculate_uncertainty(sm1[:, b]))
+        for k, v in unc.items():
+            out[f"{k}_{b}"] = v
+    # dropout off (eval-free): DROPOUT_FINAL False -> deterministic forward, plus stage-4 feature checksums
+    extra2 = copy.deepcopy(extra)
+    extra2["DROPOUT_FINAL"] = False
+    cfg2 = _Cfg({"MODEL": {"EXTRA": extra2, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+                 "DATASET": {"NUM_CLASSES": ncls}})
+    m2 = ref_hr.HighResolutionNet(cfg2)
+    m2.load_state_dict(full)
+    out["logits_nodrop"] = m2.forward(x).numpy()
+    torch.set_grad_enabled(True)
+    np.savez_compressed(os.path.join(OUT, "hrnet_small.npz"), **out)
+    print("G5 hrnet_small.npz", logits.shape, os.path.getsize(os.path.join(OUT, "hrnet_small.npz")) / 1e6, "MB; params",
+          sum(int(np.prod(s)) for s in shapes.values()), "logit range", float(logits.min()), float(logits.max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -334,3 +404,5 @@ if __name__ == "__main__":
         gen_patch_index()
     if "agg" in which:
         gen_agg()
+    if "hrnet" in which:
+        gen_hrnet()

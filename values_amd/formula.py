@@ -106,3 +106,57 @@ def formula_volume(shape, tag: int = 7) -> np.ndarray:
     vol = vol / np.sqrt((vol * vol).mean())
     out = np.broadcast_to(vol, shape).copy()
     return out.astype(np.float32).astype(np.float64)
+
+
+def _name_tag(name: str) -> int:
+    import zlib
+    return zlib.crc32(name.encode()) & 0xFFFFF
+
+
+def formula_state_dict_from_shapes(shapes, seed_tag: int = 0):
+    """Weights for an arbitrary conv/BN network (the HRNet fixtures): a pure function of (parameter NAME, shape), so
+    it does not depend on state-dict order.  Conv weights ~ U(+-sqrt(3/fan_in)), BN gamma in [0.7, 1.3], BN beta and
+    conv biases in [-0.2, 0.2].  Buffers (running_mean/var, num_batches_tracked) are left at their defaults."""
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        if name.endswith("running_mean") or name.endswith("running_var") or name.endswith("num_batches_tracked"):
+            continue
+        tag = _name_tag(name) + 7919 * seed_tag
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            w = formula_tensor(shape, tag, scale=math.sqrt(3.0 / fan_in))
+        elif name.endswith(".weight"):
+            w = 1.0 + formula_tensor(shape, tag, scale=0.3)
+        else:
+            w = formula_tensor(shape, tag, scale=0.2)
+        sd[name] = w.astype(np.float32).astype(np.float64)
+    return sd
+
+
+HRNET_SMALL_EXTRA = {
+    "DROPOUT_FINAL": True, "FINAL_CONV_KERNEL": 1,
+    "STAGE1": {"NUM_MODULES": 1, "NUM_BRANCHES": 1, "BLOCK": "BOTTLENECK", "NUM_BLOCKS": [2], "NUM_CHANNELS": [32],
+               "FUSE_METHOD": "SUM"},
+    "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "BLOCK": "BASIC", "NUM_BLOCKS": [2, 2], "NUM_CHANNELS": [16, 32],
+               "FUSE_METHOD": "SUM"},
+    "STAGE3": {"NUM_MODULES": 2, "NUM_BRANCHES": 3, "BLOCK": "BASIC", "NUM_BLOCKS": [2, 2, 2],
+               "NUM_CHANNELS": [16, 32, 64], "FUSE_METHOD": "SUM"},
+    "STAGE4": {"NUM_MODULES": 1, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [2, 2, 2, 2],
+               "NUM_CHANNELS": [16, 32, 64, 128], "FUSE_METHOD": "SUM"},
+}
+
+
+def hrnet_w48_extra(dropout_final=True):
+    """The shipped configs/model/hrnet_config*.yaml layout (W48)."""
+    return {
+        "DROPOUT_FINAL": dropout_final, "FINAL_CONV_KERNEL": 1,
+        "STAGE1": {"NUM_MODULES": 1, "NUM_BRANCHES": 1, "BLOCK": "BOTTLENECK", "NUM_BLOCKS": [4], "NUM_CHANNELS": [64],
+                   "FUSE_METHOD": "SUM"},
+        "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [48, 96],
+                   "FUSE_METHOD": "SUM"},
+        "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4],
+                   "NUM_CHANNELS": [48, 96, 192], "FUSE_METHOD": "SUM"},
+        "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4, 4],
+                   "NUM_CHANNELS": [48, 96, 192, 384], "FUSE_METHOD": "SUM"},
+    }

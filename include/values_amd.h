@@ -212,6 +212,48 @@ int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* 
                                int max_launches, float* ms, const char** labels, int* n_launches);
 
 /* ---------------------------------------------------------------------------------
+ * 2D path (HRNet, uncertainty_modeling/models/hrnet_module.py).  Activations: channels-last [N][H][W][pitch] fp32.
+ * K15: 3x3 stride 1 / 3x3 stride 2 / 1x1 convolution, padding k/2 (hrnet_module.py:37-41, 85-93, 349-358, 411-428;
+ * bias only on last_layer), raw output + per-tile (sum, sumsq) partials [ntiles_total][Cout][2] for the
+ * TRAINING-mode BatchNorm that follows (batch statistics over N,H,W; the reference never calls .eval()).
+ * Cin must be a multiple of 16 (pad image channels with zeros), weights packed by vx_pack_conv2d. */
+typedef struct vx_conv2d_args {
+  const float* in; int32_t in_pitch;
+  const float* w_packed; const float* bias; /* bias nullable, [Cout] */
+  float* out; int32_t out_pitch, out_coff;
+  int32_t N, H, W, Cin, Cout, KS, S;        /* KS in {1,3}; S in {1,2} (1x1: S = 1) */
+  float* stats_partial;                     /* nullable */
+} vx_conv2d_args;
+int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS);
+int vx_pack_conv2d(const float* w_torch /* (Cout,Cin,KS,KS) */, float* w_packed, int Cin, int Cout, int KS, vx_stream_t stream);
+int vx_conv2d_tiles(int H, int W, int KS, int S); /* tiles per image (stats_partial has N * this entries) */
+int vx_conv2d(const vx_conv2d_args* a, vx_stream_t stream);
+
+/* K16: BatchNorm2d in training mode: partials -> scale = gamma * rstd, shift = beta - mean * scale
+ * (biased variance over count = N*OH*OW, eps 1e-5; hrnet_module.py:30, BN_MOMENTUM side effect not reproduced). */
+int vx_bn_finalize(const float* stats_partial, int ntiles, int C, int64_t count, float eps, const float* gamma,
+                   const float* beta, float* scale, float* shift, vx_stream_t stream);
+
+/* K16/K17/K18: out[.., out_coff + c] = act( add + scale[c] * G(drop(x))[c] + shift[c] ); G = identity (OH,OW == H,W) or
+ * F.interpolate(mode="bilinear", align_corners=False) from (H,W) to (OH,OW); add / scale / drop optional; `add` may
+ * alias `out` (term-by-term SUM fusion, hrnet_module.py:316-333). */
+typedef struct vx_affine_args {
+  const float* x; int32_t x_pitch;
+  const float* scale; const float* shift;   /* nullable together */
+  const float* add; int32_t add_pitch;      /* nullable; [N][OH][OW][add_pitch] */
+  float* out; int32_t out_pitch, out_coff;
+  int32_t N, H, W, C, OH, OW;
+  int32_t act;                              /* VX_ACT_NONE | VX_ACT_RELU */
+  int32_t drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* F.dropout(x, 0.5, training=True) on x */
+} vx_affine_args;
+int vx_affine_gather(const vx_affine_args* a, vx_stream_t stream);
+
+/* Final upsample of the class logits to the input size (hrnet_module.py:667-669) into the reference's NCHW layout:
+ * image n -> slot dst[n] (nullable) of out [slots][C][OH][OW]; flip[n] & 1 un-flips a HorizontalFlip TTA view. */
+int vx_bilinear_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
+                     const int32_t* dst, const int32_t* flip, vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * K14: sliding-window accumulation of a batch of patches (DataCarrier3D.concat_data,
  * uncertainty_modeling/data_carrier_3D.py:137-179, with the F.softmax of test_3D.py:472 fused):
  *   sum[t][c][crop_b] += softmax_c(logits[b][t]);  count[crop_b] += 1 (once per patch, the reference's pred_idx == 0)

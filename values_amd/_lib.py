@@ -47,6 +47,20 @@ class ConvTArgs(C.Structure):
                 ("out_xblk", _i32), ("out_half", _i32)]
 
 
+class Conv2dArgs(C.Structure):
+    _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
+                ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
+                ("N", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32), ("KS", _i32), ("S", _i32),
+                ("stats_partial", _p)]
+
+
+class AffineArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i32), ("scale", _p), ("shift", _p), ("add", _p), ("add_pitch", _i32),
+                ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
+                ("N", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("OH", _i32), ("OW", _i32),
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+
+
 class UNet3DWeights(C.Structure):
     _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
                 ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32)]
@@ -86,6 +100,13 @@ SIGNATURES = {
                                         C.POINTER(C.c_char_p), C.POINTER(_i)]),
     "vx_softmax_accumulate": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vx_aleatoric_sample": (_i, [_p, _p, _u32, _i, _i, _i, _i64, _p, _p, _p]),
+    "vx_conv2d_packed_floats": (_i64, [_i, _i, _i]),
+    "vx_pack_conv2d": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vx_conv2d_tiles": (_i, [_i, _i, _i, _i]),
+    "vx_conv2d": (_i, [C.POINTER(Conv2dArgs), _p]),
+    "vx_bn_finalize": (_i, [_p, _i, _i, _i64, C.c_float, _p, _p, _p, _p, _p]),
+    "vx_affine_gather": (_i, [C.POINTER(AffineArgs), _p]),
+    "vx_bilinear_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vx_box_max": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p]),
     "vx_sum_thr": (_i, [_p, _i64, C.c_float, _p, _p]),
 }

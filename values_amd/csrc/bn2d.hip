@@ -1,0 +1,174 @@
+// K16/K17/K18 of the 2D (HRNet) path, all HBM-bound streaming kernels on channels-last fp32 [N][H][W][pitch]:
+//   vx_bn_finalize      TRAINING-mode BatchNorm2d statistics (hrnet_module.py:30, 50, 55 ...): reduce the
+//                       conv epilogue's per-tile (sum, sumsq) partials over the whole batch in float64 ->
+//                       scale[c] = gamma * rstd, shift[c] = beta - mean * scale (biased variance, eps 1e-5).
+//   vx_affine_gather    out = act( [add] + scale[c] * G(drop(x)) + shift[c] ), where G is the identity or the
+//                       bilinear resize of F.interpolate(mode="bilinear", align_corners=False)
+//                       (hrnet_module.py:324-329, 650-658).  One kernel covers: BN+ReLU, BN + residual + ReLU (block
+//                       ends, :72-75), the SUM fusion of HighResolutionModule (:316-333, accumulating term by term in
+//                       the reference's order), F.dropout on the stage-4 outputs (:642-646) fused with their upsample
+//                       into the 720-channel concat buffer (torch.cat never runs).
+//   vx_bilinear_nchw    final upsample of the class logits to the input size, written in the reference's NCHW layout
+//                       into the pred_idx slot (hrnet_module.py:667-669; test_2D.py:302-316).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C,
+                                                          double inv_count, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double s_s[4], s_q[4];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+    s += (double)partial[((size_t)t * C + c) * 2 + 0];
+    q += (double)partial[((size_t)t * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_s[threadIdx.x >> 6] = s; s_q[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+    q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+    const double mu = s * inv_count;
+    double var = q * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    scale[c] = (float)(g * rstd);
+    shift[c] = (float)(b - mu * g * rstd);
+  }
+}
+
+extern "C" int vx_bn_finalize(const float* stats_partial, int ntiles, int C, int64_t count, float eps, const float* gamma,
+                              const float* beta, float* scale, float* shift, vx_stream_t stream) {
+  if (!stats_partial || !scale || !shift) VX_FAIL(VX_E_NULL, "vx_bn_finalize: null pointer");
+  if (ntiles <= 0 || C <= 0 || count <= 0) VX_FAIL(VX_E_SHAPE, "vx_bn_finalize: empty");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, stats_partial, ntiles, C,
+                     1.0 / (double)count, eps, gamma, beta, scale, shift);
+  VX_CHECK_LAUNCH("vx_bn_finalize");
+  return VX_OK;
+}
+
+// bilinear source coordinates of F.interpolate(align_corners=False): src = (dst + 0.5) * in/out - 0.5, clamped at 0
+__device__ __forceinline__ void bil_coord(int d, int in, float ratio, int& i0, int& i1, float& l1) {
+  float s = ((float)d + 0.5f) * ratio - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+template <bool RESIZE>
+__global__ __launch_bounds__(256) void affine_gather_kernel(vx_affine_args a, int64_t total) {
+  const int C4 = a.C / 4;
+  const float ry = (float)a.H / (float)a.OH, rx = (float)a.W / (float)a.OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int c = (int)(r % C4) * 4; r /= C4;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH); r /= a.OH;
+    const int n = (int)r;
+    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+    auto fetch = [&](int y, int x) {
+      const size_t pix = ((size_t)n * a.H + y) * a.W + x;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + pix * a.x_pitch + c);
+      if (a.drop_mode == VX_DROP_HASH) {
+        const uint32_t bits = vx_drop_bits4(dkey, (uint32_t)((y * a.W + x) * a.C + c));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+      } else if (a.drop_mode == VX_DROP_MASK) {
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + pix * a.C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+      }
+      return v;
+    };
+    f32x4 v;
+    if (RESIZE) {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      bil_coord(oy, a.H, ry, y0, y1, ly);
+      bil_coord(ox, a.W, rx, x0, x1, lx);
+      const f32x4 v00 = fetch(y0, x0), v01 = fetch(y0, x1), v10 = fetch(y1, x0), v11 = fetch(y1, x1);
+      // ATen upsample_bilinear2d: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (w0lambda * v10 + w1lambda * v11)
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    } else {
+      v = fetch(oy, ox);
+    }
+    if (a.scale) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+      v = v * sc + sh;
+    }
+    const size_t opix = ((size_t)n * a.OH + oy) * a.OW + ox;
+    if (a.add) v = *reinterpret_cast<const f32x4*>(a.add + opix * a.add_pitch + c) + v;
+    if (a.act == VX_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a.out + opix * a.out_pitch + a.out_coff + c) = v;
+  }
+}
+
+extern "C" int vx_affine_gather(const vx_affine_args* ap, vx_stream_t stream) {
+  if (!ap) VX_FAIL(VX_E_NULL, "vx_affine_gather: null args");
+  const vx_affine_args& a = *ap;
+  if (!a.x || !a.out) VX_FAIL(VX_E_NULL, "vx_affine_gather: null tensor");
+  if ((a.scale == nullptr) != (a.shift == nullptr)) VX_FAIL(VX_E_NULL, "vx_affine_gather: scale/shift must come together");
+  if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0 || a.C <= 0 || a.C % 4)
+    VX_FAIL(VX_E_SHAPE, "vx_affine_gather: bad shape (C must be a multiple of 4)");
+  if (a.x_pitch % 4 || a.x_pitch < a.C || a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.C ||
+      (a.add && (a.add_pitch % 4 || a.add_pitch < a.C)))
+    VX_FAIL(VX_E_ALIGN, "vx_affine_gather: pitches/offsets must be multiples of 4 floats");
+  if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_affine_gather: mask mode without mask");
+  if (a.act != VX_ACT_NONE && a.act != VX_ACT_RELU) VX_FAIL(VX_E_DTYPE, "vx_affine_gather: act must be none or relu");
+  const int64_t total = (int64_t)a.N * a.OH * a.OW * (a.C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (a.OH != a.H || a.OW != a.W)
+    hipLaunchKernelGGL(affine_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, a, total);
+  else
+    hipLaunchKernelGGL(affine_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, a, total);
+  VX_CHECK_LAUNCH("vx_affine_gather");
+  return VX_OK;
+}
+
+__global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* __restrict__ x, int x_pitch, int N, int H, int W,
+                                                            int C, int OH, int OW, float* __restrict__ out,
+                                                            const int32_t* __restrict__ dst, const int32_t* __restrict__ flip) {
+  const float ry = (float)H / (float)OH, rx = (float)W / (float)OW;
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_coord(oy, H, ry, y0, y1, ly);
+    bil_coord(ox, W, rx, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p00 = x + (((size_t)n * H + y0) * W + x0) * x_pitch;
+    const float* p01 = x + (((size_t)n * H + y0) * W + x1) * x_pitch;
+    const float* p10 = x + (((size_t)n * H + y1) * W + x0) * x_pitch;
+    const float* p11 = x + (((size_t)n * H + y1) * W + x1) * x_pitch;
+    const int slot = dst ? dst[n] : n;
+    const int wx = (flip && (flip[n] & 1)) ? OW - 1 - ox : ox;   // un-flip of a HorizontalFlip TTA view (test_2D.py:304-309)
+    float* o = out + (size_t)slot * C * OH * OW + (size_t)oy * OW + wx;
+    for (int c = 0; c < C; ++c)
+      o[(size_t)c * OH * OW] = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+  }
+}
+
+extern "C" int vx_bilinear_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
+                                const int32_t* dst, const int32_t* flip, vx_stream_t stream) {
+  if (!x || !out) VX_FAIL(VX_E_NULL, "vx_bilinear_nchw: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || x_pitch < C) VX_FAIL(VX_E_SHAPE, "vx_bilinear_nchw: bad shape");
+  const int64_t total = (int64_t)N * OH * OW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(bilinear_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_pitch, N, H, W, C, OH, OW,
+                     out, dst, flip);
+  VX_CHECK_LAUNCH("vx_bilinear_nchw");
+  return VX_OK;
+}

@@ -1,0 +1,115 @@
+"""GPU: values_amd.HighResolutionNet (HIP) vs the golden fixture produced by the imported reference class (float32,
+training-mode BatchNorm, DROPOUT_FINAL masks injected) and vs the float64 oracle.
+
+Tolerance: the reference's 2D path is float32 end to end; its own logits differ from a float64 evaluation of the same
+network by up to ~1e-3 (test_hrnet_oracle_matches_reference bounds it).  The HIP path is held to that float64 oracle
+at the same order, and the maps computed from equal logits stay within 1e-4."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz
+from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes, formula_tensor
+
+pytestmark = pytest.mark.gpu
+KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
+
+
+def small_cfg(dropout_final=True, ncls=4):
+    extra = dict(HRNET_SMALL_EXTRA, DROPOUT_FINAL=dropout_final)
+    return {"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+            "DATASET": {"NUM_CLASSES": ncls}}
+
+
+def fixture():
+    g = load_npz("hrnet_small.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    return g, shapes, sd
+
+
+def masks_of(g, t):
+    out = []
+    for i in range(4):
+        shape = tuple(int(v) for v in g[f"maskshape_{i}"])
+        out.append(torch.from_numpy(np.unpackbits(g[f"mask_{t}_{i}"])[:int(np.prod(shape))].astype(bool).reshape(shape)))
+    return out
+
+
+def make(dropout_final=True):
+    from values_amd.hrnet import HighResolutionNet
+    g, shapes, sd = fixture()
+    m = HighResolutionNet(small_cfg(dropout_final))
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert ours == {k: tuple(v) for k, v in shapes.items()}          # identical state-dict names and shapes
+    missing = m.load_state_dict(sd, strict=False)                    # buffers (running stats) keep their defaults
+    assert not missing.unexpected_keys
+    assert all(k.endswith(("running_mean", "running_var", "num_batches_tracked")) for k in missing.missing_keys)
+    return m.cuda(), g, sd
+
+
+def test_hrnet_golden_no_dropout():
+    from oracle.hrnet_oracle import hrnet_forward
+    m, g, sd = make(dropout_final=False)
+    x = torch.from_numpy(g["input"]).cuda()
+    y = m(x)
+    assert y.shape == (2, 4, 64, 96)
+    err_ref = np.abs(y.cpu().numpy() - g["logits_nodrop"]).max()
+    with torch.no_grad():
+        y64 = hrnet_forward(dict(HRNET_SMALL_EXTRA, DROPOUT_FINAL=False), {k: v.double() for k, v in sd.items()},
+                            torch.from_numpy(g["input"]).double()).numpy()
+    err_o = np.abs(y.cpu().numpy() - y64).max()
+    ref_o = np.abs(g["logits_nodrop"] - y64).max()
+    print(f"max|d| hip-vs-reference(f32) {err_ref:.2e}, hip-vs-oracle(f64) {err_o:.2e}, reference(f32)-vs-oracle(f64) {ref_o:.2e}")
+    assert err_o < max(2 * ref_o, 5e-4)
+    assert err_ref < 2e-3
+
+
+def test_hrnet_golden_mc_dropout_final_and_maps():
+    from values_amd import uncertainty_maps
+    m, g, sd = make(dropout_final=True)
+    x = torch.from_numpy(g["input"]).cuda()
+    T = g["logits"].shape[0]
+    lg = m.forward_samples(x, T, dropout_masks=[masks_of(g, t) for t in range(T)])
+    assert lg.shape == (T, 2, 4, 64, 96)
+    err = np.abs(lg.cpu().numpy() - g["logits"]).max()
+    assert err < 2e-3, err
+    # process_output (test_2D.py:205-248): per image, (T, C+1, H, W) softmax with a zero channel -> calculate_uncertainty
+    sm = torch.softmax(lg, dim=2)
+    sm1 = torch.cat([sm, torch.zeros(T, 2, 1, 64, 96, device="cuda")], dim=2)
+    for b in range(2):
+        u = uncertainty_maps(sm1[:, b].unsqueeze(0).contiguous())
+        for k, kk in zip(KEYS, ("pred_entropy", "expected_entropy", "mutual_information")):
+            d = np.abs(u[kk][0].cpu().numpy() - g[f"{k}_{b}"]).max()
+            assert d < 1e-3, (k, d)
+    # the same maps from the REFERENCE's logits: isolates the reduction (must hold the 1e-4 of the north star)
+    smr = torch.softmax(torch.from_numpy(g["logits"]).cuda(), dim=2)
+    smr1 = torch.cat([smr, torch.zeros(T, 2, 1, 64, 96, device="cuda")], dim=2)
+    for b in range(2):
+        u = uncertainty_maps(smr1[:, b].unsqueeze(0).contiguous())
+        for k, kk in zip(KEYS, ("pred_entropy", "expected_entropy", "mutual_information")):
+            assert np.abs(u[kk][0].cpu().numpy() - g[f"{k}_{b}"]).max() < 1e-5
+
+
+def test_hrnet_hash_dropout_and_properties():
+    m, g, sd = make(dropout_final=True)
+    x = torch.from_numpy(g["input"]).cuda()
+    a = m.forward_samples(x, 3, seeds=[1, 2, 3])
+    b = m.forward_samples(x, 3, seeds=[1, 2, 3])
+    assert torch.equal(a, b)                       # deterministic, no atomics
+    assert not torch.equal(a[0], a[1])             # samples differ
+    # batch statistics: an image's logits DO depend on its batch mates (training-mode BN)
+    single = m.forward_samples(x[:1], 1, seeds=[1])
+    assert (single[0, 0] - a[0, 0]).abs().max().item() > 1e-3
+    # un-flip of a HorizontalFlip view
+    xf = torch.flip(x, [-1])
+    yf = m.forward_samples(xf, 1, seeds=[5], hflip_back=True)
+    yn = m.forward_samples(xf, 1, seeds=[5])
+    assert torch.equal(yf, torch.flip(yn, [-1]))
+    with pytest.raises(NotImplementedError):
+        from values_amd.hrnet import HighResolutionNet
+        cfg = small_cfg()
+        cfg["MODEL"]["EXTRA"] = dict(cfg["MODEL"]["EXTRA"], STAGE2=dict(cfg["MODEL"]["EXTRA"]["STAGE2"], NUM_CHANNELS=[18, 36]))
+        HighResolutionNet(cfg)

@@ -1,0 +1,443 @@
+"""HRNetV2 segmentation network on MI355X: the reference's class surface, HIP kernels underneath.
+
+Mirrors `uncertainty_modeling.models.hrnet_module.HighResolutionNet` / `get_seg_model` (hrnet_module.py:340-745): the
+same config object (MODEL.EXTRA stages, DROPOUT_FINAL, FINAL_CONV_KERNEL, DATASET.NUM_CLASSES), the same module tree
+and therefore the same state-dict key names (`conv1.weight`, `layer1.0.downsample.1.bias`,
+`stage3.2.fuse_layers.1.0.0.0.weight`, `last_layer.3.bias`, ...), so the reference's checkpoints load unchanged.
+The torch.nn layers are PARAMETER CONTAINERS; `forward` walks the tree and launches libvalues_amd.so kernels:
+vx_conv2d (+ batch statistics) -> vx_bn_finalize -> vx_affine_gather (BN affine, ReLU, residual add, bilinear
+fusion, dropout, concat) -> vx_bilinear_nchw.  ATen is never used for arithmetic.
+
+Semantics kept from the reference: BatchNorm always normalises with the statistics of the CURRENT batch
+(the reference never calls .eval()); the running-statistics side effect is not reproduced (it cannot influence
+outputs).  DROPOUT_FINAL is F.dropout(0.5, training=True) on the four stage-4 outputs, so only the head differs
+between MC samples: `forward_samples` runs the backbone once and the head T times (exact).
+
+HIP path limits: every branch width and the stem/bottleneck widths must be multiples of 16 (true for the shipped W48
+config: 48/96/192/384, 64/256, 720); SSN heads are not built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if hasattr(cfg, key) else (cfg[key] if key in cfg else default)
+
+
+class _Block(nn.Module):
+    """BasicBlock (expansion 1) / Bottleneck (expansion 4) parameter container (hrnet_module.py:44-119)."""
+
+    def __init__(self, kind, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        if kind == "BASIC":
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+
+def _expansion(kind):
+    return 1 if kind == "BASIC" else 4
+
+
+def _make_layer(kind, inplanes, planes, blocks, stride=1):
+    ds = None
+    if stride != 1 or inplanes != planes * _expansion(kind):
+        ds = nn.Sequential(nn.Conv2d(inplanes, planes * _expansion(kind), 1, stride, bias=False),
+                           nn.BatchNorm2d(planes * _expansion(kind)))
+    layers = [_Block(kind, inplanes, planes, stride, ds)]
+    for _ in range(1, blocks):
+        layers.append(_Block(kind, planes * _expansion(kind), planes))
+    return nn.Sequential(*layers)
+
+
+class _HRModule(nn.Module):
+    """HighResolutionModule container: branches + fuse_layers (hrnet_module.py:122-306)."""
+
+    def __init__(self, num_branches, kind, num_blocks, num_inchannels, num_channels, multi_scale_output=True):
+        super().__init__()
+        self.num_branches = num_branches
+        self.kind = kind
+        branches = []
+        num_inchannels = list(num_inchannels)
+        for i in range(num_branches):
+            branches.append(_make_layer(kind, num_inchannels[i], num_channels[i], num_blocks[i]))
+            num_inchannels[i] = num_channels[i] * _expansion(kind)
+        self.branches = nn.ModuleList(branches)
+        self.num_inchannels = num_inchannels
+        self.fuse_layers = None
+        if num_branches > 1:
+            fuse = []
+            for i in range(num_branches if multi_scale_output else 1):
+                row = []
+                for j in range(num_branches):
+                    if j > i:
+                        row.append(nn.Sequential(nn.Conv2d(num_inchannels[j], num_inchannels[i], 1, 1, 0, bias=False),
+                                                 nn.BatchNorm2d(num_inchannels[i])))
+                    elif j == i:
+                        row.append(None)
+                    else:
+                        chain = []
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            cout = num_inchannels[i] if last else num_inchannels[j]
+                            mods = [nn.Conv2d(num_inchannels[j], cout, 3, 2, 1, bias=False), nn.BatchNorm2d(cout)]
+                            if not last:
+                                mods.append(nn.ReLU(inplace=True))
+                            chain.append(nn.Sequential(*mods))
+                        row.append(nn.Sequential(*chain))
+                fuse.append(nn.ModuleList(row))
+            self.fuse_layers = nn.ModuleList(fuse)
+
+
+class _Act:
+    """A channels-last activation: tensor [N, H, W, pitch] whose channels [0, C) are valid."""
+    __slots__ = ("t", "C")
+
+    def __init__(self, t, c):
+        self.t, self.C = t, c
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    @property
+    def pitch(self):
+        return self.t.shape[3]
+
+
+class HighResolutionNet(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        model_cfg = _cfg_get(config, "MODEL")
+        extra = _cfg_get(model_cfg, "EXTRA")
+        if _cfg_get(model_cfg, "ALIGN_CORNERS", False):
+            raise NotImplementedError("values_amd.HighResolutionNet: ALIGN_CORNERS must be False (every shipped config)")
+        if _cfg_get(model_cfg, "SSN", False):
+            raise NotImplementedError("values_amd.HighResolutionNet: SSN head has no HIP path yet")
+        self.ssn = False
+        self.num_classes = int(_cfg_get(_cfg_get(config, "DATASET"), "NUM_CLASSES"))
+        self.in_channels = int(_cfg_get(model_cfg, "INPUT_CHANNELS", 3))
+        self.extra = {k: (dict(v) if hasattr(v, "keys") else v) for k, v in dict(extra).items()}
+        self.conv1 = nn.Conv2d(self.in_channels, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64)
+        s1 = self.extra["STAGE1"]
+        self.layer1 = _make_layer(s1["BLOCK"], 64, s1["NUM_CHANNELS"][0], s1["NUM_BLOCKS"][0])
+        pre = [_expansion(s1["BLOCK"]) * s1["NUM_CHANNELS"][0]]
+        for si in (2, 3, 4):
+            cfg = self.extra[f"STAGE{si}"]
+            chans = [c * _expansion(cfg["BLOCK"]) for c in cfg["NUM_CHANNELS"]]
+            setattr(self, f"transition{si - 1}", self._make_transition(pre, chans))
+            mods, inch = [], chans
+            for _ in range(cfg["NUM_MODULES"]):
+                m = _HRModule(cfg["NUM_BRANCHES"], cfg["BLOCK"], cfg["NUM_BLOCKS"], inch, cfg["NUM_CHANNELS"], True)
+                mods.append(m)
+                inch = m.num_inchannels
+            setattr(self, f"stage{si}", nn.Sequential(*mods))
+            pre = inch
+        self.dropout_final = bool(self.extra.get("DROPOUT_FINAL", False))
+        last = int(sum(pre))
+        k = int(self.extra.get("FINAL_CONV_KERNEL", 1))
+        if k != 1:
+            raise NotImplementedError("values_amd.HighResolutionNet: FINAL_CONV_KERNEL must be 1 (every shipped config)")
+        self.last_layer = nn.Sequential(nn.Conv2d(last, last, 1), nn.BatchNorm2d(last), nn.ReLU(inplace=True),
+                                        nn.Conv2d(last, self.num_classes, 1))
+        for w in [64, last] + [c for si in (1, 2, 3, 4) for c in self.extra[f"STAGE{si}"]["NUM_CHANNELS"]]:
+            if w % 16:
+                raise NotImplementedError(f"values_amd.HighResolutionNet: width {w} is not a multiple of 16 (HIP path limit)")
+        self._packed, self._packed_key = None, None
+        self.seed, self._calls = 123, 0
+
+    @staticmethod
+    def _make_transition(pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(nn.Sequential(nn.Conv2d(pre[i], cur[i], 3, 1, 1, bias=False), nn.BatchNorm2d(cur[i]),
+                                                nn.ReLU(inplace=True)))
+                else:
+                    layers.append(None)
+            else:
+                chain = []
+                for j in range(i + 1 - len(pre)):
+                    cout = cur[i] if j == i - len(pre) else pre[-1]
+                    chain.append(nn.Sequential(nn.Conv2d(pre[-1], cout, 3, 2, 1, bias=False), nn.BatchNorm2d(cout),
+                                               nn.ReLU(inplace=True)))
+                layers.append(nn.Sequential(*chain))
+        return nn.ModuleList(layers)
+
+    # ------------------------------------------------------------------ weights
+    def _ensure_packed(self, dev):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = _lib.load()
+        st = _lib.stream_ptr()
+        packed = {}
+        for name, mod in self.named_modules():
+            if isinstance(mod, nn.Conv2d):
+                w = mod.weight.detach().to(dev, torch.float32).contiguous()
+                cout, cin, ks, _ = w.shape
+                wp = torch.empty(lib.vx_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=dev)
+                _lib.check(lib.vx_pack_conv2d(_lib.ptr(w), _lib.ptr(wp), cin, cout, ks, st), "vx_pack_conv2d")
+                b = None
+                if mod.bias is not None:
+                    b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=dev)  # readable per 16-row tile
+                    b[:cout] = mod.bias.detach().to(dev, torch.float32)
+                packed[name] = (wp, b, cin, cout, ks, mod.stride[0], w)
+            elif isinstance(mod, nn.BatchNorm2d):
+                packed[name] = (mod.weight.detach().to(dev, torch.float32).contiguous(),
+                                mod.bias.detach().to(dev, torch.float32).contiguous())
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    # ------------------------------------------------------------------ kernel wrappers
+    def _conv(self, x: _Act, name, stats=True):
+        lib = _lib.load()
+        wp, b, cin, cout, ks, stride, _w = self._pk[name]
+        cin_pad = (cin + 15) // 16 * 16
+        assert x.C == cin_pad or x.C == cin, (name, x.C, cin)
+        n, h, w = x.N, x.H, x.W
+        oh = (h + 2 * (ks // 2) - ks) // stride + 1
+        ow = (w + 2 * (ks // 2) - ks) // stride + 1
+        pitch = (cout + 3) // 4 * 4
+        out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
+        part = None
+        a = _lib.Conv2dArgs()
+        a.in_ = x.t.data_ptr(); a.in_pitch = x.pitch; a.w_packed = wp.data_ptr()
+        a.bias = b.data_ptr() if b is not None else None
+        a.out = out.data_ptr(); a.out_pitch = pitch; a.out_coff = 0
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KS, a.S = n, h, w, cin_pad, cout, ks, stride
+        ntiles = n * lib.vx_conv2d_tiles(h, w, ks, stride)
+        if stats:
+            part = torch.empty((ntiles, cout, 2), dtype=torch.float32, device=x.t.device)
+            a.stats_partial = part.data_ptr()
+        _lib.check(lib.vx_conv2d(C.byref(a), self._st), "vx_conv2d " + name)
+        self._hold += [out, part]
+        return _Act(out, cout), part, ntiles
+
+    def _conv_bn(self, x: _Act, conv_name, bn_name):
+        lib = _lib.load()
+        raw, part, ntiles = self._conv(x, conv_name)
+        gamma, beta = self._pk[bn_name]
+        scale = torch.empty(raw.C, dtype=torch.float32, device=raw.t.device)
+        shift = torch.empty(raw.C, dtype=torch.float32, device=raw.t.device)
+        _lib.check(lib.vx_bn_finalize(_lib.ptr(part), ntiles, raw.C, raw.N * raw.H * raw.W, 1e-5, _lib.ptr(gamma),
+                                      _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), self._st), "vx_bn_finalize " + bn_name)
+        self._hold += [scale, shift]
+        return raw, scale, shift
+
+    def _aff(self, x: _Act, scale=None, shift=None, relu=False, add: Optional[_Act] = None, out: Optional[_Act] = None,
+               out_coff=0, size=None, drop=None):
+        lib = _lib.load()
+        oh, ow = size if size is not None else (x.H, x.W)
+        if out is None:
+            out = _Act(torch.empty((x.N, oh, ow, x.C), dtype=torch.float32, device=x.t.device), x.C)
+        a = _lib.AffineArgs()
+        a.x = x.t.data_ptr(); a.x_pitch = x.pitch
+        if scale is not None:
+            a.scale = scale.data_ptr(); a.shift = shift.data_ptr()
+        if add is not None:
+            a.add = add.t.data_ptr(); a.add_pitch = add.pitch
+        a.out = out.t.data_ptr(); a.out_pitch = out.pitch; a.out_coff = out_coff
+        a.N, a.H, a.W, a.C, a.OH, a.OW = x.N, x.H, x.W, x.C, oh, ow
+        a.act = _lib.VX_ACT_RELU if relu else _lib.VX_ACT_NONE
+        if drop is not None:
+            mode, seed, layer, mask = drop
+            a.drop_mode, a.drop_seed, a.drop_layer = mode, seed & 0xFFFFFFFF, layer
+            if mask is not None:
+                a.drop_mask = mask.data_ptr()
+        _lib.check(lib.vx_affine_gather(C.byref(a), self._st), "vx_affine_gather")
+        self._hold.append(out.t)
+        return out
+
+    # ------------------------------------------------------------------ network walk
+    def _block(self, x: _Act, p: str, blk: _Block) -> _Act:
+        if blk.kind == "BASIC":
+            r1 = self._conv_bn(x, p + ".conv1", p + ".bn1")
+            a1 = self._aff(r1[0], r1[1], r1[2], relu=True)
+            r2 = self._conv_bn(a1, p + ".conv2", p + ".bn2")
+        else:
+            r1 = self._conv_bn(x, p + ".conv1", p + ".bn1")
+            a1 = self._aff(r1[0], r1[1], r1[2], relu=True)
+            rm = self._conv_bn(a1, p + ".conv2", p + ".bn2")
+            a2 = self._aff(rm[0], rm[1], rm[2], relu=True)
+            r2 = self._conv_bn(a2, p + ".conv3", p + ".bn3")
+        res = x
+        if blk.downsample is not None:
+            rd = self._conv_bn(x, p + ".downsample.0", p + ".downsample.1")
+            res = self._aff(rd[0], rd[1], rd[2], relu=False)
+        return self._aff(r2[0], r2[1], r2[2], relu=True, add=res)  # out = relu(bn(conv) + residual), :72-75 / :114-117
+
+    def _module(self, xs: List[_Act], p: str, mod: _HRModule) -> List[_Act]:
+        xs = list(xs)
+        for i in range(mod.num_branches):
+            for b, blk in enumerate(mod.branches[i]):
+                xs[i] = self._block(xs[i], f"{p}.branches.{i}.{b}", blk)
+        if mod.num_branches == 1:
+            return xs
+        outs = []
+        nb = mod.num_branches
+        for i in range(len(mod.fuse_layers)):
+            y: Optional[_Act] = None
+            for j in range(nb):
+                last = j == nb - 1
+                if j == i:
+                    if y is None:
+                        y = xs[j]  # i == 0: the sum starts from x[0] itself (never written: later terms go to a new buffer)
+                        if last:
+                            y = self._aff(xs[j], relu=True)
+                        continue
+                    term = (xs[j], None, None, None)
+                elif j > i:
+                    q = f"{p}.fuse_layers.{i}.{j}"
+                    r = self._conv_bn(xs[j], q + ".0", q + ".1")
+                    term = (r[0], r[1], r[2], (xs[i].H, xs[i].W))
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        q = f"{p}.fuse_layers.{i}.{j}.{k}"
+                        r = self._conv_bn(t, q + ".0", q + ".1")
+                        if k != i - j - 1:
+                            t = self._aff(r[0], r[1], r[2], relu=True)
+                    term = (r[0], r[1], r[2], None)
+                if y is None:
+                    y = self._aff(term[0], term[1], term[2], relu=last, size=term[3])
+                else:
+                    fresh = y is xs[0] and i == 0
+                    y = self._aff(term[0], term[1], term[2], relu=last, add=y, out=None if fresh else y, size=term[3])
+            outs.append(y)
+        return outs
+
+    def _transition(self, ys: List[_Act], tname: str, layers) -> List[_Act]:
+        n_prev = len(ys)
+        out = []
+        for i, tl in enumerate(layers):
+            if i < n_prev:
+                if tl is None:
+                    out.append(ys[i])
+                else:
+                    r = self._conv_bn(ys[i], f"{tname}.{i}.0", f"{tname}.{i}.1")
+                    out.append(self._aff(r[0], r[1], r[2], relu=True))
+            else:
+                t = ys[-1]
+                for j in range(len(tl)):
+                    r = self._conv_bn(t, f"{tname}.{i}.{j}.0", f"{tname}.{i}.{j}.1")
+                    t = self._aff(r[0], r[1], r[2], relu=True)
+                out.append(t)
+        return out
+
+    def _backbone(self, x: torch.Tensor) -> List[_Act]:
+        n, cin, h, w = x.shape
+        if cin != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
+        xin = torch.zeros((n, h, w, 16), dtype=torch.float32, device=x.device)   # pad image channels to one 16-block
+        xin[..., :cin] = x.permute(0, 2, 3, 1)
+        self._hold.append(xin)
+        a = _Act(xin, 16)
+        r = self._conv_bn(a, "conv1", "bn1")
+        a = self._aff(r[0], r[1], r[2], relu=True)
+        r = self._conv_bn(a, "conv2", "bn2")
+        a = self._aff(r[0], r[1], r[2], relu=True)
+        for b, blk in enumerate(self.layer1):
+            a = self._block(a, f"layer1.{b}", blk)
+        ys = [a]
+        for si in (2, 3, 4):
+            xs = self._transition(ys, f"transition{si - 1}", getattr(self, f"transition{si - 1}"))
+            for m, mod in enumerate(getattr(self, f"stage{si}")):
+                xs = self._module(xs, f"stage{si}.{m}", mod)
+            ys = xs
+        return ys
+
+    def _head(self, feats: List[_Act], out: torch.Tensor, size, dst, flip, drop_mode, seed, masks):
+        lib = _lib.load()
+        n, h0, w0 = feats[0].N, feats[0].H, feats[0].W
+        ctot = sum(f.C for f in feats)
+        cat = _Act(torch.empty((n, h0, w0, ctot), dtype=torch.float32, device=out.device), ctot)
+        off = 0
+        for k, f in enumerate(feats):
+            drop = None
+            if drop_mode != _lib.VX_DROP_NONE:
+                drop = (drop_mode, seed, k, None if masks is None else masks[k])
+            self._aff(f, out=cat, out_coff=off, size=(h0, w0), drop=drop)   # dropout -> bilinear -> concat slot
+            off += f.C
+        r = self._conv_bn(cat, "last_layer.0", "last_layer.1")
+        y = self._aff(r[0], r[1], r[2], relu=True)
+        raw, _, _ = self._conv(y, "last_layer.3", stats=False)
+        _lib.check(lib.vx_bilinear_nchw(_lib.ptr(raw.t), raw.pitch, n, h0, w0, self.num_classes, size[0], size[1],
+                                        _lib.ptr(out), _lib.ptr(dst), _lib.ptr(flip), self._st), "vx_bilinear_nchw")
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def forward_samples(self, x: torch.Tensor, n_samples: int = 1, dropout_masks: Optional[Sequence] = None,
+                        seeds: Optional[Sequence[int]] = None, hflip_back: bool = False) -> torch.Tensor:
+        """(n_samples, B, C, H, W) logits: backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
+        [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
+        (a HorizontalFlip TTA view, test_2D.py:304-309)."""
+        _lib.require_gpu()
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        x = x.detach().to(dev, torch.float32)
+        self._pk = self._ensure_packed(dev)
+        self._st = _lib.stream_ptr()
+        self._hold = []
+        n, _, h, w = x.shape
+        feats = self._backbone(x)
+        out = torch.empty((n_samples * n, self.num_classes, h, w), dtype=torch.float32, device=dev)
+        flip = torch.full((n,), 1, dtype=torch.int32, device=dev) if hflip_back else None
+        for t in range(n_samples):
+            mode = _lib.VX_DROP_NONE
+            masks = None
+            seed = 0
+            if self.dropout_final and dropout_masks is not None:
+                mode = _lib.VX_DROP_MASK
+                masks = [m.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.uint8) for m in dropout_masks[t]]
+                self._hold += masks
+            elif self.dropout_final:  # F.dropout(..., training=True): live even in eval mode (hrnet_module.py:642-646)
+                mode = _lib.VX_DROP_HASH
+                if seeds is not None:
+                    seed = int(seeds[t])
+                else:
+                    seed = self.seed * 1000003 + self._calls
+                    self._calls += 1
+            dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
+            self._hold.append(dst)
+            self._head(feats, out, (h, w), dst, flip, mode, seed, masks)
+        self._hold_last = self._hold  # keep everything alive until the stream has consumed it
+        return out.view(n_samples, n, self.num_classes, h, w)
+
+    def forward(self, x: torch.Tensor, mean_only: bool = False) -> torch.Tensor:
+        return self.forward_samples(x, 1)[0]
+
+
+def get_seg_model(cfg, **kwargs):
+    """hrnet_module.py:740-745 (PRETRAINED weights are loaded by the caller through load_state_dict)."""
+    return HighResolutionNet(cfg)

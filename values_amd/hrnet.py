@@ -280,6 +280,11 @@ class HighResolutionNet(nn.Module):
         self._hold.append(out.t)
         return out
 
+    def _streams(self, n):
+        if not hasattr(self, "_side") or len(self._side) < n:
+            self._side = [torch.cuda.Stream() for _ in range(n)]
+        return self._side
+
     # ------------------------------------------------------------------ network walk
     def _block(self, x: _Act, p: str, blk: _Block) -> _Act:
         if blk.kind == "BASIC":
@@ -300,9 +305,24 @@ class HighResolutionNet(nn.Module):
 
     def _module(self, xs: List[_Act], p: str, mod: _HRModule) -> List[_Act]:
         xs = list(xs)
+        # the branches of a module are independent until the fusion: run them on separate HIP streams so the
+        # low-resolution branches (a few dozen workgroups per launch) fill the chip together with the wide ones
+        import os
+        main = torch.cuda.current_stream()
+        multi = mod.num_branches > 1 and not os.environ.get("VX_HRNET_SINGLE_STREAM")
+        side = self._streams(mod.num_branches) if multi else [main] * mod.num_branches
         for i in range(mod.num_branches):
-            for b, blk in enumerate(mod.branches[i]):
-                xs[i] = self._block(xs[i], f"{p}.branches.{i}.{b}", blk)
+            st = side[i]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._st = C.c_void_p(st.cuda_stream)
+                for b, blk in enumerate(mod.branches[i]):
+                    xs[i] = self._block(xs[i], f"{p}.branches.{i}.{b}", blk)
+        self._st = C.c_void_p(main.cuda_stream)
+        for i in range(mod.num_branches):
+            if side[i] is not main:
+                main.wait_stream(side[i])
         if mod.num_branches == 1:
             return xs
         outs = []
@@ -436,6 +456,27 @@ class HighResolutionNet(nn.Module):
 
     def forward(self, x: torch.Tensor, mean_only: bool = False) -> torch.Tensor:
         return self.forward_samples(x, 1)[0]
+
+    def graphed(self, example: torch.Tensor, n_samples: int = 1, seeds: Optional[Sequence[int]] = None):
+        """Capture forward_samples for a fixed input shape into one hipGraph (the eager walk is ~1200 launches and
+        host-bound below ~20 ms).  Returns f(x) -> logits view of a static output buffer; dropout seeds are baked in."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        static_x = example.detach().to(dev, torch.float32).clone()
+        seeds = list(seeds) if seeds is not None else list(range(n_samples))
+        self.forward_samples(static_x, n_samples, seeds=seeds)  # warm-up: packs weights, creates side streams
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_y = self.forward_samples(static_x, n_samples, seeds=seeds)
+        keep = self._hold_last
+
+        def run(x):
+            static_x.copy_(x)
+            g.replay()
+            return static_y
+
+        run._keep = (g, keep, static_x, static_y)
+        return run
 
 
 def get_seg_model(cfg, **kwargs):

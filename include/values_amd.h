@@ -77,6 +77,9 @@ int vx_unc_stats_finalize(const float* stats, int B, int T_total, int C, int64_t
                           float* pred_entropy, float* exp_entropy, float* mutual_info, uint8_t* argmax,
                           vx_stream_t stream);
 
+/* F.softmax(dim=1) of planar logits [R][C][nvox] (test_2D.py:302, 315), for class counts above the fused path's 8. */
+int vx_softmax_planar(const float* logits, int64_t R, int C, int64_t nvox, float* out, vx_stream_t stream);
+
 /* calculate_one_minus_msr (test_3D.py:521-525) / ExperimentDataloader.get_max_softmax_pred
  * (evaluation/experiment_dataloader.py:38-49): out[v] = 1 - max_c x[c][v]; x [C][nvox]. */
 int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, void* out, vx_stream_t stream);

@@ -113,3 +113,46 @@ def test_hrnet_hash_dropout_and_properties():
         cfg = small_cfg()
         cfg["MODEL"]["EXTRA"] = dict(cfg["MODEL"]["EXTRA"], STAGE2=dict(cfg["MODEL"]["EXTRA"]["STAGE2"], NUM_CHANNELS=[18, 36]))
         HighResolutionNet(cfg)
+
+
+def test_predict_2d_driver_mc_and_tta_vs_oracle():
+    """Tester.predict_cases ordering (test_2D.py:283-317) + process_output maps, against the float64 oracle."""
+    from oracle import uncertainty_oracle as uo
+    from oracle.hrnet_oracle import hrnet_forward
+    from values_amd.predict2d import predict_logits_2d, process_output_2d
+    m, g, sd = make(dropout_final=True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = torch.from_numpy(g["input"])
+    T = 3
+    masks = [masks_of(g, t) for t in range(T)]
+    lg = predict_logits_2d([m], x.cuda(), n_pred=T, dropout_masks=[masks])
+    assert lg.shape == (2, T, 4, 64, 96)
+    np.testing.assert_allclose(lg.permute(1, 0, 2, 3, 4).cpu().numpy(), g["logits"], atol=2e-3)
+    out = process_output_2d(lg)
+    for b in range(2):
+        for k in KEYS:
+            assert np.abs(out[k][b].cpu().numpy() - g[f"{k}_{b}"]).max() < 1e-3
+    sm_ref = torch.softmax(torch.from_numpy(g["logits"]), 2).permute(1, 0, 2, 3, 4).numpy()
+    assert np.abs(out["softmax_pred"].cpu().numpy() - sm_ref).max() < 1e-3
+    # TTA: 4 views (identity, hflip, noisy, hflip+noisy): flip views are un-flipped; dropout off in this model
+    m2, _, _ = make(dropout_final=False)
+    noise = torch.from_numpy(formula_tensor((2, 3, 64, 96), tag=82, scale=0.1)).float()
+    views = [x, torch.flip(x, [-1]), x + noise, torch.flip(x + noise, [-1])]
+    flags = [False, True, False, True]
+    lg = predict_logits_2d([m2], [v.cuda() for v in views], tta=True, hflip_views=flags)
+    extra = dict(HRNET_SMALL_EXTRA, DROPOUT_FINAL=False)
+    with torch.no_grad():
+        for vi, (v, fl) in enumerate(zip(views, flags)):
+            y = hrnet_forward(extra, sd64, v.double())
+            if fl:
+                y = torch.flip(y, [-1])
+            assert np.abs(lg[:, vi].cpu().numpy() - y.numpy()).max() < 1e-3, vi
+    out = process_output_2d(lg)
+    ref = uo.calculate_uncertainty(uo.softmax(lg[0].double().cpu().numpy(), axis=1))
+    for k in KEYS:
+        assert np.abs(out[k][0].cpu().numpy() - ref[k]).max() < 1e-5
+    # single prediction -> 1 - max softmax
+    one = process_output_2d(lg[:, :1].contiguous())
+    p = torch.softmax(lg[:, 0].double(), 1)
+    assert (one["pred_entropy"].double() - (1 - p.max(1)[0])).abs().max().item() < 1e-6
+    assert "epistemic_uncertainty" not in one

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vx_unc_reduce": (_i, [_p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "vx_unc_stats_accumulate": (_i, [_p, _i, _i, _i, _i64, _p, _p]),
     "vx_unc_stats_finalize": (_i, [_p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p]),
+    "vx_softmax_planar": (_i, [_p, _i64, _i, _i64, _p, _p]),
     "vx_one_minus_msr": (_i, [_p, _i, _i, _i64, _p, _p]),
     "vx_conv3d_k3_packed_floats": (_i64, [_i, _i]),
     "vx_pack_conv3d_k3": (_i, [_p, _p, _i, _i, _p]),

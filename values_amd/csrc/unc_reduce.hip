@@ -350,6 +350,35 @@ extern "C" int vx_unc_stats_finalize(const float* stats, int B, int T_total, int
   return VX_OK;
 }
 
+// class softmax of planar logits [R][C][nvox] (F.softmax(dim=1), test_2D.py:302,315) for class counts beyond the
+// register-resident fused path (C > 8: the 2D data sets have 19-24 classes)
+__global__ __launch_bounds__(256) void softmax_planar_kernel(const float* __restrict__ x, int C, int64_t nvox, int64_t total,
+                                                             float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nvox, v = i - r * nvox;
+    const float* p = x + (size_t)r * C * nvox + v;
+    float* o = out + (size_t)r * C * nvox + v;
+    float m = p[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, p[(size_t)c * nvox]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(p[(size_t)c * nvox] - m);
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; ++c) o[(size_t)c * nvox] = expf(p[(size_t)c * nvox] - m) * inv;
+  }
+}
+
+extern "C" int vx_softmax_planar(const float* logits, int64_t R, int C, int64_t nvox, float* out, vx_stream_t stream) {
+  if (R < 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_softmax_planar: bad shape");
+  if (R == 0 || nvox == 0) return VX_OK;
+  if (!logits || !out) VX_FAIL(VX_E_NULL, "vx_softmax_planar: null pointer");
+  const int64_t total = R * nvox;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(softmax_planar_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, logits, C, nvox, total, out);
+  VX_CHECK_LAUNCH("vx_softmax_planar");
+  return VX_OK;
+}
+
 // per-sample argmax over classes for the probability path (data_carrier_3D.py:281-283)
 template <typename TIn>
 __global__ __launch_bounds__(256) void sample_argmax_kernel(const TIn* __restrict__ x, int C, int64_t nvox, int64_t nbt,

@@ -419,7 +419,8 @@ class HighResolutionNet(nn.Module):
     # ------------------------------------------------------------------ public
     @torch.no_grad()
     def forward_samples(self, x: torch.Tensor, n_samples: int = 1, dropout_masks: Optional[Sequence] = None,
-                        seeds: Optional[Sequence[int]] = None, hflip_back: bool = False) -> torch.Tensor:
+                        seeds: Optional[Sequence[int]] = None, hflip_back: bool = False,
+                        out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0) -> torch.Tensor:
         """(n_samples, B, C, H, W) logits: backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
         [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
         (a HorizontalFlip TTA view, test_2D.py:304-309)."""
@@ -431,7 +432,9 @@ class HighResolutionNet(nn.Module):
         self._hold = []
         n, _, h, w = x.shape
         feats = self._backbone(x)
-        out = torch.empty((n_samples * n, self.num_classes, h, w), dtype=torch.float32, device=dev)
+        user_out = out is not None
+        if out is None:
+            out = torch.empty((n_samples * n, self.num_classes, h, w), dtype=torch.float32, device=dev)
         flip = torch.full((n,), 1, dtype=torch.int32, device=dev) if hflip_back else None
         for t in range(n_samples):
             mode = _lib.VX_DROP_NONE
@@ -448,10 +451,15 @@ class HighResolutionNet(nn.Module):
                 else:
                     seed = self.seed * 1000003 + self._calls
                     self._calls += 1
-            dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
+            if user_out:  # image b, sample t -> slot b * slot_stride + slot_offset + t  (per-image (Npred, C, H, W) stacks)
+                dst = torch.arange(n, dtype=torch.int32, device=dev) * slot_stride + (slot_offset + t)
+            else:
+                dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
             self._hold.append(dst)
             self._head(feats, out, (h, w), dst, flip, mode, seed, masks)
         self._hold_last = self._hold  # keep everything alive until the stream has consumed it
+        if user_out:
+            return out
         return out.view(n_samples, n, self.num_classes, h, w)
 
     def forward(self, x: torch.Tensor, mean_only: bool = False) -> torch.Tensor:

@@ -1,0 +1,68 @@
+"""2D multi-pass inference: Tester.predict_cases + process_output (uncertainty_modeling/test_2D.py:205-319) on the device.
+
+pred order (test_2D.py:283-317): for model in models: [TTA: one forward per view, HorizontalFlip views un-flipped] or
+[n_pred forwards]; SSN is not built.  Every forward is its own batch, so training-mode BatchNorm sees the same batch
+statistics as in the reference; for DROPOUT_FINAL models the n_pred forwards share the backbone (exact).
+Logits land directly in per-image stacks (B, Npred, C, H, W); the per-image reduction is calculate_uncertainty
+(Npred > 1) or calculate_one_minus_msr (Npred == 1), test_2D.py:245-248.  The reference appends an all-zero class
+channel first (:208-218) -- it contributes exactly 0 to every map through the NaN-skip, so it is not materialised.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .uncertainty import uncertainty_maps
+
+
+@torch.no_grad()
+def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False, hflip_views: Optional[Sequence[bool]] = None,
+                      dropout_masks=None, seeds=None) -> torch.Tensor:
+    """data: (B,3,H,W) tensor, or with tta a list of view tensors (the dataset's 4 views, cityscapes_dataset.py:76-99)
+    and hflip_views[i] = "HorizontalFlip" in transforms of view i.  Returns logits (B, Npred_total, C, H, W)."""
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    views = list(data) if tta else [data]
+    B, _, H, W = views[0].shape
+    per_model = len(views) if tta else n_pred
+    total = per_model * len(models)
+    C = models[0].num_classes
+    out = torch.empty((B * total, C, H, W), dtype=torch.float32, device=dev)
+    for mi, model in enumerate(models):
+        base = mi * per_model
+        if tta:
+            for vi, view in enumerate(views):
+                model.forward_samples(view, 1, hflip_back=bool(hflip_views[vi]) if hflip_views else False,
+                                      seeds=None if seeds is None else [seeds[mi] * 131 + vi],
+                                      out=out, slot_stride=total, slot_offset=base + vi)
+        else:
+            model.forward_samples(views[0], n_pred, dropout_masks=None if dropout_masks is None else dropout_masks[mi],
+                                  seeds=None if seeds is None else [seeds[mi] * 131 + t for t in range(n_pred)],
+                                  out=out, slot_stride=total, slot_offset=base)
+    return out.view(B, total, C, H, W)
+
+
+@torch.no_grad()
+def process_output_2d(logits: torch.Tensor, ssn: bool = False) -> Dict[str, torch.Tensor]:
+    """logits (B, Npred, C, H, W) -> per-image maps like process_output: softmax_pred (B, Npred, C, H, W),
+    mean_softmax (B, C, H, W), pred_seg (B, H, W) u8 argmax of the mean (save_prediction, test_2D.py:116-149) and
+    pred_entropy [/ aleatoric_uncertainty / epistemic_uncertainty] (B, H, W)."""
+    lib = _lib.load()
+    B, T, Cc, H, W = logits.shape
+    probs = torch.empty_like(logits)
+    _lib.check(lib.vx_softmax_planar(_lib.ptr(logits), B * T, Cc, H * W, _lib.ptr(probs), _lib.stream_ptr()), "vx_softmax_planar")
+    m = uncertainty_maps(probs, from_logits=False)
+    out = {"softmax_pred": probs, "mean_softmax": m["mean_softmax"], "pred_seg": m["argmax"]}
+    if T > 1:
+        out["pred_entropy"] = m["pred_entropy"]
+        a, e = ("aleatoric_uncertainty", "epistemic_uncertainty") if not ssn else ("epistemic_uncertainty", "aleatoric_uncertainty")
+        out[a], out[e] = m["expected_entropy"], m["mutual_information"]
+    else:  # calculate_one_minus_msr: 1 - max softmax under the key "pred_entropy" (test_3D.py:521-525)
+        msr = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
+        for b in range(B):
+            _lib.check(lib.vx_one_minus_msr(_lib.ptr(probs[b, 0]), _lib.VX_F32, Cc, H * W, _lib.ptr(msr[b]), _lib.stream_ptr()),
+                       "vx_one_minus_msr")
+        out["pred_entropy"] = msr
+    return out

@@ -49,8 +49,15 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
             lists = ([torch.empty_like(f) for _ in range(world)], [torch.empty_like(seg) for _ in range(world)])
             _bufs.clear()
             _bufs[key] = lists
-    dist.gather(f, lists[0] if lists else None, dst=dst)
-    dist.gather(seg, lists[1] if lists else None, dst=dst)
+    try:
+        dist.gather(f, lists[0] if lists else None, dst=dst)
+        dist.gather(seg, lists[1] if lists else None, dst=dst)
+    except RuntimeError:
+        # a backend without gather: all_gather is universally available (every rank then holds the maps)
+        if lists is None:
+            lists = ([torch.empty_like(f) for _ in range(world)], [torch.empty_like(seg) for _ in range(world)])
+        dist.all_gather(lists[0], f)
+        dist.all_gather(lists[1], seg)
     if rank != dst:
         return None
     return unpack_maps(torch.cat(lists[0], 0), torch.cat(lists[1], 0))

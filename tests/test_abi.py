@@ -107,3 +107,22 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_load_patch_and_tta_views(tmp_path):
+    import numpy as np
+    from values_amd.data import hflip_flags, load_patch, tta_views_2d
+    vol = np.arange(6 * 5 * 4, dtype=np.float32).reshape(6, 5, 4)
+    np.save(tmp_path / "v.npy", vol)
+    np.save(tmp_path / "v_00.npy", (vol > 50).astype(np.uint8))
+    s = {"image_path": str(tmp_path / "v.npy"), "label_paths": [str(tmp_path / "v_00.npy")], "crop_idx": ((1, 5), (0, 4), (2, 4))}
+    d = load_patch(s)
+    assert d["data"].shape == (1, 4, 4, 2) and d["seg"].shape == (1, 1, 4, 4, 2) and d["seg"].dtype == np.intc
+    np.testing.assert_array_equal(d["data"][0], vol[1:5, 0:4, 2:4])
+    assert d["org_image_size"] == [(6, 5, 4)]
+    img = (np.arange(4 * 6 * 3) % 256).astype(np.uint8).reshape(4, 6, 3)
+    views, tr = tta_views_2d(img, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+    assert len(views) == 4 and views[0].shape == (3, 4, 6) and views[0].dtype == np.float32
+    np.testing.assert_array_equal(views[1], views[0][:, :, ::-1])
+    np.testing.assert_allclose(views[0][0, 0, 0], (img[0, 0, 0] / 255.0 - 0.485) / 0.229, rtol=1e-6)
+    assert hflip_flags(tr) == [False, True, False, True]

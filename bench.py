@@ -56,9 +56,9 @@ def kernel_name(kind, ci, co, edge):
         if ci == 1:
             return f"conv3d_k3_c1_kernel<{co}>"
         # template instance = <CB, NT, TX, TY, TZ, NW, XP> as conv_config()/tile_config() choose it (conv3d_mfma.hip)
-        cb = 16 if ci % 16 == 0 else 8
         nt = 2 if co % 32 == 0 else 1
         xp = 1 if co == 8 else 0
+        cb = 8 if xp else (16 if ci % 16 == 0 else 8)
         ex = edge // 2 if xp else edge  # x-pair: a column is a voxel pair
         tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
         return f"conv3d_k3_mfma_kernel<{cb},{nt},{tile},{nw},{xp}>"

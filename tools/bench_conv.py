@@ -25,7 +25,7 @@ DEFAULT = ["expand_1_1:16:8:64", "contr_1_2:8:8:64", "contr_2_1:8:16:32", "contr
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=80)
-    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=300)  # short loops run at ramping clocks and under-report ~10 %
     ap.add_argument("--act", type=int, default=1)
     ap.add_argument("--drop", type=int, default=1)
     ap.add_argument("--stats", type=int, default=0)
@@ -56,7 +56,7 @@ def main():
             st = torch.zeros((N, lib.vx_conv3d_k3_tiles(edge, edge, edge), cout, 2), dtype=torch.float32, device=dev)
             a.stats_partial = st.data_ptr()
         s = _lib.stream_ptr()
-        for _ in range(2):
+        for _ in range(max(2, args.reps // 4)):
             _lib.check(lib.vx_conv3d_k3(C.byref(a), s), "conv")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -37,6 +37,8 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s);  // conv3d_dma.hip
+
 struct ConvKArgs {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z, nchunks;
@@ -445,9 +447,11 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 struct ConvCfg { int CB, NT, XP; };
 static inline ConvCfg conv_config(int Cin, int Cout) {
   ConvCfg c;
-  c.CB = (Cin % 16 == 0) ? 16 : 8;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
   c.XP = (Cout == 8) ? 1 : 0;
+  // x-pair layers always go in chunks of 8 channels (same speed as one chunk of 16 here, and the packing the
+  // opt-in LDS-DMA schedule in conv3d_dma.hip needs: all weights + two input images in LDS)
+  c.CB = c.XP ? 8 : ((Cin % 16 == 0) ? 16 : 8);
   return c;
 }
 static inline int conv_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
@@ -565,8 +569,6 @@ static int dispatch_tile(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
 }
 template <int CB>
 static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s) {
-  static const int nw16 = getenv("VX_XP_NW16") ? 1 : 0;  // tuning knob
-  if (t.TX == 16 && CB == 16 && nw16) return launch_conv<CB, 1, 16, 4, 4, 16, 1>(ka, s);
   if (t.TX == 16) return launch_conv<CB, 1, 16, 4, 4, 8, 1>(ka, s);
   if (t.TX == 8) return launch_conv<CB, 1, 8, 8, 4, 8, 1>(ka, s);
   return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);
@@ -612,7 +614,11 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   hipStream_t s = (hipStream_t)stream;
-  if (c.XP) return c.CB == 16 ? dispatch_tile_xp<16>(ka, t, s) : dispatch_tile_xp<8>(ka, t, s);
+  {
+    const int rc = vx_conv3d_k3_try_dma(a, s);   // opt-in (VX_CONV_DMA=1) LDS-DMA schedule; 1 = not taken
+    if (rc != 1) return rc;
+  }
+  if (c.XP) return dispatch_tile_xp<8>(ka, t, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_tile<16, 1>(ka, t, s);
   if (c.CB == 16 && c.NT == 2) return dispatch_tile<16, 2>(ka, t, s);
   if (c.CB == 8 && c.NT == 1) return dispatch_tile<8, 1>(ka, t, s);

@@ -55,6 +55,10 @@ def kernel_name(kind, ci, co, edge):
     if kind == "conv":
         if ci == 1:
             return f"conv3d_k3_c1_kernel<{co}>"
+        if co == 8 and ci in (8, 16):
+            # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)
+            tile = "32,4,4" if edge >= 32 else ("16,8,4" if edge >= 16 else "8,4,4")
+            return f"conv3d_k3_c8_kernel<{ci // 8},{tile}>"
         # template instance = <CB, NT, TX, TY, TZ, NW, XP> as conv_config()/tile_config() choose it (conv3d_mfma.hip)
         nt = 2 if co % 32 == 0 else 1
         xp = 1 if co == 8 else 0
@@ -63,7 +67,7 @@ def kernel_name(kind, ci, co, edge):
         tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
         return f"conv3d_k3_mfma_kernel<{cb},{nt},{tile},{nw},{xp}>"
     if kind == "convT":
-        return "convT_k2s2_kernel"
+        return "convT_k2s2_mfma_kernel" if ci in (16, 32, 64, 128) else "convT_k2s2_kernel"
     if kind == "conv1x1":
         return f"conv1x1_ncdhw_kernel<{ci}>"
     return kind

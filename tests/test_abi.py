@@ -59,7 +59,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), s
 
 
 def test_host_only_queries(lib):
-    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 16 * 16 * 36  # Cout == 8: x-pair packing, 16 rows x (9*4 taps)
+    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 27 * 16 * 8   # Cout == 8, Cin in {8, 16}: 4x4x1 kernel, dense
+    assert lib.vx_conv3d_k3_packed_floats(24, 8) == 16 * 24 * 36  # other Cout == 8: x-pair packing, 16 rows x (9*4 taps)
     assert lib.vx_conv3d_k3_packed_floats(16, 16) == 16 * 16 * 27
     assert lib.vx_conv3d_k3_packed_floats(32, 32) == 32 * 32 * 27
     assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1

@@ -216,7 +216,8 @@ def test_conv3d_c1_matches_oracle(cout, shape, flipcode):
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(16, 8, (2, 4, 8, 16)), (128, 64, (1, 2, 2, 2)), (64, 32, (1, 4, 4, 4)),
-                                            (32, 16, (1, 3, 5, 7))])
+                                            (32, 16, (1, 3, 5, 7)), (16, 16, (1, 2, 3, 5)), (32, 24, (1, 2, 2, 3)),
+                                            (48, 8, (1, 2, 2, 2)), (64, 64, (2, 2, 3, 2))])
 def test_convT_matches_oracle(cin, cout, shape):
     lib = _lib.load()
     n, d, h, w = shape

@@ -22,15 +22,23 @@ for spec in sys.argv[1:] or ["16:8:64", "16:16:32", "8:8:64", "64:32:16"]:
     a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = 1, 1, 1, 2
-    for _ in range(2):
+    reps = int(os.environ.get("STAMP_REPS", "300"))   # long enough for steady clocks
+    for _ in range(reps // 3):
         _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+    e1.record()
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
     d = dbg.cpu().double()
     used = d[:, :, 6] > 0
     it = d[:, :, 6][used].mean().item()
     names = ["barrier1", "commit", "barrier2", "prefetch", "compute", "epilogue"]
     tot = sum(d[:, :, i][used].mean().item() for i in range(6))
-    print(f"{cin}->{cout}@{edge}: {int(used.sum())} waves, {it:.1f} items/wave, {tot/it:.0f} cycles/item (s_memtime ticks, 100 MHz?)")
+    print(f"{cin}->{cout}@{edge}: {ms:.4f} ms/launch, {int(used.sum())} waves, {it:.1f} items/wave, {tot/it:.0f} ticks/item; "
+          f"loop ticks / launch time = {tot / (ms * 1e3):.0f} ticks/us (s_memtime rate if the loop spans the launch)")
     for i, n in enumerate(names):
         v = d[:, :, i][used].mean().item()
         print(f"   {n:10s} {v/it:9.1f} per item  {100*v/tot:5.1f} %")

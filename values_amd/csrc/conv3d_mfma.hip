@@ -38,6 +38,10 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s);  // conv3d_dma.hip
+// conv3d_c8.hip: the Cout = 8, Cin in {8, 16} layers on the 4x4x1 matrix instruction
+bool vx_conv3d_c8_applies(int Cin, int Cout);
+int vx_pack_conv3d_k3_c8(const float* w_torch, float* w_packed, int Cin, hipStream_t s);
+int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_t s);
 
 struct ConvKArgs {
   vx_conv3d_args a;
@@ -444,9 +448,11 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 // weight packing: torch (Cout, Cin, 3,3,3) -> [rowgroup][chunk][tap][nt][lane 64][CPL]
 //   plain : row = cout, tap = (kz,ky,kx)                       (NT fixed per (Cin, Cout) by conv_config())
 //   x-pair: row = dx*8 + cout, tap = (kz,ky,ix), value W[kx = ix - dx] or 0      (Cout == 8)
-struct ConvCfg { int CB, NT, XP; };
+struct ConvCfg { int CB, NT, XP, C8; };
 static inline ConvCfg conv_config(int Cin, int Cout) {
   ConvCfg c;
+  static const bool no_c8 = getenv("VX_CONV_NO_C8") != nullptr;   // A/B knob: x-pair kernel for every Cout = 8 layer
+  c.C8 = (!no_c8 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
   c.XP = (Cout == 8) ? 1 : 0;
   // x-pair layers always go in chunks of 8 channels (same speed as one chunk of 16 here, and the packing the
@@ -486,6 +492,7 @@ __global__ void pack_conv3d_k3_kernel(const float* __restrict__ w, float* __rest
 extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return -1;
   ConvCfg c = conv_config(Cin, Cout);
+  if (c.C8) return (int64_t)27 * Cin * 8;
   if (c.XP) return (int64_t)16 * Cin * 36;
   return (int64_t)conv_rows_padded(Cout, c.NT) * Cin * 27;
 }
@@ -495,6 +502,7 @@ extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin,
   int64_t total = vx_conv3d_k3_packed_floats(Cin, Cout);
   if (total < 0) VX_FAIL(VX_E_SHAPE, "vx_pack_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", Cin, Cout);
   ConvCfg c = conv_config(Cin, Cout);
+  if (c.C8) return vx_pack_conv3d_k3_c8(w_torch, w_packed, Cin, (hipStream_t)stream);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv3d_k3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin,
@@ -614,6 +622,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   hipStream_t s = (hipStream_t)stream;
+  if (c.C8) return vx_conv3d_k3_c8(a, t.TXV, t.TY, t.TZ, s);
   {
     const int rc = vx_conv3d_k3_try_dma(a, s);   // opt-in (VX_CONV_DMA=1) LDS-DMA schedule; 1 = not taken
     if (rc != 1) return rc;

@@ -6,6 +6,7 @@
 // The output goes straight into channels [out_coff, out_coff + Cout) of the decoder's concat buffer,
 // which removes torch.cat (K7).  Optional ReLU + dropout epilogue for center.4.
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int CT_CO = 8;  // output channels per thread
 
@@ -140,6 +141,109 @@ __global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, i
   }
 }
 
+// Matrix-core variant (Cin in {16, 32, 64, 128}): the up-convolution is the GEMM
+//     out[(dz,dy,dx,co)][voxel] = sum_ci W[(dz,dy,dx,co)][ci] * in[ci][voxel]
+// with 8 * Cout rows.  v_mfma_f32_16x16x4_f32 tiles: 16 rows x 16 consecutive input voxels; k index g of step
+// (q, j) is channel 16 q + 4 g + j, so a lane's B operand is one 16-byte load per 16 channels straight from global
+// memory (a wave reads 16 voxels x 64 B = 1 KiB contiguous) and no LDS is involved.  A lane ends with 4 consecutive
+// output channels of one output voxel -> one 16-byte store; with the rows ordered (dz, dy, dx, co) the 64 lanes of
+// a wave store whole 32/64/128-byte voxels of neighbouring output x.  A workgroup keeps the weights of RT row tiles
+// (blockIdx.y picks which) in registers for its whole life and walks column tiles with a grid stride.  The VALU
+// work left is the bias/activation/dropout epilogue, which leaves the kernel HBM-store-bound.
+template <int CIN, int RT>
+__global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, int ncoltiles, int nvox_in) {
+  constexpr int Q = CIN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int OW = a.W * 2, OH = a.H * 2, OD = a.D * 2;
+  const int rt0 = blockIdx.y * RT;
+  // A fragments: row 16 (rt0 + rt) + m, channels 16 q + 4 g + j; gathered once from the [dz][dy][ci][dx][co] packing
+  f32x4 wreg[RT][Q];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = 16 * (rt0 + rt) + m;
+    const int pos = row / a.Cout, co = row % a.Cout;
+    const float* wp = a.w_packed + (size_t)(pos >> 1) * CIN * 2 * a.Cout + (pos & 1) * a.Cout + co;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wreg[rt][q][j] = wp[(size_t)(16 * q + 4 * g + j) * 2 * a.Cout];
+  }
+  // D fragments: rows 16 (rt0 + rt) + 4 g + r: one output position (dz, dy, dx) and 4 consecutive channels
+  int opos[RT], oco[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = 16 * (rt0 + rt) + 4 * g;
+    opos[rt] = row / a.Cout;
+    oco[rt] = row % a.Cout;
+  }
+  const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;   // x-block size is 1, 2 or 4
+  const int wstride = (int)gridDim.x * 4;
+  for (int ct = blockIdx.x * 4 + wave; ct < ncoltiles; ct += wstride) {
+    const int v = ct * 16 + m;                 // flattened input voxel of this lane's column
+    const bool ok = v < nvox_in;
+    const int vc = ok ? v : nvox_in - 1;
+    f32x4 xv[Q];
+    const float* __restrict__ xin = a.in + (size_t)vc * a.in_pitch + 4 * g;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xin + 16 * q);
+    int r = vc;
+    const int x = r % a.W; r /= a.W;
+    const int y = r % a.H; r /= a.H;
+    const int z = r % a.D;
+    const int n = r / a.D;
+    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[rt][q][j], xv[q][j], acc, 0, 0, 0);
+      const int pos = opos[rt];
+      const int oz = 2 * z + (pos >> 2), oy = 2 * y + ((pos >> 1) & 1), ox = 2 * x + (pos & 1);
+      const size_t orow = ((size_t)n * OD + oz) * OH + oy;
+      if (a.act == VX_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      } else if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.01f * acc[j]);
+      }
+      if (a.drop_mode == VX_DROP_HASH) {
+        const uint32_t bits = vx_drop_bits4(dkey, (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + oco[rt]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+      } else if (a.drop_mode == VX_DROP_MASK) {
+        const uint32_t mk = ok ? *reinterpret_cast<const uint32_t*>(a.drop_mask + (orow * OW + ox) * a.Cout + oco[rt]) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * acc[j] : 0.f;
+      }
+      float* op;
+      if (a.out_xblk)
+        op = a.out + orow * (2 * (size_t)OW * a.Cout) +
+             ((((ox >> xs) * 2 + a.out_half) << xs) + (ox & (a.out_xblk - 1))) * a.Cout + oco[rt];
+      else
+        op = a.out + (orow * OW + ox) * a.out_pitch + a.out_coff + oco[rt];
+      if (ok) *reinterpret_cast<f32x4*>(op) = acc;
+    }
+  }
+}
+
+template <int CIN, int RT>
+static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
+  const int64_t nvox = (int64_t)a.N * a.D * a.H * a.W;
+  const int ncoltiles = (int)((nvox + 15) / 16);
+  const int groups = (a.Cout / 2) / RT;          // 8 * Cout rows = Cout / 2 row tiles
+  int bx = (ncoltiles + 3) / 4;
+  const int cap = (256 * 8 + groups - 1) / groups;
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
+                     ncoltiles, (int)nvox);
+  VX_CHECK_LAUNCH("vx_convT_k2s2(mfma)");
+  return VX_OK;
+}
+
 __global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int64_t total) {
   // torch (Cin, Cout, 2,2,2) -> [dz][dy][ci][dx][co]
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -186,6 +290,15 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   }
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: mask mode without mask");
   if ((int64_t)a.D * a.H * a.W * 8 * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: sample too large");
+  // matrix-core kernel for the channel counts the networks use (row tiles per workgroup: weights stay in <= 128 VGPRs)
+  if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && !getenv("VX_CONVT_NO_MFMA")) {
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = a.Cout / 2;
+    if (a.Cin == 16 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<16, 4>(a, s) : launch_convT_mfma<16, 8>(a, s);
+    if (a.Cin == 32 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<32, 4>(a, s) : launch_convT_mfma<32, 8>(a, s);
+    if (a.Cin == 64 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<64, 4>(a, s) : launch_convT_mfma<64, 8>(a, s);
+    if (a.Cin == 128 && tiles % 4 == 0) return launch_convT_mfma<128, 4>(a, s);
+  }
   // large, shallow up-convolutions: row-streaming kernel (needs 256 % (2*Cout/4) == 0 and Cout <= 128)
   if ((a.Cin == 16 || a.Cin == 32) && a.Cout <= 128 && 256 % (2 * (a.Cout / 4)) == 0) {
     const int64_t total = (int64_t)a.N * a.D * a.H * (2 * a.W) * (a.Cout / 4);

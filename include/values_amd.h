@@ -116,6 +116,15 @@ typedef struct vx_conv3d_args {
   const uint8_t* drop_mask; /* [N][D][H][W][Cout] when VX_DROP_MASK */
   float* stats_partial; /* nullable: [N][ntiles][Cout][2] (sum, sumsq of out before act) */
   int32_t in_xblk;      /* 0 = plain input; 1, 2 or 4 = x-block size of a concat input */
+  /* Optional fused head (only where vx_conv3d_k3_head_fusable(Cin, Cout)): the 1x1x1 conv of
+   * vx_conv1x1_ncdhw applied to this layer's output (after act / dropout) in the epilogue, same
+   * arguments and the same bits; `out` may then be NULL and the feature map is never stored. */
+  float* head_out;      /* nullable: [slots][head_C][D][H][W] */
+  const float* head_w;  /* torch (head_C, Cout, 1,1,1) */
+  const float* head_b;  /* [head_C] */
+  const int32_t* head_dst;  /* nullable: slot of sample n (default n) */
+  const int32_t* head_flip; /* nullable: un-flip code of sample n (bit 0 z, 1 y, 2 x) */
+  int32_t head_C;       /* 1 .. 8 */
 } vx_conv3d_args;
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
  * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
@@ -124,6 +133,7 @@ typedef struct vx_conv3d_args {
 int vx_conv3d_k3_tiles(int D, int H, int W);  /* upper bound of ntiles per sample (stats_partial sizing) */
 int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout); /* exact ntiles for a given Cout (finalize) */
 int vx_conv3d_k3(const vx_conv3d_args* a, vx_stream_t stream);
+int vx_conv3d_k3_head_fusable(int Cin, int Cout); /* 1 if the layer's kernel can take head_out */
 
 /* First layer, Cin == 1 (contr_1_1): input is the reference's (V,1,D,H,W) volume batch.
  * Sample n reads volume src[n] (nullable: n / repeat) with flip code flip[n] (nullable: 0;

@@ -130,6 +130,59 @@ def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeyp
     assert torch.equal(got, got2)   # same accumulation order in both schedules -> bit-identical
 
 
+@pytest.mark.parametrize("cin,shape,ncls,xb", [(8, (3, 8, 8, 32), 2, 0), (16, (2, 5, 7, 38), 4, 0), (16, (2, 4, 8, 16), 2, 4),
+                                                (8, (1, 3, 3, 7), 3, 0)])
+def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb):
+    """expand_1_2 + final (unet3D_module.py:365) in one launch: bit-identical to vx_conv3d_k3 followed by
+    vx_conv1x1_ncdhw, including the slot scatter and the TTA un-flip (test_3D.py:445-447)"""
+    lib = _lib.load()
+    if not lib.vx_conv3d_k3_head_fusable(cin, 8):
+        pytest.skip("head fusion not available for this layer")
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 161))
+    wt = torch.from_numpy(formula_tensor((8, cin, 3, 3, 3), 162, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((8,), 163, scale=0.2))
+    hw = torch.from_numpy(formula_tensor((ncls, 8, 1, 1, 1), 164, scale=0.3)).float().contiguous().to(dev())
+    hb = torch.from_numpy(formula_tensor((ncls,), 165, scale=0.2)).float().to(dev())
+    mask = torch.from_numpy(formula_tensor((n, 8, d, h, w), 166)) > 0
+    if xb:
+        xd = to_xblk(x[:, :cin // 2].float(), x[:, cin // 2:].float(), xb).to(dev())
+    else:
+        xd = cl(x.float()).to(dev())
+    wd, bd = wt.float().contiguous().to(dev()), b.float().to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, 8), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wd), _lib.ptr(wp), cin, 8, _lib.stream_ptr()), "pack")
+    md = cl(mask).to(torch.uint8).to(dev())
+    dst = torch.tensor([(n - 1 - i) * 2 for i in range(n)], dtype=torch.int32, device=dev())   # scattered slots
+    flip = torch.tensor([(3 * i + 5) % 8 for i in range(n)], dtype=torch.int32, device=dev())
+    slots = 2 * n
+    feat = torch.empty((n, d, h, w, 8), dtype=torch.float32, device=dev())
+    a = _lib.ConvArgs()
+    a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = feat.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, 8, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, 8
+    a.act, a.drop_mode, a.drop_mask, a.in_xblk = _lib.VX_ACT_LRELU, _lib.VX_DROP_MASK, md.data_ptr(), xb
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+    ref = torch.full((slots, ncls, d, h, w), -5.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_conv1x1_ncdhw(feat.data_ptr(), 8, hw.data_ptr(), hb.data_ptr(), ref.data_ptr(), n, d, h, w, 8, ncls,
+                                    dst.data_ptr(), flip.data_ptr(), _lib.stream_ptr()), "conv1x1")
+    got = torch.full((slots, ncls, d, h, w), -5.0, dtype=torch.float32, device=dev())
+    a.out = None
+    a.head_out, a.head_w, a.head_b, a.head_C = got.data_ptr(), hw.data_ptr(), hb.data_ptr(), ncls
+    a.head_dst, a.head_flip = dst.data_ptr(), flip.data_ptr()
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv+head")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    # and against the float64 composition of the two reference modules
+    r64 = F.leaky_relu(F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1), 0.01) * mask * 2.0
+    r64 = F.conv3d(r64, hw.cpu().double(), hb.cpu().double())
+    for i in range(n):
+        f = int(flip[i])
+        dims = [1 + k for k in range(3) if f >> k & 1]
+        want = torch.flip(r64[i], dims) if dims else r64[i]
+        assert (got[int(dst[i])].cpu().double() - want).abs().max().item() < 2e-5
+
+
 def test_conv3d_k3_epilogue_act_mask_pitch():
     x = torch.from_numpy(formula_tensor((1, 16, 8, 8, 16), 111))
     wt = torch.from_numpy(formula_tensor((8, 16, 3, 3, 3), 112, scale=0.05))

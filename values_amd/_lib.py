@@ -27,7 +27,9 @@ class ConvArgs(C.Structure):
                 ("in_pitch", _i32), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32),
-                ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32)]
+                ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32),
+                ("head_out", _p), ("head_w", _p), ("head_b", _p), ("head_dst", _p), ("head_flip", _p),
+                ("head_C", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -87,6 +89,7 @@ SIGNATURES = {
     "vx_pack_convT_k2s2": (_i, [_p, _p, _i, _i, _p]),
     "vx_conv3d_k3_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_tiles_for": (_i, [_i, _i, _i, _i]),
+    "vx_conv3d_k3_head_fusable": (_i, [_i, _i]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -31,6 +31,7 @@ struct ConvC8Args {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z;
   unsigned mx, my, mz;   // ceil(2^32 / tiles_*) for the tile decode
+  int no_xcd;            // A/B knob (VX_CONV_NO_XCD): round-robin tile order
   int dbg;               // tuning experiments only (VX_C8_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
   unsigned long long* stamps;  // VX_CONV_STAMPS diagnostic builds only
 };
@@ -189,7 +190,11 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
 #pragma unroll
   for (int c = 0; c < 8; ++c) bias[c] = a.bias[c];
 
+  // Workgroups b, b + 8, b + 16, ... share an XCD (one L2): give each XCD a CONTIGUOUS run of gridDim.x / 8 tiles
+  // per round instead of every 8th tile, so the halo a tile shares with its neighbours is fetched into one L2 once
+  // rather than into all eight (measured fabric-side FETCH_SIZE: 1.7-2.3 x the input with the round-robin order).
   int tile_lin = blockIdx.x, chunk = 0;
+  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -309,14 +314,33 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
           v[4 + c] = ((mk.y >> (8 * c)) & 0xFFu) ? 2.f * v[4 + c] : 0.f;
         }
       }
-      const unsigned vo = bad ? VX_OOB : ovoff;
-      const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), osrd, (int)vo, (int)osoff, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), osrd, (int)(vo + 16u), (int)osoff, 0);
-      // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip): keep the data registers alive
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 3" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      if (a.head_out) {
+        // fused 1x1x1 head (conv1x1.hip: same fmaf chain, slot and un-flip): all 8 channels are in this lane
+        int gx = tx * TXV + lx, gy = ty * TY + ly, gz = tz * TZ + lz;
+        const int f = a.head_flip ? a.head_flip[n] : 0;
+        if (f & 1) gz = a.D - 1 - gz;
+        if (f & 2) gy = a.H - 1 - gy;
+        if (f & 4) gx = a.W - 1 - gx;
+        const size_t nvox = (size_t)a.D * a.H * a.W;
+        const int slot = a.head_dst ? a.head_dst[n] : n;
+        float* o = a.head_out + (size_t)slot * a.head_C * nvox + ((size_t)gz * a.H + gy) * a.W + gx;
+        for (int c = 0; c < a.head_C; ++c) {
+          float hacc = a.head_b[c];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) hacc = fmaf(a.head_w[c * 8 + k], v[k], hacc);
+          if (!bad) o[(size_t)c * nvox] = hacc;
+        }
+      }
+      if (a.out) {
+        const unsigned vo = bad ? VX_OOB : ovoff;
+        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), osrd, (int)vo, (int)osoff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), osrd, (int)(vo + 16u), (int)osoff, 0);
+        // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip): keep the data registers alive
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 3" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     VX_STAMP(5);
 #ifdef VX_CONV_STAMPS
@@ -386,6 +410,7 @@ int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_
   ConvC8Args ka;
   ka.a = a;
   ka.dbg = getenv("VX_C8_DBG") ? atoi(getenv("VX_C8_DBG")) : 0;
+  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);

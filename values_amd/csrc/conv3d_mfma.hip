@@ -47,6 +47,7 @@ struct ConvKArgs {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;  // floor(2^32 / tiles_*) + 1: exact t / tiles_* = umulhi(t, m) for t * tiles_* < 2^32
+  int no_xcd;               // A/B knob (VX_CONV_NO_XCD): round-robin tile order
   unsigned long long* dbg;  // VX_CONV_STAMPS diagnostic builds only
 };
 
@@ -261,7 +262,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   // One flat loop over (tile, chunk) work items: commit the prefetched registers to LDS, issue the NEXT item's
   // global loads (straight-line, predicated -- no loop-carried register copies that would force a vmcnt(0)),
   // compute this item, and run the epilogue after a tile's last chunk.
+  // XCD-aware tile order (see conv3d_c8.hip): each XCD takes a contiguous run of tiles per round
   int tile_lin = blockIdx.x, chunk = 0;
+  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have, true);
   f32x4 acc[R][NT];
@@ -582,14 +585,26 @@ static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s
   return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);
 }
 
+extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
+  return conv_config(Cin, Cout).C8;   // the 4x4x1 kernel keeps all channels of a voxel in one lane
+}
+
 extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (!ap) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: null args");
   const vx_conv3d_args& a = *ap;
-  if (!a.in || !a.w_packed || !a.bias || !a.out) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: null tensor pointer");
+  if (!a.in || !a.w_packed || !a.bias || (!a.out && !a.head_out)) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: null tensor pointer");
+  if (a.head_out) {
+    if (!a.head_w || !a.head_b) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: fused head without weights");
+    if (a.head_C < 1 || a.head_C > 8) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: fused head takes 1..8 classes, got %d", a.head_C);
+    if (!vx_conv3d_k3_head_fusable(a.Cin, a.Cout))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: no fused head for Cin=%d Cout=%d (see vx_conv3d_k3_head_fusable)", a.Cin, a.Cout);
+    if (a.stats_partial) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: fused head on a layer with InstanceNorm statistics");
+  }
   if (a.Cin <= 0 || a.Cout <= 0 || a.Cin % 8 || a.Cout % 8)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", a.Cin, a.Cout);
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: empty tensor");
-  if (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4)
+  if (a.out && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
   if (a.in_xblk) {
     if (a.in_xblk != 1 && a.in_xblk != 2 && a.in_xblk != 4) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: in_xblk must be 0, 1, 2 or 4");
@@ -618,6 +633,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.dbg = nullptr;
+  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

@@ -12,6 +12,7 @@
 // halves are written as dense blocks by their producers and read by the decoder conv through in_xblk.
 // First layer in MC-dropout mode: computed once per volume (the T samples share input and statistics).
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W);
 
@@ -134,9 +135,17 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   auto mask = [&](int i) { return dm == VX_DROP_MASK ? r->masks[i] : (const uint8_t*)nullptr; };
 
   auto xblk_of = [](int W) { return W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); };
+  // head fusion: where the last 3x3x3 conv runs on the kernel that holds a voxel's channels in one lane
+  const bool fuse_head = NC <= 8 && vx_conv3d_k3_head_fusable(F, F) && !getenv("VX_NO_HEAD_FUSION");
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk) {
     vx_conv3d_args a;
+    a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
+    if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
+      a.head_out = r->logits; a.head_w = w->final_w; a.head_b = w->final_b; a.head_C = NC;
+      a.head_dst = r->dst; a.head_flip = r->flip;
+      out = nullptr;
+    }
     a.in_xblk = in_xblk;
     a.in = in; a.w_packed = w->conv_w[wi]; a.bias = w->conv_b[wi]; a.out = out;
     a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.out_coff = out_coff;
@@ -234,7 +243,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------
-  VX_STEP("final", vx_conv1x1_ncdhw(p.B[0], F, w->final_w, w->final_b, r->logits, N, D, H, W, F, NC, r->dst, r->flip, stream));
+  if (!fuse_head)
+    VX_STEP("final", vx_conv1x1_ncdhw(p.B[0], F, w->final_w, w->final_b, r->logits, N, D, H, W, F, NC, r->dst, r->flip, stream));
   return VX_OK;
 }
 

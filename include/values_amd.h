@@ -282,6 +282,14 @@ int vx_softmax_accumulate(const float* logits, int B, int T, int C, int P0, int 
 int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int N, int T, int C, int64_t nvox,
                         float* out, float* sigma, vx_stream_t stream);
 
+/* SSN sampling (SsnUNet3D.forward + distribution.sample, ssn_unet3D_module.py:39-70; test_3D.py:361-396):
+ * head [N][(2+R)*C][nvox] = the three 1x1x1 heads run as one conv (mean | log_cov_diag | cov_factor, factor channel
+ * r*C + c); out [N][S][C][nvox] = mean + sum_r factor_r * eps_w[s][n][r] + sqrt(exp(log_cov_diag) + epsilon) *
+ * eps_d[s][n][c][v]  (torch.distributions.LowRankMultivariateNormal.rsample).  eps_w [S][N][R], eps_d [S][N][C][nvox]
+ * injected, or NULL: generated from `seed`, N(0,1). */
+int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C, int R,
+                  int64_t nvox, float epsilon, float* out, vx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and

@@ -281,3 +281,47 @@ def test_aleatoric_head_sampling_matches_reference_formula():
     assert abs(z.mean().item()) < 0.01 and abs(z.var().item() - 1) < 0.02
     assert abs((z[0] * z[1]).mean().item()) < 0.02
     assert abs(((z ** 4).mean().item()) - 3.0) < 0.1  # kurtosis of a Gaussian
+
+
+def test_ssn_matches_reference_fixture_and_generated_noise_is_standard_normal():
+    """SsnUNet3D (ssn_unet3D_module.py) + predict_cases_ssn sampling (test_3D.py:373-388): head, samples with the
+    reference's captured normals, and the ssn=True maps; then the on-device generator's moments."""
+    from values_amd import SsnUNet3D, predict_uncertainty
+    from values_amd.formula import formula_ssn_state_dict
+    from values_amd.io import instantiate
+    g = load_npz("ssn_16.npz")
+    NC, R, size = 2, 10, 16
+    m = instantiate({"_target_": "uncertainty_modeling.models.ssn_unet3D_module.SsnUNet3D", "num_classes": NC, "rank": R})
+    assert isinstance(m, SsnUNet3D)
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_ssn_state_dict(NC, R).items()}
+    res = m.load_state_dict(sd, strict=True)          # the reference's key names, incl. the unused parent `final`
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda()
+    x = torch.from_numpy(g["input"]).cuda()
+    dist = m(x)
+    vox = size ** 3
+    np.testing.assert_allclose(dist.mean.cpu().numpy(), g["loc"], atol=LOGIT_TOL)
+    head = dist._head.cpu().numpy().reshape(1, (2 + R) * NC, vox)
+    np.testing.assert_allclose(np.exp(head[:, NC:2 * NC]).reshape(1, -1) + 1e-5, g["cov_diag"], rtol=2e-4)
+    fac = head[:, 2 * NC:].reshape(1, R, NC * vox).transpose(0, 2, 1)      # view/flatten/transpose of :52-55
+    np.testing.assert_allclose(fac, g["cov_factor"], atol=LOGIT_TOL)
+    S = g["samples"].shape[0]
+    smp = dist.sample([S], eps_w=torch.from_numpy(g["eps_w"]), eps_d=torch.from_numpy(g["eps_d"]))
+    assert tuple(smp.shape) == g["samples"].shape
+    np.testing.assert_allclose(smp.cpu().numpy(), g["samples"], atol=2e-4)
+    r = predict_uncertainty([m], x, n_pred=S, ssn=True, eps_w=torch.from_numpy(g["eps_w"]), eps_d=torch.from_numpy(g["eps_d"]))
+    for k in KEYS:
+        assert np.abs(r[k][0].cpu().numpy() - g[k]).max() < MAP_TOL, k
+    # generated normals: first two moments over 64 draws, and the low-rank term is shared by all voxels of a draw
+    big = dist.sample_volumes(64, seed=5)[0]                                 # (64, C, D,H,W)
+    mean = dist.mean.reshape(NC, size, size, size)
+    z = (big - mean[None]).reshape(64, -1)
+    var_expected = torch.from_numpy(g["cov_diag"]).cuda().reshape(-1) + (torch.from_numpy(g["cov_factor"]).cuda()[0] ** 2).sum(1)
+    ratio = (z.var(0, unbiased=True) / var_expected).mean().item()
+    assert abs(ratio - 1.0) < 0.05, ratio
+    # the diagonal part alone (mean_only: rank 0, ssn_unet3D_module.py:49-50): element-wise standard normals
+    d0 = m(x, mean_only=True)
+    z0 = (d0.sample_volumes(64, seed=9)[0] - mean[None]).reshape(64, -1) / torch.from_numpy(g["cov_diag"]).cuda().reshape(-1).sqrt()
+    assert abs(z0.mean().item()) < 0.01 and abs(z0.var().item() - 1.0) < 0.01
+    assert abs((z0 ** 4).mean().item() - 3.0) < 0.1       # kurtosis of a normal
+    assert not torch.equal(dist.sample_volumes(2, seed=5)[0, 0], dist.sample_volumes(2, seed=6)[0, 0])

@@ -217,3 +217,26 @@ def test_hrnet_oracle_matches_reference():
         r = unc.calculate_uncertainty(sm1[:, b])
         for k in KEYS:
             np.testing.assert_allclose(r[k], g[f"{k}_{b}"], atol=1e-6)
+
+
+def test_ssn_oracle_matches_reference():
+    """SsnUNet3D.forward + distribution.sample (ssn_unet3D_module.py:39-70, test_3D.py:373-388) + ssn=True maps"""
+    from oracle.ssn_oracle import lowrank_rsample, ssn_distribution
+    from values_amd.formula import formula_ssn_state_dict
+    g = load_npz("ssn_16.npz")
+    NC, R = 2, 10
+    sd = {k: torch.from_numpy(v) for k, v in formula_ssn_state_dict(NC, R).items()}
+    x = torch.from_numpy(formula_volume((1, 1, 16, 16, 16)))
+    np.testing.assert_array_equal(x.numpy().astype(np.float32), g["input"])
+    with torch.no_grad():
+        loc, diag, fac = ssn_distribution(sd, x, NC, R)
+    np.testing.assert_allclose(loc.numpy(), g["loc"], atol=5e-7)
+    np.testing.assert_allclose(diag.numpy(), g["cov_diag"], rtol=1e-6)
+    np.testing.assert_allclose(fac.numpy(), g["cov_factor"], atol=5e-7)
+    smp = lowrank_rsample(loc.numpy(), diag.numpy(), fac.numpy(), g["eps_w"], g["eps_d"])
+    np.testing.assert_allclose(smp, g["samples"], atol=2e-6)
+    S = smp.shape[0]
+    sm = unc.softmax(smp.reshape(S, NC, 16, 16, 16), axis=1)
+    r = unc.calculate_uncertainty(sm, ssn=True)
+    for k in KEYS:
+        np.testing.assert_allclose(r[k], g[k], atol=1e-6)

@@ -328,6 +328,49 @@ class _Cfg(dict):
         return _Cfg(v) if isinstance(v, dict) else v
 
 
+def gen_ssn():
+    """G7 ssn_16.npz: the reference SsnUNet3D (ssn_unet3D_module.py) + distribution.sample as predict_cases_ssn
+    calls it (test_3D.py:373-385), with the standard normals of LowRankMultivariateNormal.rsample replaced by
+    formula tensors (captured), then softmax + calculate_uncertainty(ssn=True)."""
+    import torch.distributions.lowrank_multivariate_normal as lrm
+    from uncertainty_modeling.models.ssn_unet3D_module import SsnUNet3D as RefSsn
+    from values_amd.formula import formula_ssn_state_dict
+    NC, R, S, size = 2, 10, 3, 16
+    model = RefSsn(num_classes=NC, rank=R)
+    sd = formula_ssn_state_dict(NC, R)
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    model = model.double()  # test_3D.py:367
+    x = torch.from_numpy(formula_volume((1, 1, size, size, size)))
+    with torch.no_grad():
+        dist = model.forward(x)
+    drawn = []
+    orig = lrm._standard_normal
+
+    def fake_normal(shape, dtype, device):
+        t = torch.from_numpy(formula_tensor(tuple(shape), tag=9000 + len(drawn), scale=1.7)).to(dtype)
+        drawn.append(t)
+        return t
+
+    lrm._standard_normal = fake_normal
+    try:
+        samples = dist.sample([S])   # (S, 1, NC * vox)
+    finally:
+        lrm._standard_normal = orig
+    assert len(drawn) == 2 and drawn[0].shape[-1] == R
+    out = {"input": x.numpy().astype(np.float32),
+           "loc": dist.loc.numpy().astype(np.float32), "cov_diag": dist.cov_diag.numpy().astype(np.float32),
+           "cov_factor": dist.cov_factor.numpy().astype(np.float32),           # (1, NC * vox, R)
+           "eps_w": drawn[0].numpy().astype(np.float32), "eps_d": drawn[1].numpy().astype(np.float32),
+           "samples": samples.numpy().astype(np.float32)}
+    vol = samples.view([S, 1, NC, size, size, size])
+    sm = torch.stack([F.softmax(v, dim=1)[0] for v in vol])      # test_3D.py:386-388 -> buffer (S, NC, ...)
+    unc = _t(ref_t3.calculate_uncertainty(torch.from_numpy(sm.numpy().astype(np.float64)), ssn=True))
+    out.update(unc)
+    np.savez_compressed(os.path.join(OUT, "ssn_16.npz"), **out)
+    print("G7 ssn_16.npz", os.path.getsize(os.path.join(OUT, "ssn_16.npz")) / 1e6, "MB; sample range",
+          float(samples.min()), float(samples.max()))
+
+
 def gen_hrnet():
     import copy
     import uncertainty_modeling.models.hrnet_module as ref_hr
@@ -391,7 +434,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -406,3 +449,5 @@ if __name__ == "__main__":
         gen_agg()
     if "hrnet" in which:
         gen_hrnet()
+    if "ssn" in which:
+        gen_ssn()

@@ -113,3 +113,52 @@ extern "C" int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t
   VX_CHECK_LAUNCH("vx_aleatoric_sample");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stochastic segmentation networks (SsnUNet3D.forward, ssn_unet3D_module.py:39-70; predict_cases_ssn,
+// test_3D.py:361-396): the three 1x1x1 heads on the decoder features are ONE 1x1x1 conv with (2 + R) * C output
+// channels -- [mean (C) | log_cov_diag (C) | cov_factor (R * C, channel r * C + c)] -- whose planar output `head`
+// this kernel turns into samples of LowRankMultivariateNormal(loc, cov_factor, cov_diag).rsample:
+//     y_s[c][v] = mean[c][v] + sum_r factor[r][c][v] * eps_w[s][r] + sqrt(exp(logd[c][v]) + epsilon) * eps_d[s][c][v]
+// eps_w is ONE rank-R vector per sample (the low-rank term couples all voxels), eps_d one normal per element; both
+// are injected (parity) or generated from `seed`.  HBM-bound: (2 + R) * C floats read, S * C written per voxel.
+__global__ __launch_bounds__(256) void ssn_sample_kernel(const float* __restrict__ head, const float* __restrict__ eps_w,
+                                                         const float* __restrict__ eps_d, uint32_t seed, int N, int S,
+                                                         int C, int R, int64_t nvox, float epsilon,
+                                                         float* __restrict__ out) {
+  const int64_t per = (int64_t)C * nvox;
+  const int64_t total = (int64_t)N * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per);
+    const int64_t r = i - (int64_t)n * per;   // c * nvox + v
+    const float* h = head + (size_t)n * (2 + R) * per;
+    const float mean = h[r];
+    const float sd = sqrtf(expf(h[per + r]) + epsilon);
+    for (int s = 0; s < S; ++s) {
+      float low = 0.f;
+      for (int k = 0; k < R; ++k) {
+        const float ew = eps_w ? eps_w[((size_t)s * N + n) * R + k]
+                               : vx_gauss(seed ^ 0x5bd1e995u, (uint32_t)k, (uint32_t)(n * S + s));
+        low = fmaf(h[(size_t)(2 + k) * per + r], ew, low);
+      }
+      const size_t o = ((size_t)n * S + s) * per + r;
+      const float ed = eps_d ? eps_d[((size_t)s * N + n) * per + r] : vx_gauss(seed, (uint32_t)r, (uint32_t)(n * S + s));
+      out[o] = (mean + low) + sd * ed;   // loc + W eps_W + D^(1/2) eps_D, the order torch adds them
+    }
+  }
+}
+
+extern "C" int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C,
+                             int R, int64_t nvox, float epsilon, float* out, vx_stream_t stream) {
+  if (N <= 0 || S <= 0 || C <= 0 || R < 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_ssn_sample: bad shape");
+  if (nvox == 0) return VX_OK;
+  if (!head || !out) VX_FAIL(VX_E_NULL, "vx_ssn_sample: null pointer");
+  if ((int64_t)C * nvox >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_ssn_sample: sample too large");
+  const int64_t total = (int64_t)N * C * nvox;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(ssn_sample_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, head, eps_w, eps_d, seed, N, S, C, R,
+                     nvox, epsilon, out);
+  VX_CHECK_LAUNCH("vx_ssn_sample");
+  return VX_OK;
+}

@@ -94,6 +94,19 @@ def formula_unet3d_state_dict(seed_tag: int = 0, **kw) -> "OrderedDict[str, np.n
     return sd
 
 
+def formula_ssn_state_dict(num_classes: int = 2, rank: int = 10, seed_tag: int = 0, f: int = 8):
+    """Weights for the reference SsnUNet3D (ssn_unet3D_module.py:7-37): the parent UNet3D built with
+    num_classes * (2 + rank) outputs, plus the mean / log_cov_diag / cov_factor 1x1x1 heads."""
+    sd = formula_unet3d_state_dict(seed_tag=seed_tag, num_classes=num_classes * 2 + num_classes * rank, f=f)
+    bound = 1.0 / math.sqrt(f)
+    for i, (name, cout) in enumerate((("mean_conv", num_classes), ("log_cov_diag_conv", num_classes),
+                                      ("cov_factor_conv", num_classes * rank))):
+        for j, (suffix, shape) in enumerate(((".weight", (cout, f, 1, 1, 1)), (".bias", (cout,)))):
+            w = formula_tensor(shape, tag=5000 * (seed_tag + 1) + 10 * i + j, scale=bound)
+            sd[name + suffix] = w.astype(np.float32).astype(np.float64)
+    return sd
+
+
 def formula_volume(shape, tag: int = 7) -> np.ndarray:
     """Smooth-ish z-scored test volume: a few low-frequency bumps + hash noise."""
     shape = tuple(shape)

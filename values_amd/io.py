@@ -18,6 +18,8 @@ import torch
 TARGET_MAP = {
     "uncertainty_modeling.models.unet3D_module.UNet3D": "values_amd.unet3d.UNet3D",
     "models.unet3D_module.UNet3D": "values_amd.unet3d.UNet3D",
+    "uncertainty_modeling.models.ssn_unet3D_module.SsnUNet3D": "values_amd.ssn.SsnUNet3D",
+    "models.ssn_unet3D_module.SsnUNet3D": "values_amd.ssn.SsnUNet3D",
 }
 
 

@@ -49,15 +49,28 @@ def _predict_logits_aleatoric(models, x, n_samples, eps=None, seeds=None):
     return out
 
 
+def predict_logits_ssn(model, x: torch.Tensor, n_pred: int = 1, eps_w=None, eps_d=None, seed=None) -> torch.Tensor:
+    """predict_cases_ssn (test_3D.py:361-396) for a batch of volumes: x (V,1,D,H,W) -> (V, n_pred, C, D,H,W) logit
+    samples of the network's low-rank normal (softmax + reduction follow in uncertainty_maps)."""
+    _lib.require_gpu()
+    dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    dist = model(x.to(dev, torch.float32))
+    return dist.sample_volumes(n_pred, eps_w=eps_w, eps_d=eps_d, seed=seed)
+
+
 def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
                    x_noise: Optional[torch.Tensor] = None, dropout_masks=None, seeds=None,
-                   n_aleatoric_samples: int = 10, eps=None) -> torch.Tensor:
+                   n_aleatoric_samples: int = 10, eps=None, **kw_ssn) -> torch.Tensor:
     """x: (V,1,D,H,W).  Returns logits (V, n_total, C, D,H,W) f32 on the device, n_total = passes per volume in
     pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests)."""
     _lib.require_gpu()
     dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
     x = x.to(dev, torch.float32)
     V, _, D, H, W = x.shape
+    if hasattr(models[0], "rank") and hasattr(models[0], "cov_factor_conv"):
+        # predict_cases_ssn (test_3D.py:361-396): ONE forward -> distribution; n_pred draws of it
+        return predict_logits_ssn(models[0], x, n_pred, eps_w=kw_ssn.get("eps_w"), eps_d=kw_ssn.get("eps_d"),
+                                  seed=seeds[0] if seeds is not None else None)
     aleatoric = bool(getattr(models[0], "aleatoric_loss", False)) and not tta
     if aleatoric:
         # test_3D.py:458-469: ONE forward -> (mu, s); n_pred := n_aleatoric_samples draws of mu + exp(s/2) * eps

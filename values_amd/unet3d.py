@@ -124,9 +124,7 @@ class UNet3D(nn.Module):
             keep += [packed, b, wt]
             w.up_w[i] = packed.data_ptr()
             w.up_b[i] = b.data_ptr()
-        head = "final_aleatoric" if self.aleatoric_loss else "final"
-        fw = sd[head + ".weight"].reshape(sd[head + ".weight"].shape[0], -1).contiguous()
-        fb = sd[head + ".bias"]
+        fw, fb = self._head_params(sd)
         keep += [fw, fb]
         w.final_w = fw.data_ptr()
         w.final_b = fb.data_ptr()
@@ -135,6 +133,11 @@ class UNet3D(nn.Module):
         self._packed = (w, keep)
         self._packed_key = key
         return self._packed
+
+    def _head_params(self, sd):
+        """(weight (C, F), bias (C,)) of the 1x1x1 head the forward ends with (unet3D_module.py:199-204, 365-369)."""
+        head = "final_aleatoric" if self.aleatoric_loss else "final"
+        return sd[head + ".weight"].reshape(sd[head + ".weight"].shape[0], -1).contiguous(), sd[head + ".bias"]
 
     def _workspace(self, N, D, H, W, device):
         key = (N, D, H, W, str(device))
@@ -153,6 +156,14 @@ class UNet3D(nn.Module):
                 dropout_masks: Optional[Sequence[torch.Tensor]] = None, seed: Optional[int] = None):
         if not enable_concat or not last_layer:
             raise NotImplementedError("values_amd.UNet3D: autoencoder / feature modes are training-only and not on the HIP path")
+        res = self._run(x, n_samples=n_samples, src=src, flip=flip, dst=dst, out=out, dropout_masks=dropout_masks, seed=seed)
+        if self.aleatoric_loss:
+            mu, s = res.split(self.num_classes, 1)  # unet3D_module.py:367-369
+            return mu, s
+        return res
+
+    def _run(self, x, *, n_samples=1, src=None, flip=None, dst=None, out=None, dropout_masks=None, seed=None):
+        """The whole network through vx_unet3d_forward: (N, head channels, D, H, W) in x's dtype."""
         _lib.require_gpu()
         lib = _lib.load()
         if x.dim() != 5 or x.shape[1] != 1:
@@ -202,8 +213,4 @@ class UNet3D(nn.Module):
         run.workspace_bytes = ws_bytes
         _lib.check(lib.vx_unet3d_forward(C.byref(w), C.byref(run), _lib.stream_ptr()), "vx_unet3d_forward")
         self._hold = hold  # keep inputs alive until the stream has consumed them
-        res = out if in_dtype == torch.float32 else out.to(in_dtype)
-        if self.aleatoric_loss:
-            mu, s = res.split(self.num_classes, 1)  # unet3D_module.py:367-369
-            return mu, s
-        return res
+        return out if in_dtype == torch.float32 else out.to(in_dtype)

@@ -290,6 +290,17 @@ int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int 
 int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C, int R,
                   int64_t nvox, float epsilon, float* out, vx_stream_t stream);
 
+/* Metric reductions behind calculate_test_metrics / calculate_ged (test_3D.py:250-358): see metrics.hip.
+ * vx_mask_agreement: masks [M][nvox] uint8 labels < C; counts [M][M][C] uint64 (zeroed here),
+ *   counts[i][j][c] = #{v: mask_i(v) == c and mask_j(v) == c}.  M <= 32, C <= 8.
+ * vx_soft_metric_sums: prob [C][nvox] float32 (mean softmax), gt [R][nvox] uint8; sums [R][3*C+1] float64:
+ *   for each class (sum p_c [gt==c], sum [gt==c], sum p_c), then sum_v log p_{gt(v)}(v);
+ *   workspace of vx_soft_metric_workspace_bytes(C, R). */
+int vx_mask_agreement(const uint8_t* masks, int M, int C, int64_t nvox, uint64_t* counts, vx_stream_t stream);
+int64_t vx_soft_metric_workspace_bytes(int C, int R);
+int vx_soft_metric_sums(const float* prob, const uint8_t* gt, int C, int R, int64_t nvox, double* sums, void* workspace,
+                        vx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and

@@ -74,3 +74,46 @@ def test_softmax_model_gets_one_minus_msr_maps(tmp_path):
     ref = 1 - sm[0].double().cpu().numpy().max(0)
     np.testing.assert_allclose(got, ref, atol=1e-12)
     assert dl.get_mean_pred_seg("c0").shape == (16, 16, 16)  # Softmax models use the _01 segmentation
+
+
+@pytest.mark.parametrize("C,T,R,shape", [(2, 5, 4, (12, 10, 8)), (3, 4, 3, (9, 7, 5)), (2, 1, 1, (4, 4, 4))])
+def test_metrics_match_oracle(C, T, R, shape):
+    """calculate_test_metrics / calculate_ged (test_3D.py:250-358) from the two device reductions vs the oracle"""
+    from oracle import metrics_oracle as mo
+    from values_amd.formula import formula_tensor
+    from values_amd.metrics import calculate_ged, calculate_test_metrics, mask_agreement
+    logits = formula_tensor((T, C) + shape, 8100 + C, scale=2.5)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    sm = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    gt = ((formula_tensor((R,) + shape, 8200 + C) + 1.0) * 0.5 * C).astype(np.int64).clip(0, C - 1)
+    mean = sm.mean(0, keepdims=True)
+    got = calculate_test_metrics(torch.from_numpy(mean).cuda(), torch.from_numpy(gt).cuda())
+    ref = mo.calculate_test_metrics(mean.astype(np.float64), gt)
+    assert abs(got["loss"] - ref["loss"]) < 1e-5 and abs(got["dice"] - ref["dice"]) < 1e-7
+    got = calculate_ged(torch.from_numpy(sm).cuda(), torch.from_numpy(gt).cuda())
+    ref = mo.calculate_ged(sm, gt)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) < 1e-6, k
+    # the counts themselves, against a direct count
+    masks = np.concatenate([sm.argmax(1), gt], 0)
+    I = mask_agreement(torch.from_numpy(masks).cuda(), C)
+    for i in range(len(masks)):
+        for j in range(len(masks)):
+            for c in range(C):
+                assert I[i, j, c] == int(((masks[i] == c) & (masks[j] == c)).sum())
+
+
+def test_metrics_edge_cases():
+    from oracle import metrics_oracle as mo
+    from values_amd.metrics import calculate_ged
+    shape = (6, 6, 6)
+    sm = np.zeros((3, 2) + shape, np.float32); sm[:, 0] = 0.9; sm[:, 1] = 0.1       # predictions: all background
+    gt = np.zeros((2,) + shape, np.int64)                                           # raters: all background
+    got, ref = calculate_ged(torch.from_numpy(sm).cuda(), torch.from_numpy(gt).cuda()), mo.calculate_ged(sm, gt)
+    assert got == pytest.approx(ref) and got["ged"] == pytest.approx(0.0)           # 2*1 - 1 - 1 (all 0/0 -> Dice 0)
+    gt[0, :3] = 1
+    got, ref = calculate_ged(torch.from_numpy(sm).cuda(), torch.from_numpy(gt).cuda()), mo.calculate_ged(sm, gt)
+    assert got == pytest.approx(ref)
+    got = calculate_ged(torch.from_numpy(sm).cuda(), torch.from_numpy(gt).cuda(), ged_only=True)
+    assert list(got) == ["ged"]

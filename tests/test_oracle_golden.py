@@ -240,3 +240,26 @@ def test_ssn_oracle_matches_reference():
     r = unc.calculate_uncertainty(sm, ssn=True)
     for k in KEYS:
         np.testing.assert_allclose(r[k], g[k], atol=1e-6)
+
+
+def test_metrics_oracle_loss_matches_reference_and_dice_by_definition():
+    """SoftDiceLoss + NLLLoss (loss_modules.py:7-97, test_3D.py:262-273) pinned to the imported reference; the
+    torchmetrics Dice restatement against the textbook definition on label masks (parity unpinned, see the oracle)."""
+    from oracle import metrics_oracle as mo
+    g = load_npz("metrics_kat.npz")
+    for C in (2, 3):
+        sm, gt = g[f"softmax_{C}"], g[f"gt_{C}"]
+        per = [mo.soft_dice_loss(sm, gt[r][None]) + mo.nll_loss(np.log(sm), gt[r][None]) for r in range(gt.shape[0])]
+        np.testing.assert_allclose(per, g[f"loss_per_rater_{C}"], rtol=1e-10)
+        assert abs(mo.calculate_test_metrics(sm, gt)["loss"] - float(g[f"loss_{C}"])) < 1e-10
+    a = np.array([[0, 1, 1, 0, 1, 0]]); b = np.array([[0, 1, 0, 0, 1, 1]])
+    assert mo.tm_dice(a, b, ignore_index=0) == pytest.approx(2 * 2 / (3 + 3))          # foreground Dice
+    assert mo.tm_dice(a, b) == pytest.approx(4 / 6)                                     # micro over both classes = accuracy
+    assert mo.tm_dice(np.zeros((1, 5), int), np.zeros((1, 5), int), ignore_index=0) == 0.0   # empty foreground: 0/0 -> 0
+    probs = np.stack([1 - a, a], 1).astype(np.float64) * 0.8 + 0.1                     # (1, 2, 6): arg-max == a
+    assert mo.tm_dice(probs, b, ignore_index=0) == pytest.approx(4 / 6)
+    # GED of identical predictions and raters is 0; of disjoint masks 2 * 1 - 0 - 0
+    sm1 = np.repeat(probs, 3, 0)
+    assert mo.calculate_ged(sm1, np.repeat(a, 2, 0))["ged"] == pytest.approx(0.0)
+    anti = np.stack([a, 1 - a], 1).astype(np.float64) * 0.8 + 0.1
+    assert mo.calculate_ged(np.repeat(anti, 2, 0), np.repeat(a, 2, 0))["ged"] == pytest.approx(2.0)

@@ -371,6 +371,28 @@ def gen_ssn():
           float(samples.min()), float(samples.max()))
 
 
+def gen_metrics():
+    """G8 metrics_kat.npz: the reference's SoftDiceLoss (loss_modules.py) + torch NLLLoss exactly as
+    calculate_test_metrics combines them (test_3D.py:262-273), on a formula mean-softmax (1, C, 12,10,8) and R = 3
+    formula raters, for C = 2 and C = 3.  (The Dice/GED half needs torchmetrics, absent here: unpinned.)"""
+    from loss_modules import SoftDiceLoss
+    out = {}
+    for C in (2, 3):
+        logits = torch.from_numpy(formula_tensor((1, C, 12, 10, 8), 7100 + C, scale=2.0))
+        sm = F.softmax(logits, dim=1)
+        gt = torch.from_numpy(((formula_tensor((3, 12, 10, 8), 7200 + C) + 1.0) * 0.5 * C).astype(np.int64).clip(0, C - 1))
+        losses = []
+        for r in range(gt.shape[0]):
+            g = torch.unsqueeze(gt[r], 0).type(torch.LongTensor)
+            losses.append((SoftDiceLoss()(sm, g) + torch.nn.NLLLoss()(torch.log(sm), g)).item())
+        out[f"softmax_{C}"] = sm.numpy()
+        out[f"gt_{C}"] = gt.numpy().astype(np.uint8)
+        out[f"loss_per_rater_{C}"] = np.array(losses)
+        out[f"loss_{C}"] = np.mean(np.array(losses))
+    np.savez_compressed(os.path.join(OUT, "metrics_kat.npz"), **out)
+    print("G8 metrics_kat.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("loss")})
+
+
 def gen_hrnet():
     import copy
     import uncertainty_modeling.models.hrnet_module as ref_hr
@@ -434,7 +456,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -451,3 +473,5 @@ if __name__ == "__main__":
         gen_hrnet()
     if "ssn" in which:
         gen_ssn()
+    if "metrics" in which:
+        gen_metrics()

@@ -104,6 +104,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_char_p), C.POINTER(_i)]),
     "vx_softmax_accumulate": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vx_aleatoric_sample": (_i, [_p, _p, _u32, _i, _i, _i, _i64, _p, _p, _p]),
+    "vx_mask_agreement": (_i, [_p, _i, _i, _i64, _p, _p]),
+    "vx_soft_metric_workspace_bytes": (_i64, [_i, _i]),
+    "vx_soft_metric_sums": (_i, [_p, _p, _i, _i, _i64, _p, _p, _p]),
     "vx_ssn_sample": (_i, [_p, _p, _p, _u32, _i, _i, _i, _i, _i64, C.c_float, _p, _p]),
     "vx_conv2d_packed_floats": (_i64, [_i, _i, _i]),
     "vx_pack_conv2d": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -290,6 +290,14 @@ int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int 
 int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C, int R,
                   int64_t nvox, float epsilon, float* out, vx_stream_t stream);
 
+/* K21: threshold search (evaluation/uncertainty_aggregation/find_threshold.py).
+ * vx_select_kth: out[0] = k-th smallest (0-based) of the n finite float32 values of x, by radix select
+ *   (np.quantile(x, q) = lerp of the two order statistics around q*(n-1), done by the host in float64);
+ *   workspace of vx_select_workspace_bytes().  vx_count_nonzero_u8: np.count_nonzero of a label mask. */
+int64_t vx_select_workspace_bytes(void);
+int vx_select_kth(const float* x, int64_t n, int64_t k, float* out, void* workspace, vx_stream_t stream);
+int vx_count_nonzero_u8(const uint8_t* x, int64_t n, uint64_t* out, vx_stream_t stream);
+
 /* Metric reductions behind calculate_test_metrics / calculate_ged (test_3D.py:250-358): see metrics.hip.
  * vx_mask_agreement: masks [M][nvox] uint8 labels < C; counts [M][M][C] uint64 (zeroed here),
  *   counts[i][j][c] = #{v: mask_i(v) == c and mask_j(v) == c}.  M <= 32, C <= 8.

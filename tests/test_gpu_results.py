@@ -117,3 +117,57 @@ def test_metrics_edge_cases():
     assert got == pytest.approx(ref)
     got = calculate_ged(torch.from_numpy(sm).cuda(), torch.from_numpy(gt).cuda(), ged_only=True)
     assert list(got) == ["ged"]
+
+
+@pytest.mark.parametrize("n,qs", [(1, [0.0, 0.5, 1.0]), (2, [0.25, 0.5, 0.75]), (1000, [0.0, 0.013, 0.5, 0.987, 1.0]),
+                                  (3 * 64 ** 3, [0.9731, 0.5, 0.99999])])
+def test_quantile_is_bit_identical_to_numpy(n, qs):
+    """np.quantile of find_threshold.py:61-66 via radix select: exact, including ties, negatives and interpolation"""
+    from values_amd.formula import hash_uniform
+    from values_amd.thresholds import quantile
+    x = (hash_uniform(n, 31) * 0.7).astype(np.float32)
+    x[::7] = 0.0                      # many exact ties at 0 (uncertainty maps are mostly 0)
+    x[1::11] = np.abs(x[1::11])
+    xd = torch.from_numpy(x).cuda()
+    for q in qs:
+        # float64 index and interpolation on the float32 values = numpy 1.24.3 (the reference's pin) for a python-float
+        # q; numpy >= 2 rounds q and the interpolation to float32 for float32 data, so compare on the float64 view
+        assert quantile(xd, q) == float(np.quantile(x.astype(np.float64), q)), (n, q)
+    assert quantile(torch.zeros(50).cuda(), 0.3) == 0.0
+
+
+def test_find_threshold_files(tmp_path):
+    """quantile_analysis.json / threshold_analysis.json as find_threshold.py writes them, consumed by
+    threshold_aggregation (aggregate_uncertainties.py:59-60)"""
+    from values_amd import nifti
+    from values_amd.aggregation import threshold_aggregation
+    from values_amd.formula import formula_tensor
+    from values_amd.thresholds import (calculate_foreground_quantile_image, find_threshold, save_foreground_quantiles)
+    segs = [(formula_tensor((8, 8, 8), 40 + i) > 0.6).astype(np.uint8) for i in range(3)]
+    qs = [calculate_foreground_quantile_image(s) for s in segs]
+    assert qs == [1 - np.count_nonzero(s) / s.size for s in segs]
+    methods = save_foreground_quantiles({"Dropout": {"v1": qs[:2], "v2": qs[2:]}, "Softmax": {"v1": qs[:1]}}, tmp_path)
+    assert methods["Dropout"] == float(np.mean(qs))
+    paths = {"Dropout": {"v1": {}}, "Softmax": {"v1": {}}}
+    maps = {}
+    for unc in ("predictive_uncertainty", "aleatoric_uncertainty", "epistemic_uncertainty"):   # evaluation/configs/datasets/*.yaml
+        ps = []
+        for i in range(2):
+            m = np.abs(formula_tensor((8, 8, 8), 50 + i + len(unc))).astype(np.float32)
+            p = tmp_path / f"{unc}_{i}.nii.gz"
+            nifti.save(m, p)
+            ps.append(p)
+            maps.setdefault(unc, []).append(m)
+        paths["Dropout"]["v1"][unc] = ps
+    paths["Softmax"]["v1"]["predictive_uncertainty"] = paths["Dropout"]["v1"]["predictive_uncertainty"]
+    td = find_threshold(paths, tmp_path, tmp_path)
+    want = float(np.quantile(np.array(maps["aleatoric_uncertainty"]).astype(np.float64), methods["Dropout"]))
+    assert td["Dropout"]["Mean aleatoric threshold"] == want
+    on_disk = json.load(open(tmp_path / "threshold_analysis.json"))
+    assert on_disk["Mean"]["Mean predictive threshold"] == np.mean([td["Dropout"]["Mean predictive threshold"],
+                                                                     td["Softmax"]["Mean predictive threshold"]])
+    r = threshold_aggregation(image=maps["predictive_uncertainty"][0], pred_model="Dropout", unc_type="predictive_uncertainty",
+                              threshold_path=str(tmp_path / "threshold_analysis.json"))
+    assert r["threshold"] == on_disk["Dropout"]["Mean predictive threshold"]
+    m = maps["predictive_uncertainty"][0].astype(np.float64)
+    assert abs(r["max_score"] - m[m >= r["threshold"]].mean()) < 1e-9

@@ -290,6 +290,11 @@ int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int 
 int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C, int R,
                   int64_t nvox, float epsilon, float* out, vx_stream_t stream);
 
+/* Colour rendering of an arg-max mask (Tester.save_prediction, test_2D.py:124-134): rgb[i] = lut[labels[i]] with
+ * labels[i] := unlabeled where ignore[i] != 0 (ignore nullable); lut [256][3] uint8, rgb [n][3]. */
+int vx_colorize_u8(const uint8_t* labels, const uint8_t* ignore, int64_t n, const uint8_t* lut, int unlabeled, uint8_t* rgb,
+                   vx_stream_t stream);
+
 /* K21: threshold search (evaluation/uncertainty_aggregation/find_threshold.py).
  * vx_select_kth: out[0] = k-th smallest (0-based) of the n finite float32 values of x, by radix select
  *   (np.quantile(x, q) = lerp of the two order statistics around q*(n-1), done by the host in float64);

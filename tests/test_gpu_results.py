@@ -171,3 +171,29 @@ def test_find_threshold_files(tmp_path):
     assert r["threshold"] == on_disk["Dropout"]["Mean predictive threshold"]
     m = maps["predictive_uncertainty"][0].astype(np.float64)
     assert abs(r["max_score"] - m[m >= r["threshold"]].mean()) < 1e-9
+
+
+def test_2d_results_directory(tmp_path):
+    """save_prediction / save_uncertainty (test_2D.py:116-159): names, colours, ignore map, float32 TIFF content"""
+    from values_amd.formula import formula_tensor
+    from values_amd.image_io import read_png, read_tiff_f32
+    from values_amd.results2d import TRAINID2COLOR, create_save_dirs, save_prediction, save_uncertainty
+    H, W, T = 12, 20, 3
+    masks = ((formula_tensor((T, H, W), 71) + 1) * 12).astype(np.uint8).clip(0, 23)
+    mean = ((formula_tensor((H, W), 72) + 1) * 12).astype(np.uint8).clip(0, 23)
+    ign = formula_tensor((H, W), 73) > 0.8
+    d = create_save_dirs(str(tmp_path), "exp", 0, "val")
+    assert d["save_pred_dir"].endswith(os.path.join("exp", "test_results", "0", "val", "pred_seg"))
+    save_prediction(d["save_pred_dir"], "img7", torch.from_numpy(masks).cuda(), torch.from_numpy(mean).cuda(), ign)
+    assert sorted(os.listdir(d["save_pred_dir"])) == ["img7_01.png", "img7_02.png", "img7_03.png", "img7_mean.png"]
+    want = np.zeros((H, W, 3), np.uint8)
+    lab = mean.copy(); lab[ign] = 255
+    for k, v in TRAINID2COLOR.items():
+        want[lab == k] = v
+    np.testing.assert_array_equal(read_png(os.path.join(d["save_pred_dir"], "img7_mean.png")), want)
+    save_prediction(d["save_pred_dir"], "solo", torch.from_numpy(masks[:1]).cuda(), None, None)
+    assert os.path.exists(os.path.join(d["save_pred_dir"], "solo_01.png"))
+    unc = {"pred_entropy": torch.from_numpy(np.abs(formula_tensor((H, W), 74)).astype(np.float32)).cuda()}
+    save_uncertainty(d["save_dir"], "img7", unc)
+    np.testing.assert_array_equal(read_tiff_f32(os.path.join(d["save_dir"], "pred_entropy", "img7.tif")),
+                                  unc["pred_entropy"].cpu().numpy())

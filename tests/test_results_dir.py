@@ -90,3 +90,31 @@ def test_experiment_version_and_dataloader_paths(tmp_path):
     assert refs.shape == (2, 6, 5, 4)
     np.testing.assert_array_equal(dl.get_gt_unc_map("img0"), np.var(refs, axis=0))
     assert dl.get_aggregated_unc_files_dict() == {}
+
+
+def test_png_and_tiff_codecs_round_trip_and_decode_with_an_independent_reader(tmp_path):
+    """2D result files (test_2D.py:145-158): our writers vs our readers, and vs PIL where it is installed"""
+    from values_amd.formula import formula_tensor
+    from values_amd.image_io import read_png, read_tiff_f32, write_png, write_tiff_f32
+    rgb = ((formula_tensor((37, 53, 3), 91) + 1) * 127.5).astype(np.uint8)
+    grey = ((formula_tensor((5, 7), 92) + 1) * 127.5).astype(np.uint8)
+    f32 = formula_tensor((31, 17), 93, scale=3.0).astype(np.float32)
+    f32[0, 0], f32[1, 1] = 0.0, np.float32(1e-30)
+    write_png(tmp_path / "a.png", rgb); write_png(tmp_path / "g.png", grey); write_tiff_f32(tmp_path / "f.tif", f32)
+    np.testing.assert_array_equal(read_png(tmp_path / "a.png"), rgb)
+    np.testing.assert_array_equal(read_png(tmp_path / "g.png"), grey)
+    np.testing.assert_array_equal(read_tiff_f32(tmp_path / "f.tif"), f32)
+    PIL = pytest.importorskip("PIL.Image")
+    np.testing.assert_array_equal(np.array(PIL.open(tmp_path / "a.png")), rgb)
+    np.testing.assert_array_equal(np.array(PIL.open(tmp_path / "g.png")), grey)
+    np.testing.assert_array_equal(np.array(PIL.open(tmp_path / "f.tif")), f32)
+    # a PNG written by another encoder (filters 1-4) decodes too
+    PIL.fromarray(rgb).save(tmp_path / "p.png", optimize=True)
+    np.testing.assert_array_equal(read_png(tmp_path / "p.png"), rgb)
+
+
+def test_trainid_palette_matches_reference_table():
+    """cityscapes_labels.py:59-126 (trainId2color is built over reversed(labels): the FIRST label of a train id wins)"""
+    from values_amd.results2d import TRAINID2COLOR, UNLABELED
+    assert len(TRAINID2COLOR) == 25 and TRAINID2COLOR[UNLABELED] == (0, 0, 0)
+    assert TRAINID2COLOR[0] == (128, 64, 128) and TRAINID2COLOR[13] == (0, 0, 142) and TRAINID2COLOR[23] == (84, 86, 22)

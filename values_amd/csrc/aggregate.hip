@@ -124,3 +124,33 @@ extern "C" int vx_sum_thr(const float* map, int64_t n, float thr, double* sums, 
   VX_CHECK_LAUNCH("vx_sum_thr");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Colour rendering of an arg-max mask (Tester.save_prediction, test_2D.py:124-134): label -> RGB through a 256-entry
+// table, pixels of the ignore map first set to `unlabeled`.  Byte gather, HBM-bound.
+__global__ __launch_bounds__(256) void colorize_u8_kernel(const uint8_t* __restrict__ labels, const uint8_t* __restrict__ ignore,
+                                                          int64_t n, const uint8_t* __restrict__ lut, int unlabeled,
+                                                          uint8_t* __restrict__ rgb) {
+  __shared__ uint8_t s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int l = labels[i];
+    if (ignore && ignore[i]) l = unlabeled;
+    rgb[3 * i + 0] = s_lut[3 * l + 0];
+    rgb[3 * i + 1] = s_lut[3 * l + 1];
+    rgb[3 * i + 2] = s_lut[3 * l + 2];
+  }
+}
+
+extern "C" int vx_colorize_u8(const uint8_t* labels, const uint8_t* ignore, int64_t n, const uint8_t* lut, int unlabeled,
+                              uint8_t* rgb, vx_stream_t stream) {
+  if (n < 0 || unlabeled < 0 || unlabeled > 255) VX_FAIL(VX_E_SHAPE, "vx_colorize_u8: n=%lld unlabeled=%d", (long long)n, unlabeled);
+  if (n == 0) return VX_OK;
+  if (!labels || !lut || !rgb) VX_FAIL(VX_E_NULL, "vx_colorize_u8: null pointer");
+  int bx = (int)((n + 255) / 256);
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(colorize_u8_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, labels, ignore, n, lut, unlabeled, rgb);
+  VX_CHECK_LAUNCH("vx_colorize_u8");
+  return VX_OK;
+}

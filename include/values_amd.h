@@ -314,6 +314,17 @@ int64_t vx_soft_metric_workspace_bytes(int C, int R);
 int vx_soft_metric_sums(const float* prob, const uint8_t* gt, int C, int R, int64_t nvox, double* sums, void* workspace,
                         vx_stream_t stream);
 
+/* 2D SSN head (HighResolutionNet.hrnet_ssn, hrnet_module.py:559-595), see accumulate.hip:
+ * vx_ssn2d_lowres: channels-last head outputs at the head's resolution -- mean [B*pix][mean_pitch] (C used),
+ *   factor [B*pix][factor_pitch] (channel r*C + c) -- and eps_w [S][B][R] (nullable: generated) ->
+ *   comb [S][B*pix][C] = mean + sum_r factor_r * eps_w,  expm [B*pix][C] = exp(mean) (nullable).
+ * vx_ssn2d_add_diag: out [B][S][per] += sqrt(diag [B][per] + epsilon) * eps_d [S][B][per] (nullable: generated). */
+int vx_ssn2d_lowres(const float* mean, int mean_pitch, const float* factor, int factor_pitch, const float* eps_w,
+                    uint32_t seed, int B, int64_t pix_per_image, int S, int C, int R, float* comb, float* expm,
+                    vx_stream_t stream);
+int vx_ssn2d_add_diag(float* out, const float* diag, const float* eps_d, uint32_t seed, int S, int B, int64_t per,
+                      float epsilon, vx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and

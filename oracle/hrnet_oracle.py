@@ -103,10 +103,11 @@ def _transition(prev, sd, p, n_prev, n_cur):
     return out
 
 
-def hrnet_forward(extra, sd, x, dropout_masks=None, return_features=False):
+def hrnet_forward(extra, sd, x, dropout_masks=None, return_features=False, ssn=None):
     """extra: the MODEL.EXTRA dict of the yaml (STAGE1..4, FINAL_CONV_KERNEL, optional DROPOUT_FINAL);
     sd: state dict (reference key names) of torch tensors; x (B,Cin,H,W).
-    dropout_masks: None or 4 bool keep-masks (stage-4 outputs) for DROPOUT_FINAL."""
+    dropout_masks: None or 4 bool keep-masks (stage-4 outputs) for DROPOUT_FINAL.
+    ssn: None, or (num_classes, rank, epsilon) -> (loc, cov_diag, cov_factor) of hrnet_ssn (hrnet_module.py:559-595)."""
     size = x.shape[-2:]
     x = F.relu(_bn(_conv(x, sd, "conv1", stride=2), sd, "bn1"))
     x = F.relu(_bn(_conv(x, sd, "conv2", stride=2), sd, "bn2"))
@@ -128,9 +129,26 @@ def hrnet_forward(extra, sd, x, dropout_masks=None, return_features=False):
     h, w = feats[0].shape[-2:]
     ups = [feats[0]] + [F.interpolate(f, size=(h, w), mode="bilinear", align_corners=ALIGN_CORNERS) for f in feats[1:]]
     cat = torch.cat(ups, 1)
+    if ssn is not None:
+        return _ssn_head(cat, sd, size, *ssn)
     y = F.relu(_bn(_conv(cat, sd, "last_layer.0"), sd, "last_layer.1"))
     y = _conv(y, sd, "last_layer.3", pad=1 if extra["FINAL_CONV_KERNEL"] == 3 else 0)
     y = F.interpolate(y, size=size, mode="bilinear", align_corners=ALIGN_CORNERS)
     if return_features:
         return y, ys
     return y
+
+
+def _ssn_head(cat, sd, size, num_classes, rank, epsilon):
+    """hrnet_module.py:559-583: mean and cov_diag BOTH come from last_layer (the reference calls it twice), the factor
+    from cov_factor_conv; each is interpolated to the input size and flattened as the reference does."""
+    def last(x, head):
+        y = F.relu(_bn(_conv(x, sd, head + ".0"), sd, head + ".1"))
+        return _conv(y, sd, head + ".3", pad=0)
+    b = cat.shape[0]
+    mean = F.interpolate(last(cat, "last_layer"), size=size, mode="bilinear", align_corners=ALIGN_CORNERS).reshape(b, -1)
+    diag = F.interpolate(last(cat, "last_layer").exp() + epsilon, size=size, mode="bilinear",
+                         align_corners=ALIGN_CORNERS).reshape(b, -1)
+    fac = F.interpolate(last(cat, "cov_factor_conv"), size=size, mode="bilinear", align_corners=ALIGN_CORNERS)
+    fac = fac.reshape(b, rank, num_classes, -1).flatten(2, 3).transpose(1, 2)
+    return mean, diag, fac

@@ -156,3 +156,35 @@ def test_predict_2d_driver_mc_and_tta_vs_oracle():
     p = torch.softmax(lg[:, 0].double(), 1)
     assert (one["pred_entropy"].double() - (1 - p.max(1)[0])).abs().max().item() < 1e-6
     assert "epistemic_uncertainty" not in one
+
+
+def test_hrnet_ssn_head_matches_reference_fixture():
+    """HighResolutionNet with the SSN head (hrnet_config_ssn.yaml keys; hrnet_module.py:430-453, 559-595): state-dict
+    names, mean, samples with the reference's captured normals (test_2D.py:285-299), and the generated diagonal noise"""
+    from values_amd.formula import formula_tensor
+    from values_amd.hrnet import HighResolutionNet
+    g = load_npz("hrnet_ssn.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    cfg = small_cfg(False)
+    cfg["MODEL"].update({"SSN": True, "SSN_RANK": 10, "SSN_EPS": 1e-5})
+    m = HighResolutionNet(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    x = torch.from_numpy(g["input"]).cuda()
+    dist = m(x)
+    assert np.abs(dist.mean.cpu().numpy() - g["loc"]).max() < 1e-4
+    S, B = g["samples"].shape[:2]
+    eps_d = torch.from_numpy(formula_tensor(g["samples"].shape, tag=int(g["eps_d_tag"]), scale=1.7).astype(np.float32))
+    smp = dist.sample([S], eps_w=torch.from_numpy(g["eps_w"]), eps_d=eps_d)
+    assert tuple(smp.shape) == g["samples"].shape
+    err = np.abs(smp.cpu().numpy() - g["samples"])
+    assert err.max() < 5e-4, err.max()          # samples reach |9|; float32 backbone + exp() of the head
+    assert np.abs(err).mean() < 2e-5
+    # generated normals: unit variance of the diagonal part (rank-0 distribution)
+    d0 = m(x, mean_only=True)
+    z = d0.sample_images(16, seed=3)                                   # (B, 16, C, H, W)
+    mean = d0.mean.reshape(B, 1, 4, 64, 96)
+    zz = ((z - mean) / torch.from_numpy(g["cov_diag"]).cuda().reshape(B, 1, 4, 64, 96).sqrt()).reshape(-1)
+    assert abs(zz.mean().item()) < 0.01 and abs(zz.var().item() - 1.0) < 0.01

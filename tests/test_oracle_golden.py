@@ -263,3 +263,25 @@ def test_metrics_oracle_loss_matches_reference_and_dice_by_definition():
     assert mo.calculate_ged(sm1, np.repeat(a, 2, 0))["ged"] == pytest.approx(0.0)
     anti = np.stack([a, 1 - a], 1).astype(np.float64) * 0.8 + 0.1
     assert mo.calculate_ged(np.repeat(anti, 2, 0), np.repeat(a, 2, 0))["ged"] == pytest.approx(2.0)
+
+
+def test_hrnet_ssn_oracle_matches_reference():
+    """hrnet_ssn (hrnet_module.py:559-595) + distribution.sample (test_2D.py:285-299), normals captured"""
+    import json as _json
+    from oracle.hrnet_oracle import hrnet_forward
+    from oracle.ssn_oracle import lowrank_rsample
+    from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
+    g = load_npz("hrnet_ssn.npz")
+    shapes = _json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    x = torch.from_numpy(g["input"])
+    extra = dict(HRNET_SMALL_EXTRA, DROPOUT_FINAL=False)
+    with torch.no_grad():
+        loc, diag, fac = hrnet_forward(extra, sd, x, ssn=(4, 10, 1e-5))
+    assert np.abs(loc.numpy() - g["loc"]).max() < 2e-5
+    np.testing.assert_allclose(diag.numpy(), g["cov_diag"], rtol=2e-5)
+    assert np.abs(fac[:, ::997].numpy() - g["cov_factor_probe"]).max() < 2e-5
+    S = g["samples"].shape[0]
+    eps_d = formula_tensor(g["samples"].shape, tag=int(g["eps_d_tag"]), scale=1.7).astype(np.float32)
+    smp = lowrank_rsample(loc.numpy(), diag.numpy(), fac.numpy(), g["eps_w"], eps_d)
+    assert np.abs(smp - g["samples"]).max() < 1e-4

@@ -328,6 +328,54 @@ class _Cfg(dict):
         return _Cfg(v) if isinstance(v, dict) else v
 
 
+def gen_hrnet_ssn():
+    """G9 hrnet_ssn.npz: the reference HighResolutionNet with the SSN head (hrnet_module.py:430-453, 559-595; config
+    keys of hrnet_config_ssn.yaml) at the small stage layout, training-mode BN, formula weights; distribution.sample as
+    test_2D.py:285-299 calls it with the normals of LowRankMultivariateNormal.rsample captured."""
+    import copy
+    import torch.distributions.lowrank_multivariate_normal as lrm
+    import uncertainty_modeling.models.hrnet_module as ref_hr
+    from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
+    extra = copy.deepcopy(HRNET_SMALL_EXTRA)
+    extra["DROPOUT_FINAL"] = False
+    ncls, R, S = 4, 10, 2
+    cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False,
+                          "SSN": True, "SSN_RANK": R, "SSN_EPS": 1e-5},
+                "DATASET": {"NUM_CLASSES": ncls}})
+    model = ref_hr.HighResolutionNet(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = formula_state_dict_from_shapes(shapes)
+    full = model.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v).float()
+    model.load_state_dict(full)
+    x = torch.from_numpy(formula_tensor((2, 3, 64, 96), tag=83, scale=1.5)).float()
+    torch.set_grad_enabled(False)
+    dist = model.forward(x)
+    drawn = []
+    orig = lrm._standard_normal
+
+    def fake_normal(shape, dtype, device):
+        t = torch.from_numpy(formula_tensor(tuple(shape), tag=9100 + len(drawn), scale=1.7)).to(dtype)
+        drawn.append(t)
+        return t
+
+    lrm._standard_normal = fake_normal
+    try:
+        samples = dist.sample([S])            # (S, B, C*H*W)
+    finally:
+        lrm._standard_normal = orig
+        torch.set_grad_enabled(True)
+    out = {"input": x.numpy(), "loc": dist.loc.numpy(), "cov_diag": dist.cov_diag.numpy(),
+           "eps_w": drawn[0].numpy().astype(np.float32), "eps_d_tag": np.array(9101), "samples": samples.numpy(),
+           "cov_factor_probe": dist.cov_factor[:, ::997].numpy(),      # every 997th row of (B, C*H*W, R)
+           "shapes_json": np.frombuffer(json.dumps({k: list(v) for k, v in shapes.items()}).encode(), dtype=np.uint8)}
+    assert tuple(drawn[1].shape) == tuple(samples.shape)
+    np.savez_compressed(os.path.join(OUT, "hrnet_ssn.npz"), **out)
+    print("G9 hrnet_ssn.npz", samples.shape, os.path.getsize(os.path.join(OUT, "hrnet_ssn.npz")) / 1e6, "MB; sample range",
+          float(samples.min()), float(samples.max()), "diag range", float(dist.cov_diag.min()), float(dist.cov_diag.max()))
+
+
 def gen_ssn():
     """G7 ssn_16.npz: the reference SsnUNet3D (ssn_unet3D_module.py) + distribution.sample as predict_cases_ssn
     calls it (test_3D.py:373-385), with the standard normals of LowRankMultivariateNormal.rsample replaced by
@@ -456,7 +504,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -475,3 +523,5 @@ if __name__ == "__main__":
         gen_ssn()
     if "metrics" in which:
         gen_metrics()
+    if "hrnet_ssn" in which:
+        gen_hrnet_ssn()

@@ -162,3 +162,82 @@ extern "C" int vx_ssn_sample(const float* head, const float* eps_w, const float*
   VX_CHECK_LAUNCH("vx_ssn_sample");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2D stochastic segmentation head (HighResolutionNet.hrnet_ssn, hrnet_module.py:559-595).  The reference
+// interpolates mean, exp(.)+eps and the rank-R factor to the input size and samples the full-resolution low-rank
+// normal.  Bilinear interpolation is linear, so  interp(mean) + sum_r interp(factor_r) eps_r  =
+// interp(mean + sum_r factor_r eps_r): the rank-R combination is formed at the head's 1/4 resolution (16 x fewer
+// elements, and the (B, C*H*W, R) factor tensor -- 117 MB per 256x478 image at R = 10 -- never exists), then ONE
+// upsample per sample; the diagonal term needs interp(exp(mean)) at full resolution (second kernel).
+//   ssn2d_lowres_kernel : channels-last low-res mean [P][pm], factor [P][pf] (channel r * C + c), eps_w [S][B][R]
+//                         -> comb [S][P][C] = mean + sum_r factor_r * eps_w[s][b][r],  expm [P][C] = exp(mean)
+//   ssn2d_add_diag_kernel: out [S][B][C][HW] += sqrt(diag [B][C][HW] + epsilon) * eps_d (injected or generated)
+__global__ __launch_bounds__(256) void ssn2d_lowres_kernel(const float* __restrict__ mean, int pm, const float* __restrict__ fac,
+                                                           int pf, const float* __restrict__ eps_w, uint32_t seed, int B,
+                                                           int64_t pix_per_image, int S, int C, int R,
+                                                           float* __restrict__ comb, float* __restrict__ expm) {
+  const int64_t P = (int64_t)B * pix_per_image;
+  const int64_t total = P * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const int b = (int)(pix / pix_per_image);
+    const float m = mean[pix * pm + c];
+    if (expm) expm[i] = expf(m);
+    for (int s = 0; s < S; ++s) {
+      float low = 0.f;
+      for (int k = 0; k < R; ++k) {
+        const float ew = eps_w ? eps_w[((size_t)s * B + b) * R + k]
+                               : vx_gauss(seed ^ 0x5bd1e995u, (uint32_t)k, (uint32_t)(b * S + s));
+        low = fmaf(fac[pix * pf + k * C + c], ew, low);
+      }
+      comb[((size_t)s * P + pix) * C + c] = m + low;
+    }
+  }
+}
+
+extern "C" int vx_ssn2d_lowres(const float* mean, int mean_pitch, const float* factor, int factor_pitch, const float* eps_w,
+                               uint32_t seed, int B, int64_t pix_per_image, int S, int C, int R, float* comb, float* expm,
+                               vx_stream_t stream) {
+  if (B <= 0 || pix_per_image <= 0 || S <= 0 || C <= 0 || R < 0 || mean_pitch < C || (R > 0 && factor_pitch < R * C))
+    VX_FAIL(VX_E_SHAPE, "vx_ssn2d_lowres: bad shape");
+  if (!mean || !comb || (R > 0 && !factor)) VX_FAIL(VX_E_NULL, "vx_ssn2d_lowres: null pointer");
+  const int64_t total = (int64_t)B * pix_per_image * C;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(ssn2d_lowres_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, mean, mean_pitch, factor, factor_pitch,
+                     eps_w, seed, B, pix_per_image, S, C, R, comb, expm);
+  VX_CHECK_LAUNCH("vx_ssn2d_lowres");
+  return VX_OK;
+}
+
+__global__ __launch_bounds__(256) void ssn2d_add_diag_kernel(float* __restrict__ out, const float* __restrict__ diag,
+                                                             const float* __restrict__ eps_d, uint32_t seed, int S, int B,
+                                                             int64_t per, float epsilon) {
+  // out [B][S][per] (slot b * S + s), diag [B][per], eps_d [S][B][per]
+  const int64_t total = (int64_t)B * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const int64_t r = i - (int64_t)b * per;
+    const float sd = sqrtf(diag[i] + epsilon);
+    for (int s = 0; s < S; ++s) {
+      const size_t o = ((size_t)b * S + s) * per + r;
+      const float e = eps_d ? eps_d[((size_t)s * B + b) * per + r] : vx_gauss(seed, (uint32_t)r, (uint32_t)(b * S + s));
+      out[o] = out[o] + sd * e;
+    }
+  }
+}
+
+extern "C" int vx_ssn2d_add_diag(float* out, const float* diag, const float* eps_d, uint32_t seed, int S, int B, int64_t per,
+                                 float epsilon, vx_stream_t stream) {
+  if (S <= 0 || B <= 0 || per <= 0 || per >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_ssn2d_add_diag: bad shape");
+  if (!out || !diag) VX_FAIL(VX_E_NULL, "vx_ssn2d_add_diag: null pointer");
+  const int64_t total = (int64_t)B * per;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(ssn2d_add_diag_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, out, diag, eps_d, seed, S, B, per,
+                     epsilon);
+  VX_CHECK_LAUNCH("vx_ssn2d_add_diag");
+  return VX_OK;
+}

@@ -14,7 +14,7 @@ outputs).  DROPOUT_FINAL is F.dropout(0.5, training=True) on the four stage-4 ou
 between MC samples: `forward_samples` runs the backbone once and the head T times (exact).
 
 HIP path limits: every branch width and the stem/bottleneck widths must be multiples of 16 (true for the shipped W48
-config: 48/96/192/384, 64/256, 720); SSN heads are not built.
+config: 48/96/192/384, 64/256, 720).  The SSN head (hrnet_config_ssn.yaml) returns a LowRankNormal2D.
 """
 from __future__ import annotations
 
@@ -132,6 +132,72 @@ class _Act:
         return self.t.shape[3]
 
 
+class LowRankNormal2D:
+    """The distribution object of hrnet_ssn as test_2D.py:285-299 uses it: sample([n_pred]) -> (n, B, C*H*W).
+    The rank-R combination is formed at the head's resolution and upsampled once per sample (bilinear interpolation
+    is linear); the diagonal term uses interp(exp(mean)) + epsilon at full resolution (the reference takes
+    `last_layer(x).exp()` for cov_diag, i.e. the SAME tensor as the mean, hrnet_module.py:560-568)."""
+
+    def __init__(self, mean_lo: "_Act", fac_lo: "_Act", num_classes, rank, epsilon, size, seed):
+        self._m, self._f = mean_lo, fac_lo
+        self.num_classes, self.rank, self.epsilon, self.size = num_classes, rank, epsilon, size
+        self._seed, self._draws = seed, 0
+
+    def _up(self, t: torch.Tensor, pitch, n, out, dst):
+        lib = _lib.load()
+        h0, w0 = self._m.H, self._m.W
+        _lib.check(lib.vx_bilinear_nchw(t.data_ptr(), pitch, n, h0, w0, self.num_classes, self.size[0], self.size[1],
+                                        out.data_ptr(), _lib.ptr(dst), None, _lib.stream_ptr()), "vx_bilinear_nchw")
+
+    @property
+    def mean(self) -> torch.Tensor:
+        B = self._m.N
+        out = torch.empty((B, self.num_classes) + tuple(self.size), dtype=torch.float32, device=self._m.t.device)
+        self._up(self._m.t, self._m.pitch, B, out, None)
+        return out.reshape(B, -1)
+
+    def sample_images(self, n: int, eps_w=None, eps_d=None, seed: Optional[int] = None) -> torch.Tensor:
+        """(B, n, C, H, W) logit samples (per-image stacks, the layout process_output_2d reads)."""
+        lib = _lib.load()
+        dev = self._m.t.device
+        B, C, R = self._m.N, self.num_classes, self.rank
+        h0, w0 = self._m.H, self._m.W
+        H, W = self.size
+        pix = h0 * w0
+        if seed is None:
+            seed = (self._seed * 7919 + self._draws) & 0xFFFFFFFF
+            self._draws += 1
+        hold = []
+        pw = pd = None
+        if eps_w is not None:
+            ew = eps_w.to(device=dev, dtype=torch.float32).contiguous(); hold.append(ew); pw = ew.data_ptr()
+        if eps_d is not None:
+            ed = eps_d.to(device=dev, dtype=torch.float32).contiguous(); hold.append(ed); pd = ed.data_ptr()
+        comb = torch.empty((n, B * pix, C), dtype=torch.float32, device=dev)
+        expm = torch.empty((B * pix, C), dtype=torch.float32, device=dev)
+        _lib.check(lib.vx_ssn2d_lowres(self._m.t.data_ptr(), self._m.pitch, self._f.t.data_ptr() if R else None,
+                                       self._f.pitch if R else 0, pw, int(seed) & 0xFFFFFFFF, B, pix, n, C, R,
+                                       comb.data_ptr(), expm.data_ptr(), _lib.stream_ptr()), "vx_ssn2d_lowres")
+        out = torch.empty((B, n, C, H, W), dtype=torch.float32, device=dev)
+        for s in range(n):   # image b of sample s -> slot b * n + s
+            dst = torch.arange(B, dtype=torch.int32, device=dev) * n + s
+            hold.append(dst)
+            self._up(comb[s], C, B, out, dst)
+        diag = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+        self._up(expm, C, B, diag, None)
+        _lib.check(lib.vx_ssn2d_add_diag(out.data_ptr(), diag.data_ptr(), pd, int(seed) & 0xFFFFFFFF, n, B, C * H * W,
+                                         float(self.epsilon), _lib.stream_ptr()), "vx_ssn2d_add_diag")
+        self._hold = hold + [comb, expm, diag]
+        return out
+
+    def sample(self, sample_shape=(1,), **kw) -> torch.Tensor:
+        n = int(sample_shape[0]) if len(sample_shape) else 1
+        v = self.sample_images(n, **kw)
+        return v.transpose(0, 1).reshape(n, v.shape[0], -1)
+
+    rsample = sample
+
+
 class HighResolutionNet(nn.Module):
     def __init__(self, config, **kwargs):
         super().__init__()
@@ -139,9 +205,10 @@ class HighResolutionNet(nn.Module):
         extra = _cfg_get(model_cfg, "EXTRA")
         if _cfg_get(model_cfg, "ALIGN_CORNERS", False):
             raise NotImplementedError("values_amd.HighResolutionNet: ALIGN_CORNERS must be False (every shipped config)")
-        if _cfg_get(model_cfg, "SSN", False):
-            raise NotImplementedError("values_amd.HighResolutionNet: SSN head has no HIP path yet")
-        self.ssn = False
+        self.ssn = bool(_cfg_get(model_cfg, "SSN", False))          # hrnet_module.py:430-435
+        if self.ssn:
+            self.rank = int(_cfg_get(model_cfg, "SSN_RANK"))
+            self.epsilon = float(_cfg_get(model_cfg, "SSN_EPS"))
         self.num_classes = int(_cfg_get(_cfg_get(config, "DATASET"), "NUM_CLASSES"))
         self.in_channels = int(_cfg_get(model_cfg, "INPUT_CHANNELS", 3))
         self.extra = {k: (dict(v) if hasattr(v, "keys") else v) for k, v in dict(extra).items()}
@@ -170,6 +237,9 @@ class HighResolutionNet(nn.Module):
             raise NotImplementedError("values_amd.HighResolutionNet: FINAL_CONV_KERNEL must be 1 (every shipped config)")
         self.last_layer = nn.Sequential(nn.Conv2d(last, last, 1), nn.BatchNorm2d(last), nn.ReLU(inplace=True),
                                         nn.Conv2d(last, self.num_classes, 1))
+        if self.ssn:   # hrnet_module.py:436-453
+            self.cov_factor_conv = nn.Sequential(nn.Conv2d(last, last, 1), nn.BatchNorm2d(last), nn.ReLU(inplace=True),
+                                                 nn.Conv2d(last, self.num_classes * self.rank, 1))
         for w in [64, last] + [c for si in (1, 2, 3, 4) for c in self.extra[f"STAGE{si}"]["NUM_CHANNELS"]]:
             if w % 16:
                 raise NotImplementedError(f"values_amd.HighResolutionNet: width {w} is not a multiple of 16 (HIP path limit)")
@@ -398,6 +468,26 @@ class HighResolutionNet(nn.Module):
             ys = xs
         return ys
 
+    def _head_lowres(self, feats: List[_Act], drop_mode, seed, masks, device):
+        """concat of the four (dropped, upsampled) stage-4 outputs -> last_layer [and cov_factor_conv] at 1/4 resolution"""
+        n, h0, w0 = feats[0].N, feats[0].H, feats[0].W
+        ctot = sum(f.C for f in feats)
+        cat = _Act(torch.empty((n, h0, w0, ctot), dtype=torch.float32, device=device), ctot)
+        off = 0
+        for k, f in enumerate(feats):
+            drop = None
+            if drop_mode != _lib.VX_DROP_NONE:
+                drop = (drop_mode, seed, k, None if masks is None else masks[k])
+            self._aff(f, out=cat, out_coff=off, size=(h0, w0), drop=drop)
+            off += f.C
+        outs = []
+        for head in (("last_layer",) + (("cov_factor_conv",) if self.ssn else ())):
+            r = self._conv_bn(cat, head + ".0", head + ".1")
+            y = self._aff(r[0], r[1], r[2], relu=True)
+            raw, _, _ = self._conv(y, head + ".3", stats=False)
+            outs.append(raw)
+        return outs
+
     def _head(self, feats: List[_Act], out: torch.Tensor, size, dst, flip, drop_mode, seed, masks):
         lib = _lib.load()
         n, h0, w0 = feats[0].N, feats[0].H, feats[0].W
@@ -462,8 +552,36 @@ class HighResolutionNet(nn.Module):
             return out
         return out.view(n_samples, n, self.num_classes, h, w)
 
-    def forward(self, x: torch.Tensor, mean_only: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, mean_only: bool = False):
+        if self.ssn:
+            return self.forward_ssn(x, mean_only=mean_only)
         return self.forward_samples(x, 1)[0]
+
+    @torch.no_grad()
+    def forward_ssn(self, x: torch.Tensor, mean_only: bool = False, dropout_masks=None, seed: Optional[int] = None):
+        """hrnet_ssn (hrnet_module.py:559-595): backbone + mean / factor heads -> a LowRankNormal2D whose
+        sample([n]) has the reference's shape (n, B, C*H*W)."""
+        _lib.require_gpu()
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        x = x.detach().to(dev, torch.float32)
+        self._pk = self._ensure_packed(dev)
+        self._st = _lib.stream_ptr()
+        self._hold = []
+        n, _, h, w = x.shape
+        feats = self._backbone(x)
+        mode, masks, sd = _lib.VX_DROP_NONE, None, 0
+        if self.dropout_final and dropout_masks is not None:
+            mode = _lib.VX_DROP_MASK
+            masks = [m.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.uint8) for m in dropout_masks]
+            self._hold += masks
+        elif self.dropout_final:
+            mode = _lib.VX_DROP_HASH
+            sd = int(seed) if seed is not None else self.seed * 1000003 + self._calls
+            self._calls += 1
+        mean_lo, fac_lo = self._head_lowres(feats, mode, sd, masks, dev)
+        self._hold_last = self._hold
+        return LowRankNormal2D(mean_lo, fac_lo, self.num_classes, 0 if mean_only else self.rank, self.epsilon, (h, w),
+                               self.seed + self._calls)
 
     def graphed(self, example: torch.Tensor, n_samples: int = 1, seeds: Optional[Sequence[int]] = None):
         """Capture forward_samples for a fixed input shape into one hipGraph (the eager walk is ~1200 launches and

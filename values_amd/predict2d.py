@@ -29,6 +29,9 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
     per_model = len(views) if tta else n_pred
     total = per_model * len(models)
     C = models[0].num_classes
+    if getattr(models[0], "ssn", False) and not tta and len(models) == 1:
+        # test_2D.py:285-299: one forward -> distribution, n_pred draws of it
+        return models[0].forward_ssn(views[0]).sample_images(n_pred, seed=None if seeds is None else seeds[0])
     out = torch.empty((B * total, C, H, W), dtype=torch.float32, device=dev)
     for mi, model in enumerate(models):
         base = mi * per_model

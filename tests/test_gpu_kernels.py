@@ -316,7 +316,7 @@ def test_convT_matches_oracle(cin, cout, shape):
 
 
 @pytest.mark.parametrize("c,shape,pool", [(8, (2, 8, 8, 16), True), (16, (1, 4, 6, 10), True), (8, (1, 3, 5, 7), False),
-                                          (64, (2, 2, 2, 2), True)])
+                                          (64, (2, 2, 2, 2), True), (256, (1, 2, 4, 6), True), (4, (1, 2, 2, 2), False)])
 def test_instnorm_lrelu_drop_pool_matches_oracle(c, shape, pool):
     lib = _lib.load()
     n, d, h, w = shape

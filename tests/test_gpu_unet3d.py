@@ -143,6 +143,26 @@ def test_non_cubic_volume_vs_oracle():
         model(torch.zeros(1, 1, 40, 16, 16).cuda())
 
 
+@pytest.mark.parametrize("f,size,ncls", [(16, 32, 2), (32, 16, 3)])
+def test_wider_networks_vs_oracle(f, size, ncls):
+    """initial_filter_size 16 / 32 (ctor kwarg of unet3D_module.py:8-35): every layer on the 16x16x4 kernels, separate
+    1x1x1 head (no fusion), more classes"""
+    from oracle.unet3d_oracle import unet3d_forward
+    from values_amd import UNet3D
+    sd64 = formula_unet3d_state_dict(seed_tag=3, num_classes=ncls, f=f)
+    sd = {k: torch.from_numpy(v) for k, v in sd64.items()}
+    m = UNet3D(num_classes=ncls, initial_filter_size=f, do_dropout=False)
+    res = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda()
+    x = torch.from_numpy(formula_volume((2, 1, size, size, size), tag=29))
+    with torch.no_grad():
+        ref = unet3d_forward(sd, x, masks=None).numpy()
+        got = m(x.float().cuda()).cpu().numpy()
+    assert got.shape == (2, ncls, size, size, size)
+    assert np.abs(got - ref).max() < LOGIT_TOL
+
+
 def test_full_size_properties_64_T10():
     """BASELINE config C2 (64^3, T=10, hash dropout) -- too big for a float64 CPU oracle inside the suite
     (7 s/pass), so check what must hold at any size."""

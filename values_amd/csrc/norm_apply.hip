@@ -53,16 +53,18 @@ extern "C" int vx_instnorm_finalize(const float* stats_partial, int N, int ntile
 // instruction-bound at 2.7 TB/s.
 struct NormDecode { unsigned per_sample, mPW, mC4, mH; };   // magic 0 = divisor 1
 __device__ __forceinline__ unsigned vx_magic_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
-template <bool POOL>
+// WIDE (pooling with more than 128 channels): the x-neighbour's piece would sit in another wave, so a thread takes
+// BOTH voxels of an x-pair (a row then has W/2 * C/4 work items) and no shuffle is needed.
+template <bool POOL, bool WIDE = false>
 __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a, int x_repeat, NormDecode dc) {
   const int C4 = a.C / 4;
-  const int PW = a.W * C4;  // pieces per row
+  const int PW = (WIDE ? a.W / 2 : a.W) * C4;  // work items per row
   const int n = blockIdx.y;
   const int RH = POOL ? a.H / 2 : a.H;   // rows (row bundles) per z
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < dc.per_sample; i += gridDim.x * 256u) {
     const unsigned row = vx_magic_div(i, dc.mPW);       // i / PW
     const int p = (int)(i - row * (unsigned)PW);
-    const int x = (int)vx_magic_div((unsigned)p, dc.mC4), c = (p - x * C4) * 4;
+    const int xq = (int)vx_magic_div((unsigned)p, dc.mC4), c = (p - xq * C4) * 4;
     const int bz = (int)vx_magic_div(row, dc.mH);       // row / RH
     const int by = (int)(row - (unsigned)bz * (unsigned)RH);
     const int ns = n / x_repeat;
@@ -73,19 +75,21 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
     }
     const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
     f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    constexpr int NR = POOL ? 4 : 1;
+    constexpr int NR = POOL ? (WIDE ? 8 : 4) : 1;
     f32x4 v[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int z = POOL ? bz * 2 + (k >> 1) : bz;
+      const int z = POOL ? bz * 2 + ((k >> 1) & 1) : bz;
       const int y = POOL ? by * 2 + (k & 1) : by;
+      const int x = WIDE ? 2 * xq + (k >> 2) : xq;
       const size_t svox = ((size_t)(ns * a.D + z) * a.H + y) * a.W + x;
       v[k] = *reinterpret_cast<const f32x4*>(a.x + svox * a.x_pitch + c);
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int z = POOL ? bz * 2 + (k >> 1) : bz;
+      const int z = POOL ? bz * 2 + ((k >> 1) & 1) : bz;
       const int y = POOL ? by * 2 + (k & 1) : by;
+      const int x = WIDE ? 2 * xq + (k >> 2) : xq;
       const size_t vox = ((size_t)(n * a.D + z) * a.H + y) * a.W + x;
       f32x4 t = (v[k] - mu) * rs;
       if (a.act == VX_ACT_LRELU) {
@@ -119,7 +123,11 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
         for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], t[j]);
       }
     }
-    if (POOL) {
+    if (POOL && WIDE) {
+      const size_t pv = ((size_t)(n * (a.D / 2) + bz) * (a.H / 2) + by) * (a.W / 2) + xq;
+      *reinterpret_cast<f32x4*>(a.pool_out + pv * a.pool_pitch + c) = mx;
+    } else if (POOL) {
+      const int x = xq;
       // x-neighbour voxel's piece with the same channels sits C4 pieces (= lanes) away
       f32x4 o;
 #pragma unroll
@@ -162,12 +170,13 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
     // the x-pair exchange is a shuffle over C/4 lanes: both voxels of a pair must sit in one wave, i.e. the
     // pieces of a row must not straddle a 64-lane boundary mid-pair: (W*C/4) % (2*C/4) == 0 always holds (W even)
     // and a wave starts at a multiple of 64 pieces, which is a multiple of 2*C/4 when C/4 divides 32
-    if (a.C / 4 > 32 || (32 % (a.C / 4)) != 0)
-      VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: pooling needs C/4 to divide 32 (C = %d)", a.C);
+    if (a.C / 4 <= 32 && (32 % (a.C / 4)) != 0)
+      VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: pooling needs C/4 to divide 32, or C > 128 (C = %d)", a.C);
   }
   {
     const int pool = a.pool_out ? 1 : 0;
-    const int C4 = a.C / 4, PW = a.W * C4, RH = pool ? a.H / 2 : a.H, RD = pool ? a.D / 2 : a.D;
+    const int wide = pool && a.C / 4 > 32;
+    const int C4 = a.C / 4, PW = (wide ? a.W / 2 : a.W) * C4, RH = pool ? a.H / 2 : a.H, RD = pool ? a.D / 2 : a.D;
     const int64_t per = (int64_t)RD * RH * PW;
     const int64_t dmax = PW > RH ? PW : RH;
     if (per * dmax >= (1ll << 32) || a.N > 65535)
@@ -179,7 +188,9 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
     int bx = (int)((per + 255) / 256);
     const int cap = (16384 + a.N - 1) / a.N;
     if (!pool && bx > cap) bx = cap > 0 ? cap : 1;
-    if (pool)
+    if (wide)
+      hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
+    else if (pool)
       hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
     else
       hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);

@@ -163,6 +163,18 @@ def test_wider_networks_vs_oracle(f, size, ncls):
     assert np.abs(got - ref).max() < LOGIT_TOL
 
 
+def test_large_non_cubic_volume_vs_oracle():
+    """a monolithic 96 x 128 x 80 volume (larger than any patch config; many workgroup rounds, ragged last tiles in y)"""
+    from oracle.unet3d_oracle import unet3d_forward
+    sd = formula_sd_torch(seed_tag=4)
+    model = make_model(seed_tag=4, do_dropout=False)
+    x = torch.from_numpy(formula_volume((1, 1, 96, 128, 80), tag=31))
+    with torch.no_grad():
+        ref = unet3d_forward(sd, x, masks=None).numpy()
+        got = model(x.float().cuda()).cpu().numpy()
+    assert np.abs(got - ref).max() < LOGIT_TOL
+
+
 def test_full_size_properties_64_T10():
     """BASELINE config C2 (64^3, T=10, hash dropout) -- too big for a float64 CPU oracle inside the suite
     (7 s/pass), so check what must hold at any size."""

@@ -40,6 +40,16 @@ def from_xblk(buf, half, n, c, d, h, w, xb):
     return ncdhw(buf.reshape(n, d, h, w // xb, 2, xb, c)[:, :, :, :, half].reshape(n, d, h, w, c))
 
 
+@pytest.fixture(params=["split16", "fp32"])
+def conv_mode(request, monkeypatch):
+    """the default split-fp16 schedule (conv3d_s16.hip) and the native-fp32 kernels (VX_CONV_FP32=1)"""
+    if request.param == "fp32":
+        monkeypatch.setenv("VX_CONV_FP32", "1")
+    else:
+        monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    return request.param
+
+
 def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=False, in_pitch=None, out_pitch=None,
              out_coff=0, xblk=0):
     """x (N,Cin,D,H,W) f32 cpu, w torch layout -> (out NCDHW cpu, stats or None)"""
@@ -94,7 +104,7 @@ def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=Fals
     (8, 8, (2, 8, 8, 64)), (16, 8, (1, 4, 4, 32)), (16, 8, (1, 5, 7, 38)),  # x-pair packing, full and ragged tiles
     (8, 8, (1, 3, 3, 7)), (16, 8, (2, 2, 2, 2)),                            # x-pair, odd width / tiny
 ])
-def test_conv3d_k3_matches_oracle(cin, cout, shape):
+def test_conv3d_k3_matches_oracle(cin, cout, shape, conv_mode):
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 101))
     wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 102, scale=(1.0 / (27 * cin)) ** 0.5))
@@ -115,6 +125,7 @@ def test_conv3d_k3_matches_oracle(cin, cout, shape):
 ])
 def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeypatch):
     """the opt-in double-buffered LDS-DMA schedule (conv3d_dma.hip) gives the same result as the default kernel"""
+    monkeypatch.setenv("VX_CONV_FP32", "1")     # the LDS-DMA schedule is a variant of the native-fp32 kernels
     monkeypatch.setenv("VX_CONV_DMA", "1")
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 105))
@@ -132,12 +143,12 @@ def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeyp
 
 @pytest.mark.parametrize("cin,shape,ncls,xb", [(8, (3, 8, 8, 32), 2, 0), (16, (2, 5, 7, 38), 4, 0), (16, (2, 4, 8, 16), 2, 4),
                                                 (8, (1, 3, 3, 7), 3, 0)])
-def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb):
+def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb, monkeypatch):
     """expand_1_2 + final (unet3D_module.py:365) in one launch: bit-identical to vx_conv3d_k3 followed by
     vx_conv1x1_ncdhw, including the slot scatter and the TTA un-flip (test_3D.py:445-447)"""
     lib = _lib.load()
-    if not lib.vx_conv3d_k3_head_fusable(cin, 8):
-        pytest.skip("head fusion not available for this layer")
+    monkeypatch.setenv("VX_CONV_FP32", "1")     # the fused head lives in the 4x4x1 kernel (native-fp32 mode)
+    assert lib.vx_conv3d_k3_head_fusable(cin, 8)
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 161))
     wt = torch.from_numpy(formula_tensor((8, cin, 3, 3, 3), 162, scale=(1.0 / (27 * cin)) ** 0.5))
@@ -183,7 +194,7 @@ def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb):
         assert (got[int(dst[i])].cpu().double() - want).abs().max().item() < 2e-5
 
 
-def test_conv3d_k3_epilogue_act_mask_pitch():
+def test_conv3d_k3_epilogue_act_mask_pitch(conv_mode):
     x = torch.from_numpy(formula_tensor((1, 16, 8, 8, 16), 111))
     wt = torch.from_numpy(formula_tensor((8, 16, 3, 3, 3), 112, scale=0.05))
     b = torch.from_numpy(formula_tensor((8,), 113, scale=0.2))
@@ -201,7 +212,7 @@ def test_conv3d_k3_epilogue_act_mask_pitch():
 
 @pytest.mark.parametrize("c,cout,shape,xb", [(8, 8, (2, 8, 8, 32), 4), (16, 16, (1, 4, 8, 16), 4), (32, 32, (1, 4, 4, 8), 4),
                                              (64, 64, (1, 6, 6, 6), 2), (8, 8, (1, 3, 5, 7), 1), (16, 16, (1, 4, 4, 12), 4)])
-def test_conv3d_k3_reads_xblocked_concat(c, cout, shape, xb):
+def test_conv3d_k3_reads_xblocked_concat(c, cout, shape, xb, conv_mode):
     """decoder conv on cat([up, skip]) (unet3D_module.py:332-334) reading the two halves from the x-blocked buffer"""
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, 2 * c, d, h, w), 115))

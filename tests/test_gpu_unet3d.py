@@ -88,6 +88,26 @@ def test_golden_no_dropout_forward(size):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("size", [16, 32])
+def test_native_fp32_mode_network_vs_golden(size, monkeypatch):
+    """VX_CONV_FP32=1: the native-fp32 matrix kernels (16x16x4 / 4x4x1 with the final 1x1x1 conv fused into
+    expand_1_2) give the same network within tolerance, with the reference's dropout masks and TTA flips"""
+    from values_amd import predict_uncertainty
+    monkeypatch.setenv("VX_CONV_FP32", "1")
+    g = load_npz(f"unet3d_{size}.npz")
+    T = g["logits"].shape[0]
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(g["input"]).cuda()
+    with torch.no_grad():
+        logits = model(x, n_samples=T, dropout_masks=stacked_masks(g, T))
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < LOGIT_TOL
+    ge = load_npz("ensemble_tta_16.npz")
+    models = [make_model(seed_tag=s, do_dropout=False) for s in range(3)]
+    out = predict_uncertainty(models, torch.from_numpy(ge["input"]).cuda(), tta=True, x_noise=torch.from_numpy(ge["input_noise"]).cuda())
+    for k in KEYS:
+        assert np.abs(out[k][0].cpu().numpy() - ge[k]).max() < MAP_TOL, k
+
+
 def test_golden_ensemble_and_tta_order():
     """Config C3 ordering (members) and the 16-view TTA of test_3D.py:426-456, against the buffer the
     reference's own concat_data filled."""

@@ -42,6 +42,10 @@ int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s);  // conv3d_dma
 bool vx_conv3d_c8_applies(int Cin, int Cout);
 int vx_pack_conv3d_k3_c8(const float* w_torch, float* w_packed, int Cin, hipStream_t s);
 int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_t s);
+// conv3d_s16.hip: split-fp16 schedule for the Cout >= 16 layers
+int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout);
+int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
+int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s);
 
 struct ConvKArgs {
   vx_conv3d_args a;
@@ -451,11 +455,18 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
 // weight packing: torch (Cout, Cin, 3,3,3) -> [rowgroup][chunk][tap][nt][lane 64][CPL]
 //   plain : row = cout, tap = (kz,ky,kx)                       (NT fixed per (Cin, Cout) by conv_config())
 //   x-pair: row = dx*8 + cout, tap = (kz,ky,ix), value W[kx = ix - dx] or 0      (Cout == 8)
-struct ConvCfg { int CB, NT, XP, C8; };
+struct ConvCfg { int CB, NT, XP, C8, S16; };
 static inline ConvCfg conv_config(int Cin, int Cout) {
   ConvCfg c;
-  static const bool no_c8 = getenv("VX_CONV_NO_C8") != nullptr;   // A/B knob: x-pair kernel for every Cout = 8 layer
-  c.C8 = (!no_c8 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
+  // Default: the split-fp16 schedule (conv3d_s16.hip) for every layer -- faster AND closer to float64 than the
+  // native fp32 matrix instruction.  VX_CONV_FP32=1 selects the native-fp32 kernels of this
+  // file / conv3d_c8.hip (an exact fmaf chain; the A/B baseline), VX_CONV_FP32=2 keeps fp32 only for Cout = 8.
+  // (read per call, not cached: packing and launch of a layer must simply see the same environment)
+  const char* ef = getenv("VX_CONV_FP32");
+  const int fp32 = ef ? atoi(ef) : 0;
+  const bool no_c8 = getenv("VX_CONV_NO_C8") != nullptr;   // fp32 mode: x-pair kernel instead of the 4x4x1 one
+  c.S16 = (fp32 == 0 || (fp32 == 2 && Cout != 8)) ? 1 : 0;
+  c.C8 = (!c.S16 && !no_c8 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
   c.XP = (Cout == 8) ? 1 : 0;
   // x-pair layers always go in chunks of 8 channels (same speed as one chunk of 16 here, and the packing the
@@ -496,6 +507,7 @@ extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return -1;
   ConvCfg c = conv_config(Cin, Cout);
   if (c.C8) return (int64_t)27 * Cin * 8;
+  if (c.S16) return vx_conv3d_s16_packed_floats(Cin, Cout);
   if (c.XP) return (int64_t)16 * Cin * 36;
   return (int64_t)conv_rows_padded(Cout, c.NT) * Cin * 27;
 }
@@ -506,6 +518,7 @@ extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin,
   if (total < 0) VX_FAIL(VX_E_SHAPE, "vx_pack_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", Cin, Cout);
   ConvCfg c = conv_config(Cin, Cout);
   if (c.C8) return vx_pack_conv3d_k3_c8(w_torch, w_packed, Cin, (hipStream_t)stream);
+  if (c.S16) return vx_pack_conv3d_k3_s16(w_torch, w_packed, Cin, Cout, (hipStream_t)stream);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv3d_k3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin,
@@ -529,7 +542,7 @@ static inline TileCfg tile_config(int W, int XP) {
 }
 
 static int conv_tiles(int D, int H, int W, int Cout) {
-  TileCfg t = tile_config(W, Cout == 8);
+  TileCfg t = tile_config(W, Cout == 8 && !conv_config(8, 8).S16);
   return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
 }
 extern "C" int vx_conv3d_k3_tiles(int D, int H, int W) {
@@ -639,6 +652,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
 #endif
   hipStream_t s = (hipStream_t)stream;
   if (c.C8) return vx_conv3d_k3_c8(a, t.TXV, t.TY, t.TZ, s);
+  if (c.S16) return vx_conv3d_k3_s16(a, s);
   {
     const int rc = vx_conv3d_k3_try_dma(a, s);   // opt-in (VX_CONV_DMA=1) LDS-DMA schedule; 1 = not taken
     if (rc != 1) return rc;

@@ -1,0 +1,487 @@
+// K1, split-precision schedule: the 3x3x3 convolution of conv3d_mfma.hip with every fp32 product evaluated on the
+// fp16 matrix cores by operand splitting (Ootomo & Yokota's scheme for SGEMM on tensor cores, here on CDNA4):
+//
+//     x = hi + lo * 2^-11,   hi = fp16(x),  lo = fp16((x - hi) * 2^11)         (the residual is exact in fp32)
+//     a * b = hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) + 2^-22 lo_a lo_b      (last term <= 2^-24 |a b|: dropped)
+//
+// Three v_mfma_f32_16x16x32_f16 (products exact, fp32 accumulation; a main and a cross accumulator) replace the
+// eight v_mfma_f32_16x16x4_f32 of one K = 32 step.  Measured (tools/micro/split_f16.hip, K = 432 dot products of
+// conv-like data against float64): max error 5.9e-7 / rms 9.1e-8 for this scheme, 1.1e-6 / 1.6e-7 for the native
+// fp32 matrix instruction (which rounds after every K = 4), at 650 vs 155 TFLOP/s of fp32-equivalent work with
+// operands in registers.  Activations and weights stay float32 in HBM; the split happens on the way into LDS
+// (activations) and at pack time (weights).  Range: |x| < 65504 (fp16); hi is clamped there.
+//
+// Everything around the MFMA loop -- work items, register prefetch with out-of-range steering, tile shapes,
+// x-blocked concat input, XCD-aware tile order, the fused bias / activation / dropout / statistics epilogue and its
+// store layout (the D layout of 16x16x32 is that of 16x16x4) -- is conv3d_mfma.hip's.
+//
+//   K = 32 step:  CB = 16: two taps x 16 channels,  lane k-group kg = 2 * (tap & 1) + (channel >> 3)
+//                 CB =  8: four taps x 8 channels,   kg = tap & 3                         (27 taps padded with zero weights)
+//   LDS image:    hi plane and lo plane, each [channel octet][halo position][8 halves]; a lane's B fragment for a
+//                 step is one ds_read_b128 per plane at (position of its column + its k-group's tap offset).
+//   weights:      [chunk][step][row tile][hi | lo][lane][8 halves], one ds_read_b128 per (step, row tile, plane).
+// The loop is LDS-bandwidth-bound ((2 NT + 2 R) KiB per 3 R NT MFMAs), not issue- or power-bound.
+#include "common.h"
+#include <stdlib.h>
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define VX_NUMREC 0xFFFFF000u
+#define VX_OOB 0xFFFFF800u
+
+struct ConvSArgs {
+  vx_conv3d_args a;
+  int tiles_x, tiles_y, tiles_z, nchunks;
+  unsigned mx, my, mz;
+  int no_xcd;
+};
+
+__device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = fminf(fmaxf(v[j], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)x;
+    hi[j] = h;
+    lo[j] = (_Float16)((v[j] - (float)h) * 2048.f);
+  }
+}
+
+template <int CB, int NT, int TX, int TY, int TZ, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
+  constexpr int NTH = 64 * NW;
+  constexpr int NVT = TX * TY * TZ / 16;
+  constexpr int R = NVT / NW;
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  constexpr int NHALO = HX * HY * HZ;
+  constexpr int OCT = CB / 8;                      // channel octets per chunk
+  constexpr int TPS = 32 / CB;                     // taps per K = 32 step
+  constexpr int NSTEP = (27 + TPS - 1) / TPS;
+  constexpr int PLANE = ((NHALO + 15) / 16) * 16;  // positions per octet plane (multiple of 16: the two octets a
+                                                   // 16-lane read group mixes then fall on complementary slots)
+  constexpr int IMG_H = OCT * PLANE * 8;           // halves per precision plane
+  constexpr int IN_BYTES = 2 * IMG_H * 2;
+  constexpr int W_H = NSTEP * NT * 2 * 64 * 8;     // halves of one chunk's weights
+  constexpr int Q = CB / 4;                        // 16-byte fp32 pieces per voxel
+  constexpr int IN_IT = (NHALO * Q + NTH - 1) / NTH;
+  constexpr int W_IT = (W_H / 8 + NTH - 1) / NTH;  // 16-byte pieces per thread
+  static_assert(NVT % NW == 0 && IN_IT <= 16, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* s_hi = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* s_lo = s_hi + IMG_H;
+  _Float16* s_w = s_hi + 2 * IMG_H;
+  float* s_red = reinterpret_cast<float*>(smem_raw + IN_BYTES + W_H * 2);
+
+  const vx_conv3d_args& a = ka.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int m = lane & 15;
+  const int g = lane >> 4;      // k-group of the operands; D rows 4g..4g+3
+  const int cg = blockIdx.y;
+  const int ntiles = ka.tiles_x * ka.tiles_y * ka.tiles_z;
+  const int total = ntiles * a.N;
+  const int lastx = (ka.tiles_x - 1) * TX, lasty = (ka.tiles_y - 1) * TY, lastz = (ka.tiles_z - 1) * TZ;
+
+  // ---- per-lane constants of the compute phase and the epilogue ----
+  int vbase[R];      // halo position of the lane's column at tap (0,0,0)
+  unsigned ovoff[R], eoff[R];
+  unsigned obad_xhi = 0, obad_yhi = 0, obad_zhi = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int v = (wave * R + r) * 16 + m;
+    const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
+    vbase[r] = (lz * HY + ly) * HX + lx;
+    const int oc = g * 4;
+    const int ovox = (lz * a.H + ly) * a.W + lx;
+    ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * 4);
+    eoff[r] = (unsigned)(ovox * a.Cout + oc);
+    if (lx >= a.W - lastx) obad_xhi |= 1u << r;
+    if (ly >= a.H - lasty) obad_yhi |= 1u << r;
+    if (lz >= a.D - lastz) obad_zhi |= 1u << r;
+  }
+  // this lane's (tap, octet) of every step, as a position offset into a precision plane (padding taps re-read
+  // tap 26: their weights are zero, but the data must be finite)
+  int toff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap = CB == 16 ? 2 * s + (g >> 1) : 4 * s + g;
+    if (tap > 26) tap = 26;
+    const int oct = CB == 16 ? (g & 1) : 0;
+    toff[s] = oct * PLANE + ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+  }
+
+  // ---- per-thread staging pattern ----
+  const int xb = a.in_xblk;
+  const int Csrc = xb ? a.Cin / 2 : a.Cin;
+  const int voxf = xb ? 2 * Csrc : a.in_pitch;
+  const int rowf = a.W * voxf;
+  const int biasf = (a.H + 1) * rowf + 4 * voxf;
+  unsigned voff[IN_IT];
+  int ldst[IN_IT];   // halves index of the piece within a precision plane
+  unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0, ibad_zlo = 0, ibad_zhi = 0;
+#pragma unroll
+  for (int it = 0; it < IN_IT; ++it) {
+    const int idx = tid + it * NTH;
+    const int vox = idx / Q, q = idx % Q;
+    const int hx = vox % HX, hy = (vox / HX) % HY, hz = vox / (HX * HY);
+    const int dxr = hx - 1, dyr = hy - 1, dzr = hz - 1;
+    int xf;
+    if (xb) {
+      const int blk = dxr >= 0 ? dxr / xb : -((-dxr + xb - 1) / xb);
+      const int rem = dxr - blk * xb;
+      const int sl = (Csrc < CB) ? (4 * q) / Csrc : 0;
+      const int cs = (Csrc < CB) ? (4 * q) % Csrc : 4 * q;
+      xf = (blk * 2 + sl) * xb * Csrc + rem * Csrc + cs;
+    } else {
+      xf = dxr * a.in_pitch + 4 * q;
+    }
+    voff[it] = (unsigned)(((dzr * a.H + dyr) * rowf + xf + biasf) * 4);
+    ldst[it] = ((q >> 1) * PLANE + (hz * HY + hy) * HX + hx) * 8 + (q & 1) * 4;
+    if (idx >= NHALO * Q) ibad_always |= 1u << it;
+    if (dxr < 0) ibad_xlo |= 1u << it;
+    if (dxr >= a.W - lastx) ibad_xhi |= 1u << it;
+    if (dyr < 0) ibad_ylo |= 1u << it;
+    if (dyr >= a.H - lasty) ibad_yhi |= 1u << it;
+    if (dzr < 0) ibad_zlo |= 1u << it;
+    if (dzr >= a.D - lastz) ibad_zhi |= 1u << it;
+  }
+  const size_t in_sample = (size_t)a.D * a.H * rowf;
+  const size_t out_sample = (size_t)a.D * a.H * a.W * a.out_pitch;
+  const int cper = xb && Csrc >= CB ? Csrc / CB : 0;
+
+  auto decode = [&](int tile_lin, int& n, int& tx, int& ty, int& tz) {
+    unsigned t = (unsigned)tile_lin, q;
+    q = ka.tiles_x == 1 ? t : __umulhi(t, ka.mx); tx = (int)(t - q * ka.tiles_x); t = q;
+    q = ka.tiles_y == 1 ? t : __umulhi(t, ka.my); ty = (int)(t - q * ka.tiles_y); t = q;
+    q = ka.tiles_z == 1 ? t : __umulhi(t, ka.mz); tz = (int)(t - q * ka.tiles_z); n = (int)q;
+  };
+
+  const f32x4* w_cg = reinterpret_cast<const f32x4*>(a.w_packed) + (size_t)cg * ka.nchunks * (W_H / 8);
+  f32x4 ibuf[IN_IT];
+  f32x4 wbuf[W_IT];
+  const bool w_resident = ka.nchunks == 1;
+  bool w_fresh = true;
+
+  auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w) {
+    int n, tx, ty, tz;
+    decode(tile_lin, n, tx, ty, tz);
+    unsigned bad = ibad_always;
+    if (tx == 0) bad |= ibad_xlo;
+    if (tx == ka.tiles_x - 1) bad |= ibad_xhi;
+    if (ty == 0) bad |= ibad_ylo;
+    if (ty == ka.tiles_y - 1) bad |= ibad_yhi;
+    if (tz == 0) bad |= ibad_zlo;
+    if (tz == ka.tiles_z - 1) bad |= ibad_zhi;
+    if (!have) bad = 0xFFFFFFFFu;
+    int coff;
+    if (!xb) coff = chunk * CB;
+    else if (cper) coff = (chunk / cper) * xb * Csrc + (chunk % cper) * CB;
+    else coff = 0;
+    const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TX * voxf + coff) * 4);
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
+      ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
+    }
+    const f32x4* src = w_cg + (size_t)chunk * (W_H / 8);
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int idx = tid + it * NTH;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (have && with_w && idx < W_H / 8) v = src[idx];
+      wbuf[it] = v;
+    }
+  };
+  auto commit = [&](bool with_w) {
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      if (tid + it * NTH < NHALO * Q) {
+        f16x4 hi, lo;
+        vx_split4(ibuf[it], hi, lo);
+        *reinterpret_cast<f16x4*>(s_hi + ldst[it]) = hi;
+        *reinterpret_cast<f16x4*>(s_lo + ldst[it]) = lo;
+      }
+    }
+    if (with_w) {
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it) {
+        const int idx = tid + it * NTH;
+        if (idx < W_H / 8) reinterpret_cast<f32x4*>(s_w)[idx] = wbuf[it];
+      }
+    }
+  };
+
+  f32x4 bias4[NT];
+  bool cvalid[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (cg * NT + nt) * 16 + g * 4;
+    cvalid[nt] = co < a.Cout;
+    bias4[nt] = cvalid[nt] ? *reinterpret_cast<const f32x4*>(a.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  int tile_lin = blockIdx.x, chunk = 0;
+  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  bool have = tile_lin < total;
+  prefetch(tile_lin, 0, have, true);
+  f32x4 acc[R][NT], accx[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  while (have) {
+    __syncthreads();
+    commit(w_fresh);
+    __syncthreads();
+    w_fresh = !w_resident;
+    int ntile = tile_lin, nchunk = chunk + 1;
+    if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
+    const bool nhave = ntile < total;
+    prefetch(ntile, nchunk, nhave, !w_resident);
+
+    {
+      // ---- NSTEP steps x 3 x R x NT MFMAs; fragments of step s + 1 are read before the MFMAs of step s ----
+      f16x8 ah[2][NT], al[2][NT], bh[2][R], bl[2][R];
+      auto load_step = [&](int s, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const _Float16* wp = s_w + (((s * NT + nt) * 2) * 64 + lane) * 8;
+          ah[slot][nt] = *reinterpret_cast<const f16x8*>(wp);
+          al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int p = (vbase[r] + toff[s]) * 8;
+          bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
+          bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
+        }
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+        const int cur = s & 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bh[cur][r], acc[r][nt], 0, 0, 0);
+            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bl[cur][r], accx[r][nt], 0, 0, 0);
+            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][nt], bh[cur][r], accx[r][nt], 0, 0, 0);
+          }
+      }
+    }
+
+    if (chunk == ka.nchunks - 1) {
+      // ---- epilogue (conv3d_mfma.hip) ----
+      int n, tx, ty, tz;
+      decode(tile_lin, n, tx, ty, tz);
+      unsigned obad = 0;
+      if (tx == ka.tiles_x - 1) obad |= obad_xhi;
+      if (ty == ka.tiles_y - 1) obad |= obad_yhi;
+      if (tz == ka.tiles_z - 1) obad |= obad_zhi;
+      const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TX);
+      const unsigned osoff = vox0 * (unsigned)a.out_pitch * 4u;
+      const unsigned e0 = vox0 * (unsigned)a.Cout;
+      const __amdgpu_buffer_rsrc_t osrd =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
+      const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+
+      float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
+
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned cshift = (unsigned)((cg * NT + nt) * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
+          f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
+          if (a.stats_partial && !bad) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
+          }
+          if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.01f * v[j]);
+          } else if (a.act == VX_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          const unsigned e = e0 + eoff[r] + cshift;
+          if (a.drop_mode == VX_DROP_HASH) {
+            const uint32_t bits = vx_drop_bits4(dkey, e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+          } else if (a.drop_mode == VX_DROP_MASK) {
+            uint32_t mk = 0;
+            if (!bad) mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (size_t)n * a.D * a.H * a.W * a.Cout + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+          }
+          const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
+          // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 3" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+
+      if (a.stats_partial) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float s = ssum[nt][j], q = ssq[nt][j];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+              s += __shfl_xor(s, off, 64);
+              q += __shfl_xor(q, off, 64);
+            }
+            if (m == 0) {
+              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
+              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
+            }
+          }
+        __syncthreads();
+        if (tid < NT * 16) {
+          const int nt = tid / 16, c = tid % 16;
+          const int co = (cg * NT + nt) * 16 + c;
+          if (co < a.Cout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+              s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
+              q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+            }
+            const int tile = tile_lin - n * ntiles;
+            float* dst = a.stats_partial + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
+            dst[0] = s;
+            dst[1] = q;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+    tile_lin = ntile; chunk = nchunk; have = nhave;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: torch (Cout, Cin, 3,3,3) fp32 -> [rowgroup][chunk][step][nt][hi | lo][lane 64][8 halves]
+__global__ void pack_conv3d_k3_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int CB,
+                                          int NT, int64_t total) {
+  const int TPS = 32 / CB, NSTEP = (27 + TPS - 1) / TPS, nchunks = Cin / CB;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int j = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int hl = r % 2; r /= 2;
+    const int nt = r % NT; r /= NT;
+    const int step = r % NSTEP; r /= NSTEP;
+    const int chunk = r % nchunks; r /= nchunks;
+    const int rgrp = (int)r;
+    const int row = (rgrp * NT + nt) * 16 + (lane & 15);
+    const int kg = lane >> 4;
+    const int tap = CB == 16 ? 2 * step + (kg >> 1) : 4 * step + kg;
+    const int ci = chunk * CB + (CB == 16 ? 8 * (kg & 1) + j : j);
+    float v = 0.f;
+    if (row < Cout && tap < 27) v = w[((size_t)row * Cin + ci) * 27 + tap];
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    out[i] = hl == 0 ? h : (_Float16)((v - (float)h) * 2048.f);
+  }
+}
+
+struct S16Cfg { int CB, NT; };
+static inline S16Cfg s16_config(int Cin, int Cout) {
+  S16Cfg c;
+  c.NT = (Cout % 32 == 0) ? 2 : 1;
+  c.CB = (Cin % 16 == 0) ? 16 : 8;
+  return c;
+}
+static inline int s16_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
+
+int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout) {
+  const S16Cfg c = s16_config(Cin, Cout);
+  const int TPS = 32 / c.CB, NSTEP = (27 + TPS - 1) / TPS;
+  const int64_t halves = (int64_t)(s16_rows_padded(Cout, c.NT) / 16) * (Cin / c.CB) * NSTEP * 2 * 64 * 8;
+  return halves / 2;
+}
+
+int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s) {
+  const S16Cfg c = s16_config(Cin, Cout);
+  const int64_t total = vx_conv3d_s16_packed_floats(Cin, Cout) * 2;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_conv3d_k3_s16_kernel, dim3(blocks), dim3(256), 0, s, w_torch, reinterpret_cast<_Float16*>(w_packed),
+                     Cin, Cout, c.CB, c.NT, total);
+  VX_CHECK_LAUNCH("vx_pack_conv3d_k3(s16)");
+  return VX_OK;
+}
+
+template <int CB, int NT, int TX, int TY, int TZ, int NW>
+static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
+  constexpr int NHALO = (TX + 2) * (TY + 2) * (TZ + 2);
+  constexpr int PLANE = ((NHALO + 15) / 16) * 16;
+  constexpr int TPS = 32 / CB, NSTEP = (27 + TPS - 1) / TPS;
+  constexpr size_t lds = (size_t)2 * (CB / 8) * PLANE * 8 * 2 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)NW * NT * 16 * 2 * 4;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(s16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  const vx_conv3d_args& a = ka.a;
+  const int total_tiles = ka.tiles_x * ka.tiles_y * ka.tiles_z * a.N;
+  const int ygroups = (a.Cout + 16 * NT - 1) / (16 * NT);
+  int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  if (per_cu * NW > 16) per_cu = 16 / NW > 0 ? 16 / NW : 1;
+  if (const char* e = getenv("VX_S16_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  int gx = (256 * per_cu + ygroups - 1) / ygroups;
+  if (gx > total_tiles) gx = total_tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(64 * NW), lds, s, ka);
+  VX_CHECK_LAUNCH("vx_conv3d_k3(s16)");
+  return VX_OK;
+}
+
+template <int CB, int NT>
+static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
+  if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8>(ka, s);
+  if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8>(ka, s);
+  return launch_s16<CB, NT, 4, 4, 4, 4>(ka, s);
+}
+
+// tile = the plain tiling of conv3d_mfma.hip (tx = 16 / 8 / 4 by W)
+int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
+  const S16Cfg c = s16_config(a.Cin, a.Cout);
+  const int tx = a.W >= 16 ? 16 : (a.W >= 8 ? 8 : 4);
+  const int ty = tx == 8 ? 8 : 4, tz = 4;
+  ConvSArgs ka;
+  ka.a = a;
+  ka.tiles_x = (a.W + tx - 1) / tx; ka.tiles_y = (a.H + ty - 1) / ty; ka.tiles_z = (a.D + tz - 1) / tz;
+  ka.nchunks = a.Cin / c.CB;
+  ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
+  ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
+  ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
+  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
+  if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1>(ka, tx, s);
+  if (c.CB == 16 && c.NT == 2) return dispatch_s16<16, 2>(ka, tx, s);
+  if (c.CB == 8 && c.NT == 1) return dispatch_s16<8, 1>(ka, tx, s);
+  return dispatch_s16<8, 2>(ka, tx, s);
+}

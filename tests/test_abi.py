@@ -62,8 +62,9 @@ def test_host_only_queries(lib):
     # default = split-fp16 schedule: [row groups][chunks of CB][K=32 steps][NT][hi|lo][64 lanes][8 halves], in floats
     def s16(cin, cout):
         nt = 2 if cout % 32 == 0 else 1
-        cb = 16 if cin % 16 == 0 else 8
-        steps = -(-27 // (32 // cb))
+        xp = cout == 8                      # x-pair packing: chunks of 8 channels, 9 (kz, ky) steps
+        cb = 8 if xp else (16 if cin % 16 == 0 else 8)
+        steps = 9 if xp else -(-27 // (32 // cb))
         rows = -(-cout // (16 * nt)) * 16 * nt
         return (rows // 16) * (cin // cb) * steps * 2 * 64 * 8 // 2
     for cin, cout in ((16, 8), (24, 8), (16, 16), (32, 32), (128, 64)):
@@ -80,7 +81,7 @@ def test_host_only_queries(lib):
     assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1
     assert lib.vx_convT_k2s2_packed_floats(16, 8) == 16 * 8 * 8
     assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
-    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 4 * 16 * 16
+    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 16 * 16  # x-pair tiles are 32 voxels wide
     assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 

@@ -542,7 +542,8 @@ static inline TileCfg tile_config(int W, int XP) {
 }
 
 static int conv_tiles(int D, int H, int W, int Cout) {
-  TileCfg t = tile_config(W, Cout == 8 && !conv_config(8, 8).S16);
+  // Cout = 8 layers use the x-pair tiling (32 voxels wide) in every mode but the split-fp16 A/B knob VX_S16_NO_XP
+  TileCfg t = tile_config(W, Cout == 8 && !(conv_config(8, 8).S16 && getenv("VX_S16_NO_XP")));
   return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
 }
 extern "C" int vx_conv3d_k3_tiles(int D, int H, int W) {

@@ -36,6 +36,7 @@ struct ConvSArgs {
   int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;
   int no_xcd;
+  int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
 };
 
 __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
@@ -44,23 +45,32 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     const float x = fminf(fmaxf(v[j], -65504.f), 65504.f);
     const _Float16 h = (_Float16)x;
     hi[j] = h;
-    lo[j] = (_Float16)((v[j] - (float)h) * 2048.f);
+    lo[j] = (_Float16)fminf(fmaxf((v[j] - (float)h) * 2048.f, -65504.f), 65504.f);   // (finite even out of range)
   }
 }
 
-template <int CB, int NT, int TX, int TY, int TZ, int NW>
+// XP (Cout == 8, CB == 8): x-pair packing as in conv3d_mfma.hip -- rows = (dx, cout), columns = voxel pairs
+// (x = 2p, 2p + 1), a K = 32 step = one (kz, ky) row with the four x-offsets ix = 0..3 as the four k-groups
+// (weight W[kx = ix - dx], zero outside 0..2): 9 steps for two voxels per column instead of 2 x 7, all 16 rows and
+// all four lane groups of the epilogue useful.  Even / odd x live in two parity planes so that columns stay
+// consecutive positions.
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
+  constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
   constexpr int NVT = TX * TY * TZ / 16;
   constexpr int R = NVT / NW;
-  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  constexpr int HX = TXV + 2, HY = TY + 2, HZ = TZ + 2;
   constexpr int NHALO = HX * HY * HZ;
+  constexpr int HXP = XP ? HX / 2 : HX;            // positions per x-row (per parity plane)
   constexpr int OCT = CB / 8;                      // channel octets per chunk
   constexpr int TPS = 32 / CB;                     // taps per K = 32 step
-  constexpr int NSTEP = (27 + TPS - 1) / TPS;
-  constexpr int PLANE = ((NHALO + 15) / 16) * 16;  // positions per octet plane (multiple of 16: the two octets a
-                                                   // 16-lane read group mixes then fall on complementary slots)
-  constexpr int IMG_H = OCT * PLANE * 8;           // halves per precision plane
+  constexpr int NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
+  // positions per plane (octet plane, or parity plane for x-pair): a multiple of 16, so that the two planes a
+  // 16-lane read group mixes fall on complementary slots
+  constexpr int PLANE = (((XP ? HXP * HY * HZ : NHALO) + 15) / 16) * 16;
+  constexpr int IMG_H = (XP ? 2 : OCT) * PLANE * 8;  // halves per precision plane
+  static_assert(!XP || (CB == 8 && NT == 1), "x-pair packing is for Cout == 8 in chunks of 8 channels");
   constexpr int IN_BYTES = 2 * IMG_H * 2;
   constexpr int W_H = NSTEP * NT * 2 * 64 * 8;     // halves of one chunk's weights
   constexpr int Q = CB / 4;                        // 16-byte fp32 pieces per voxel
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   const int cg = blockIdx.y;
   const int ntiles = ka.tiles_x * ka.tiles_y * ka.tiles_z;
   const int total = ntiles * a.N;
-  const int lastx = (ka.tiles_x - 1) * TX, lasty = (ka.tiles_y - 1) * TY, lastz = (ka.tiles_z - 1) * TZ;
+  const int lastx = (ka.tiles_x - 1) * TXV, lasty = (ka.tiles_y - 1) * TY, lastz = (ka.tiles_z - 1) * TZ;
 
   // ---- per-lane constants of the compute phase and the epilogue ----
   int vbase[R];      // halo position of the lane's column at tap (0,0,0)
@@ -92,9 +102,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int v = (wave * R + r) * 16 + m;
-    const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
-    vbase[r] = (lz * HY + ly) * HX + lx;
-    const int oc = g * 4;
+    const int cx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
+    vbase[r] = (lz * HY + ly) * HXP + cx;
+    const int lx = XP ? 2 * cx + (g >> 1) : cx;            // voxel this lane stores
+    const int oc = XP ? (g & 1) * 4 : g * 4;               // its first channel (within row tile 0)
     const int ovox = (lz * a.H + ly) * a.W + lx;
     ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * 4);
     eoff[r] = (unsigned)(ovox * a.Cout + oc);
@@ -107,10 +118,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   int toff[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    int tap = CB == 16 ? 2 * s + (g >> 1) : 4 * s + g;
-    if (tap > 26) tap = 26;
-    const int oct = CB == 16 ? (g & 1) : 0;
-    toff[s] = oct * PLANE + ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+    if (XP) {   // step = (kz, ky) row, k-group = x-offset ix: voxel 2p + ix -> parity ix & 1, position p + (ix >> 1)
+      toff[s] = (g & 1) * PLANE + ((s / 3) * HY + s % 3) * HXP + (g >> 1);
+    } else {
+      int tap = CB == 16 ? 2 * s + (g >> 1) : 4 * s + g;
+      if (tap > 26) tap = 26;
+      const int oct = CB == 16 ? (g & 1) : 0;
+      toff[s] = oct * PLANE + ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+    }
   }
 
   // ---- per-thread staging pattern ----
@@ -139,7 +154,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       xf = dxr * a.in_pitch + 4 * q;
     }
     voff[it] = (unsigned)(((dzr * a.H + dyr) * rowf + xf + biasf) * 4);
-    ldst[it] = ((q >> 1) * PLANE + (hz * HY + hy) * HX + hx) * 8 + (q & 1) * 4;
+    ldst[it] = XP ? ((hx & 1) * PLANE + (hz * HY + hy) * HXP + (hx >> 1)) * 8 + (q & 1) * 4
+                  : ((q >> 1) * PLANE + (hz * HY + hy) * HX + hx) * 8 + (q & 1) * 4;
     if (idx >= NHALO * Q) ibad_always |= 1u << it;
     if (dxr < 0) ibad_xlo |= 1u << it;
     if (dxr >= a.W - lastx) ibad_xhi |= 1u << it;
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     if (!xb) coff = chunk * CB;
     else if (cper) coff = (chunk / cper) * xb * Csrc + (chunk % cper) * CB;
     else coff = 0;
-    const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TX * voxf + coff) * 4);
+    const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TXV * voxf + coff) * 4);
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   bool cvalid[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int co = (cg * NT + nt) * 16 + g * 4;
+    const int co = XP ? (g & 1) * 4 : (cg * NT + nt) * 16 + g * 4;
     cvalid[nt] = co < a.Cout;
     bias4[nt] = cvalid[nt] ? *reinterpret_cast<const f32x4*>(a.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -236,14 +252,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   while (have) {
-    __syncthreads();
-    commit(w_fresh);
-    __syncthreads();
+    if (ka.dbg < 3) __syncthreads();
+    if (ka.dbg < 2) commit(w_fresh);
+    if (ka.dbg < 3) __syncthreads();
     w_fresh = !w_resident;
     int ntile = tile_lin, nchunk = chunk + 1;
     if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
     const bool nhave = ntile < total;
-    prefetch(ntile, nchunk, nhave, !w_resident);
+    if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
 
     {
       // ---- NSTEP steps x 3 x R x NT MFMAs; fragments of step s + 1 are read before the MFMAs of step s ----
@@ -278,7 +294,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       }
     }
 
-    if (chunk == ka.nchunks - 1) {
+    if (ka.dbg >= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" :: "v"(acc[r][nt]), "v"(accx[r][nt]));
+    } else if (chunk == ka.nchunks - 1) {
       // ---- epilogue (conv3d_mfma.hip) ----
       int n, tx, ty, tz;
       decode(tile_lin, n, tx, ty, tz);
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       if (tx == ka.tiles_x - 1) obad |= obad_xhi;
       if (ty == ka.tiles_y - 1) obad |= obad_yhi;
       if (tz == ka.tiles_z - 1) obad |= obad_zhi;
-      const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TX);
+      const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TXV);
       const unsigned osoff = vox0 * (unsigned)a.out_pitch * 4u;
       const unsigned e0 = vox0 * (unsigned)a.Cout;
       const __amdgpu_buffer_rsrc_t osrd =
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const unsigned cshift = (unsigned)((cg * NT + nt) * 16);
+        const unsigned cshift = XP ? 0u : (unsigned)((cg * NT + nt) * 16);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
@@ -356,13 +377,17 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         __syncthreads();
         if (tid < NT * 16) {
           const int nt = tid / 16, c = tid % 16;
-          const int co = (cg * NT + nt) * 16 + c;
-          if (co < a.Cout) {
+          const int co = XP ? c : (cg * NT + nt) * 16 + c;   // x-pair: rows c and c + 8 are the two x of channel c
+          if (co < a.Cout && (!XP || c < 8)) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
               s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
               q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+              if (XP) {
+                s += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 0];
+                q += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 1];
+              }
             }
             const int tile = tile_lin - n * ntiles;
             float* dst = a.stats_partial + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
@@ -383,8 +408,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 // ---------------------------------------------------------------------------------------------
 // weight packing: torch (Cout, Cin, 3,3,3) fp32 -> [rowgroup][chunk][step][nt][hi | lo][lane 64][8 halves]
 __global__ void pack_conv3d_k3_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int CB,
-                                          int NT, int64_t total) {
-  const int TPS = 32 / CB, NSTEP = (27 + TPS - 1) / TPS, nchunks = Cin / CB;
+                                          int NT, int XP, int64_t total) {
+  const int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS, nchunks = Cin / CB;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int j = r % 8; r /= 8;
@@ -399,25 +424,31 @@ __global__ void pack_conv3d_k3_s16_kernel(const float* __restrict__ w, _Float16*
     const int tap = CB == 16 ? 2 * step + (kg >> 1) : 4 * step + kg;
     const int ci = chunk * CB + (CB == 16 ? 8 * (kg & 1) + j : j);
     float v = 0.f;
-    if (row < Cout && tap < 27) v = w[((size_t)row * Cin + ci) * 27 + tap];
+    if (XP) {   // row = dx * 8 + co, step = (kz, ky), k-group = ix
+      const int dx = row >> 3, co = row & 7, kx = kg - dx;
+      if (kx >= 0 && kx <= 2) v = w[((size_t)co * Cin + ci) * 27 + step * 3 + kx];
+    } else if (row < Cout && tap < 27) {
+      v = w[((size_t)row * Cin + ci) * 27 + tap];
+    }
     const float c = fminf(fmaxf(v, -65504.f), 65504.f);
     const _Float16 h = (_Float16)c;
     out[i] = hl == 0 ? h : (_Float16)((v - (float)h) * 2048.f);
   }
 }
 
-struct S16Cfg { int CB, NT; };
+struct S16Cfg { int CB, NT, XP; };
 static inline S16Cfg s16_config(int Cin, int Cout) {
   S16Cfg c;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
-  c.CB = (Cin % 16 == 0) ? 16 : 8;
+  c.XP = (Cout == 8 && !getenv("VX_S16_NO_XP")) ? 1 : 0;
+  c.CB = c.XP ? 8 : ((Cin % 16 == 0) ? 16 : 8);
   return c;
 }
 static inline int s16_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
 int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout) {
   const S16Cfg c = s16_config(Cin, Cout);
-  const int TPS = 32 / c.CB, NSTEP = (27 + TPS - 1) / TPS;
+  const int TPS = 32 / c.CB, NSTEP = c.XP ? 9 : (27 + TPS - 1) / TPS;
   const int64_t halves = (int64_t)(s16_rows_padded(Cout, c.NT) / 16) * (Cin / c.CB) * NSTEP * 2 * 64 * 8;
   return halves / 2;
 }
@@ -428,19 +459,20 @@ int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Co
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv3d_k3_s16_kernel, dim3(blocks), dim3(256), 0, s, w_torch, reinterpret_cast<_Float16*>(w_packed),
-                     Cin, Cout, c.CB, c.NT, total);
+                     Cin, Cout, c.CB, c.NT, c.XP, total);
   VX_CHECK_LAUNCH("vx_pack_conv3d_k3(s16)");
   return VX_OK;
 }
 
-template <int CB, int NT, int TX, int TY, int TZ, int NW>
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
 static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
-  constexpr int NHALO = (TX + 2) * (TY + 2) * (TZ + 2);
-  constexpr int PLANE = ((NHALO + 15) / 16) * 16;
-  constexpr int TPS = 32 / CB, NSTEP = (27 + TPS - 1) / TPS;
-  constexpr size_t lds = (size_t)2 * (CB / 8) * PLANE * 8 * 2 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)NW * NT * 16 * 2 * 4;
+  constexpr int TXV = XP ? 2 * TX : TX;
+  constexpr int NHALO = (TXV + 2) * (TY + 2) * (TZ + 2);
+  constexpr int PLANE = (((XP ? NHALO / 2 : NHALO) + 15) / 16) * 16;
+  constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
+  constexpr size_t lds = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)NW * NT * 16 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW>;
+  auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -449,7 +481,7 @@ static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
   }
   const vx_conv3d_args& a = ka.a;
   const int total_tiles = ka.tiles_x * ka.tiles_y * ka.tiles_z * a.N;
-  const int ygroups = (a.Cout + 16 * NT - 1) / (16 * NT);
+  const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   if (per_cu * NW > 16) per_cu = 16 / NW > 0 ? 16 / NW : 1;
   if (const char* e = getenv("VX_S16_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
@@ -460,28 +492,32 @@ static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
   return VX_OK;
 }
 
-template <int CB, int NT>
+template <int CB, int NT, int XP>
 static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
-  if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8>(ka, s);
-  if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8>(ka, s);
-  return launch_s16<CB, NT, 4, 4, 4, 4>(ka, s);
+  if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
+  if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
+  return launch_s16<CB, NT, 4, 4, 4, 4, XP>(ka, s);
 }
 
-// tile = the plain tiling of conv3d_mfma.hip (tx = 16 / 8 / 4 by W)
+// tiles = those of conv3d_mfma.hip's tile_config (tx columns per row: 16 / 8 / 4 by W, or by W / 2 for x-pair)
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   const S16Cfg c = s16_config(a.Cin, a.Cout);
-  const int tx = a.W >= 16 ? 16 : (a.W >= 8 ? 8 : 4);
+  const int wcols = c.XP ? a.W / 2 : a.W;
+  const int tx = wcols >= 16 ? 16 : (wcols >= 8 ? 8 : 4);
   const int ty = tx == 8 ? 8 : 4, tz = 4;
+  const int txv = c.XP ? 2 * tx : tx;
   ConvSArgs ka;
   ka.a = a;
-  ka.tiles_x = (a.W + tx - 1) / tx; ka.tiles_y = (a.H + ty - 1) / ty; ka.tiles_z = (a.D + tz - 1) / tz;
+  ka.tiles_x = (a.W + txv - 1) / txv; ka.tiles_y = (a.H + ty - 1) / ty; ka.tiles_z = (a.D + tz - 1) / tz;
   ka.nchunks = a.Cin / c.CB;
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
-  if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1>(ka, tx, s);
-  if (c.CB == 16 && c.NT == 2) return dispatch_s16<16, 2>(ka, tx, s);
-  if (c.CB == 8 && c.NT == 1) return dispatch_s16<8, 1>(ka, tx, s);
-  return dispatch_s16<8, 2>(ka, tx, s);
+  ka.dbg = getenv("VX_S16_DBG") ? atoi(getenv("VX_S16_DBG")) : 0;
+  if (c.XP) return dispatch_s16<8, 1, 1>(ka, tx, s);
+  if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1, 0>(ka, tx, s);
+  if (c.CB == 16 && c.NT == 2) return dispatch_s16<16, 2, 0>(ka, tx, s);
+  if (c.CB == 8 && c.NT == 1) return dispatch_s16<8, 1, 0>(ka, tx, s);
+  return dispatch_s16<8, 2, 0>(ka, tx, s);
 }

@@ -1,6 +1,7 @@
 """GPU: every kernel of libvalues_amd.so, called through the C ABI, against the oracle
 (oracle/*.py: float64 CPU restatement of the reference) on seeded inputs."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -143,11 +144,19 @@ def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeyp
 
 @pytest.mark.parametrize("cin,shape,ncls,xb", [(8, (3, 8, 8, 32), 2, 0), (16, (2, 5, 7, 38), 4, 0), (16, (2, 4, 8, 16), 2, 4),
                                                 (8, (1, 3, 3, 7), 3, 0)])
-def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb, monkeypatch):
-    """expand_1_2 + final (unet3D_module.py:365) in one launch: bit-identical to vx_conv3d_k3 followed by
-    vx_conv1x1_ncdhw, including the slot scatter and the TTA un-flip (test_3D.py:445-447)"""
+def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb, conv_mode):
+    """expand_1_2 + final (unet3D_module.py:365) in one launch: equal to vx_conv3d_k3 followed by
+    vx_conv1x1_ncdhw (bit-identical on the 4x4x1 kernel), including the slot scatter and the TTA un-flip (test_3D.py:445-447)"""
     lib = _lib.load()
-    monkeypatch.setenv("VX_CONV_FP32", "1")     # the fused head lives in the 4x4x1 kernel (native-fp32 mode)
+    if conv_mode != "fp32":
+        os.environ["VX_S16_HEAD"] = "1"            # opt-in on the x-pair split-fp16 kernel (no measured gain there)
+    try:
+        _fused_head_case(lib, cin, shape, ncls, xb, conv_mode)
+    finally:
+        os.environ.pop("VX_S16_HEAD", None)
+
+
+def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):
     assert lib.vx_conv3d_k3_head_fusable(cin, 8)
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 161))
@@ -183,7 +192,10 @@ def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb, mon
     a.head_dst, a.head_flip = dst.data_ptr(), flip.data_ptr()
     _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv+head")
     torch.cuda.synchronize()
-    assert torch.equal(got, ref)
+    if conv_mode == "fp32":
+        assert torch.equal(got, ref)     # same fmaf chain as conv1x1.hip
+    else:
+        assert (got - ref).abs().max().item() < 1e-5   # two 4-channel partial chains + one add
     # and against the float64 composition of the two reference modules
     r64 = F.leaky_relu(F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1), 0.01) * mask * 2.0
     r64 = F.conv3d(r64, hw.cpu().double(), hb.cpu().double())

@@ -46,6 +46,7 @@ int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_
 int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout);
 int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s);
+bool vx_conv3d_s16_head_fusable(int Cin, int Cout);
 
 struct ConvKArgs {
   vx_conv3d_args a;
@@ -601,7 +602,9 @@ static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s
 
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
-  return conv_config(Cin, Cout).C8;   // the 4x4x1 kernel keeps all channels of a voxel in one lane
+  const ConvCfg c = conv_config(Cin, Cout);
+  if (c.S16) return vx_conv3d_s16_head_fusable(Cin, Cout) ? 1 : 0;   // x-pair split-fp16 kernel: halves in lanes l, l ^ 16
+  return c.C8;   // the 4x4x1 kernel keeps all channels of a voxel in one lane
 }
 
 extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {

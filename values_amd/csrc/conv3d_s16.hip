@@ -9,7 +9,7 @@
 // conv-like data against float64): max error 5.9e-7 / rms 9.1e-8 for this scheme, 1.1e-6 / 1.6e-7 for the native
 // fp32 matrix instruction (which rounds after every K = 4), at 650 vs 155 TFLOP/s of fp32-equivalent work with
 // operands in registers.  Activations and weights stay float32 in HBM; the split happens on the way into LDS
-// (activations) and at pack time (weights).  Range: |x| < 65504 (fp16); hi is clamped there.
+// (activations) and at pack time (weights).  Range: |x| < 65504 (fp16).
 //
 // Everything around the MFMA loop -- work items, register prefetch with out-of-range steering, tile shapes,
 // x-blocked concat input, XCD-aware tile order, the fused bias / activation / dropout / statistics epilogue and its
@@ -39,13 +39,21 @@ struct ConvSArgs {
   int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
 };
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// x -> (hi, lo) with x = hi + lo * 2^-11 (see the header).  Two elements at a time so that the conversions and the
+// residual arithmetic use the packed instructions (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32): 12 VALU
+// instructions per 16-byte piece.  No clamping: |x| >= 65520 turns into inf and the output into NaN -- loud, and
+// out of reach for activations that went through InstanceNorm / a dropout-scaled LeakyReLU.
 __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float x = fminf(fmaxf(v[j], -65504.f), 65504.f);
-    const _Float16 h = (_Float16)x;
-    hi[j] = h;
-    lo[j] = (_Float16)fminf(fmaxf((v[j] - (float)h) * 2048.f, -65504.f), 65504.f);   // (finite even out of range)
+  for (int j = 0; j < 4; j += 2) {
+    const f32x2 x = {v[j], v[j + 1]};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
   }
 }
 
@@ -349,12 +357,36 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
           }
-          const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
-          // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 3" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
+          if (XP && a.head_out) {
+            // fused 1x1x1 head (conv1x1.hip): this lane holds channels 4 (g & 1) .. + 3 of voxel 2p + (g >> 1), the
+            // lane 16 further (g ^ 1) the other four -- one cross-lane add per class, then the g-even lane stores.
+            // Summation order differs from conv1x1.hip's single chain (two partial chains + one add): not bit-equal.
+            const int vv = (wave * R + r) * 16 + m;
+            int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
+            const int f = a.head_flip ? a.head_flip[n] : 0;
+            if (f & 1) gz = a.D - 1 - gz;
+            if (f & 2) gy = a.H - 1 - gy;
+            if (f & 4) gx = a.W - 1 - gx;
+            const size_t nvox = (size_t)a.D * a.H * a.W;
+            const int slot = a.head_dst ? a.head_dst[n] : n;
+            float* o = a.head_out + (size_t)slot * a.head_C * nvox + ((size_t)gz * a.H + gy) * a.W + gx;
+            const int k0 = (g & 1) * 4;
+            for (int c = 0; c < a.head_C; ++c) {
+              float part = (g & 1) ? 0.f : a.head_b[c];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) part = fmaf(a.head_w[c * 8 + k0 + k], v[k], part);
+              part += __shfl_xor(part, 16, 64);
+              if (!bad && !(g & 1)) o[(size_t)c * nvox] = part;
+            }
+          }
+          if (a.out) {
+            const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
+            // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 3" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
 
@@ -500,6 +532,10 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
 }
 
 // tiles = those of conv3d_mfma.hip's tile_config (tx columns per row: 16 / 8 / 4 by W, or by W / 2 for x-pair)
+// measured: no gain over the separate conv1x1 kernel (1647 vs 1654 volumes/s) -- the per-class cross-lane adds and the
+// stride-2 logit stores cost what the saved feature-map round trip buys; kept, off unless VX_S16_HEAD=1
+bool vx_conv3d_s16_head_fusable(int Cin, int Cout) { return s16_config(Cin, Cout).XP != 0 && getenv("VX_S16_HEAD") != nullptr; }
+
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   const S16Cfg c = s16_config(a.Cin, a.Cout);
   const int wcols = c.XP ? a.W / 2 : a.W;

@@ -60,11 +60,14 @@ def kernel_name(kind, ci, co, edge):
             return f"conv3d_k3_c1_kernel<{co}>"
         fp32 = int(os.environ.get("VX_CONV_FP32", "0") or 0)
         if fp32 == 0 or (fp32 == 2 and co != 8):
-            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW>, split-fp16 products on v_mfma_f32_16x16x32_f16
-            cb = 16 if ci % 16 == 0 else 8
+            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP>, split-fp16 products on v_mfma_f32_16x16x32_f16;
+            # Cout = 8 layers: x-pair packing (XP = 1) in chunks of 8 channels, a column is a voxel pair
+            xp = 1 if co == 8 else 0
+            cb = 8 if xp else (16 if ci % 16 == 0 else 8)
             nt = 2 if co % 32 == 0 else 1
-            tile, nw = ("16,4,4", 8) if edge >= 16 else (("8,8,4", 8) if edge >= 8 else ("4,4,4", 4))
-            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw}>"
+            ex = edge // 2 if xp else edge
+            tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
+            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp}>"
         if co == 8 and ci in (8, 16):
             # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)
             tile = "32,4,4" if edge >= 32 else ("16,8,4" if edge >= 16 else "8,4,4")
@@ -150,6 +153,7 @@ def roofline_leg(model, x, T, reps=3):
     peak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     roof = {"bound": "mfma", "kernel": name, "achieved": round(tflops, 3), "peak": peak,
             "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+            "frac_of_fp32_matrix_peak": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4),
             "peak_note": ("fp32-equivalent matrix roof of the split-fp16 scheme: f16 dense peak (16 x 157.3 TF) / 3 "
                           "products per fp32 product; the native-fp32 matrix peak is 157.3 TF") if split else
                          "fp32 matrix peak, dense",

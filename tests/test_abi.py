@@ -81,7 +81,8 @@ def test_host_only_queries(lib):
     assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1
     assert lib.vx_convT_k2s2_packed_floats(16, 8) == 16 * 8 * 8
     assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
-    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 16 * 16  # x-pair tiles are 32 voxels wide
+    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 8 * 16   # split-fp16 x-pair tiles of large layers: 32 x 8 x 4
+    assert lib.vx_conv3d_k3_tiles_for(16, 16, 16, 16) == 1 * 4 * 4  # small layers: 16 x 4 x 4
     assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 

@@ -47,6 +47,7 @@ int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout);
 int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s);
 bool vx_conv3d_s16_head_fusable(int Cin, int Cout);
+void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz);
 
 struct ConvKArgs {
   vx_conv3d_args a;
@@ -543,14 +544,18 @@ static inline TileCfg tile_config(int W, int XP) {
 }
 
 static int conv_tiles(int D, int H, int W, int Cout) {
-  // Cout = 8 layers use the x-pair tiling (32 voxels wide) in every mode but the split-fp16 A/B knob VX_S16_NO_XP
-  TileCfg t = tile_config(W, Cout == 8 && !(conv_config(8, 8).S16 && getenv("VX_S16_NO_XP")));
+  if (conv_config(8, Cout).S16) {   // split-fp16 schedule: its own tile choice (larger tiles for large layers)
+    int txv, ty, tz;
+    vx_conv3d_s16_tile(H, W, Cout, &txv, &ty, &tz);
+    return ((W + txv - 1) / txv) * ((H + ty - 1) / ty) * ((D + tz - 1) / tz);
+  }
+  TileCfg t = tile_config(W, Cout == 8);
   return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
 }
 extern "C" int vx_conv3d_k3_tiles(int D, int H, int W) {
-  // upper bound over both packings (stats_partial sizing): the plain tiling has the most tiles
-  int a = conv_tiles(D, H, W, 16), b = conv_tiles(D, H, W, 8);
-  return a > b ? a : b;
+  // upper bound over every packing and mode (stats_partial sizing): the plain 16 x 4 x 4 tiling has the most tiles
+  const TileCfg t = tile_config(W, 0);
+  return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
 }
 extern "C" int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout) { return conv_tiles(D, H, W, Cout); }
 

@@ -36,6 +36,7 @@ struct ConvSArgs {
   int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;
   int no_xcd;
+  int ty8;   // 16 x 8 x 4 tiles (vx_conv3d_s16_tile)
   int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
 };
 
@@ -526,6 +527,7 @@ static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
 
 template <int CB, int NT, int XP>
 static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
+  if (tx == 16 && ka.ty8) return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);   // large layers: 4 column tiles per wave
   if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
   if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
   return launch_s16<CB, NT, 4, 4, 4, 4, XP>(ka, s);
@@ -534,14 +536,28 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
 // tiles = those of conv3d_mfma.hip's tile_config (tx columns per row: 16 / 8 / 4 by W, or by W / 2 for x-pair)
 // measured: no gain over the separate conv1x1 kernel (1647 vs 1654 volumes/s) -- the per-class cross-lane adds and the
 // stride-2 logit stores cost what the saved feature-map round trip buys; kept, off unless VX_S16_HEAD=1
+// Tile of a layer: tx columns per row (16 / 8 / 4 by W, or by W / 2 for x-pair) as in conv3d_mfma.hip; large layers
+// (H >= 32) take 16 x 8 x 4 tiles = 4 column tiles per wave: the halo read per output voxel drops from 2.5x to 2.1x
+// and the per-item costs (barriers, decode, masks) halve -- +14..20 % on the 64^3 layers; small layers keep
+// 16 x 4 x 4 so that the 256 CUs still get enough work items.
+void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
+  const int xp = s16_config(8, Cout).XP;
+  const int wcols = xp ? W / 2 : W;
+  const int tx = wcols >= 16 ? 16 : (wcols >= 8 ? 8 : 4);
+  const bool ty8 = tx == 16 && H >= 32 && !getenv("VX_S16_NO_TY8");
+  *txv = xp ? 2 * tx : tx;
+  *ty = (tx == 8 || ty8) ? 8 : 4;
+  *tz = 4;
+}
+
 bool vx_conv3d_s16_head_fusable(int Cin, int Cout) { return s16_config(Cin, Cout).XP != 0 && getenv("VX_S16_HEAD") != nullptr; }
 
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   const S16Cfg c = s16_config(a.Cin, a.Cout);
-  const int wcols = c.XP ? a.W / 2 : a.W;
-  const int tx = wcols >= 16 ? 16 : (wcols >= 8 ? 8 : 4);
-  const int ty = tx == 8 ? 8 : 4, tz = 4;
-  const int txv = c.XP ? 2 * tx : tx;
+  int txv, ty, tz;
+  vx_conv3d_s16_tile(a.H, a.W, a.Cout, &txv, &ty, &tz);
+  const int tx = c.XP ? txv / 2 : txv;
+  const int ty8 = (tx == 16 && ty == 8) ? 1 : 0;
   ConvSArgs ka;
   ka.a = a;
   ka.tiles_x = (a.W + txv - 1) / txv; ka.tiles_y = (a.H + ty - 1) / ty; ka.tiles_z = (a.D + tz - 1) / tz;
@@ -551,6 +567,7 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
   ka.dbg = getenv("VX_S16_DBG") ? atoi(getenv("VX_S16_DBG")) : 0;
+  ka.ty8 = ty8;
   if (c.XP) return dispatch_s16<8, 1, 1>(ka, tx, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1, 0>(ka, tx, s);
   if (c.CB == 16 && c.NT == 2) return dispatch_s16<16, 2, 0>(ka, tx, s);

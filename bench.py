@@ -66,7 +66,10 @@ def kernel_name(kind, ci, co, edge):
             cb = 8 if xp else (16 if ci % 16 == 0 else 8)
             nt = 2 if co % 32 == 0 else 1
             ex = edge // 2 if xp else edge
-            tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
+            if ex >= 16:   # vx_conv3d_s16_tile: large layers (H >= 32) take 16 x 8 x 4 tiles
+                tile, nw = ("16,8,4" if edge >= 32 else "16,4,4"), 8
+            else:
+                tile, nw = ("8,8,4", 8) if ex >= 8 else ("4,4,4", 4)
             return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp}>"
         if co == 8 and ci in (8, 16):
             # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)

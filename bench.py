@@ -255,7 +255,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from values_amd import UNet3D, predict_uncertainty
-    from values_amd.dist import gather_maps
+    from values_amd.dist import MapGatherPipeline
 
     torch.manual_seed(123)  # reference seed (configs/dropout_config.yaml:8); default torch init = random weights
     model = UNet3D(num_classes=2, do_dropout=True).to(dev)
@@ -263,9 +263,13 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((V, 1, S, S, S), generator=g).to(dev)  # z-scored synthetic volumes, resident in HBM
 
+    # maps are collected on rank 0 with the gather of step i overlapping the kernels of step i + 1 (two buffers);
+    # everything is flushed before the closing barrier, so the timed region contains every transfer
+    pipe = MapGatherPipeline(world, rank, depth=2)
+
     def step(i):
         out = predict_uncertainty([model], x, n_pred=T, seeds=[i])
-        return gather_maps(out, world, rank)
+        return pipe.submit(out)
 
     def barrier():
         if world > 1:
@@ -274,10 +278,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    pipe.flush()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    pipe.flush()
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)

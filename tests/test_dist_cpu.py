@@ -44,6 +44,60 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_pipeline(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from values_amd.dist import MapGatherPipeline
+    pipe = MapGatherPipeline(world, rank, depth=2)
+    got = []
+    n_vol = 4
+    for step in range(5):    # more steps than buffers: every send / receive buffer is reused
+        lo, hi = shard_range(n_vol, world, rank)
+        maps = _fake_maps(lo + 10 * step, hi + 10 * step)
+        r = pipe.submit(maps)
+        for v in maps.values():
+            v.zero_() if v.is_contiguous() else None    # the caller may reuse its tensors right away
+        if r is not None:
+            got.append(r)
+    got += [r for r in pipe.flush() if r is not None]
+    if rank == 0:
+        ok = len(got) == 5
+        for step, res in enumerate(got):
+            ref = {}
+            parts = [_fake_maps(*[x + 10 * step for x in shard_range(n_vol, world, r)]) for r in range(world)]
+            for k in parts[0]:
+                ref[k] = torch.cat([p[k] for p in parts], 0)
+            ok = ok and all(torch.equal(res[k], ref[k]) for k in ref)
+        q.put(ok)
+    else:
+        q.put(len(got) == 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_map_gather_pipeline_world2_gloo():
+    """the overlapped gather of bench.py --gpus N: order of results, buffer reuse, flush"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(res)
+
+
+def test_map_gather_pipeline_world1():
+    from values_amd.dist import MapGatherPipeline
+    pipe = MapGatherPipeline(1, 0, depth=2)
+    outs = [pipe.submit({"step": i}) for i in range(4)]
+    assert outs[:2] == [None, None] and outs[2] == {"step": 0} and outs[3] == {"step": 1}
+    assert pipe.flush() == [{"step": 2}, {"step": 3}]
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 5, 8, 17):
         for world in (1, 2, 3, 8):

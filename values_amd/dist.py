@@ -63,6 +63,63 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
     return unpack_maps(torch.cat(lists[0], 0), torch.cat(lists[1], 0))
 
 
+class MapGatherPipeline:
+    """gather_maps with the collective OFF the compute path: `submit(out)` packs the step's maps into one of
+    `depth` send buffers and starts an asynchronous gather (RCCL runs it on its own stream, so the next step's
+    kernels overlap the transfer -- at ~1 900 volumes/s a step of 16 volumes is 8 ms of compute and 88 MB of maps
+    per rank, i.e. 0.6 GB into rank 0 per step at 8 GPUs); `collect()` waits for the OLDEST gather in flight and
+    returns its maps on dst (None elsewhere).  submit() collects first when `depth` gathers are already in flight,
+    so a send buffer is never overwritten while it is being read.  world == 1: submit/collect are a FIFO."""
+
+    def __init__(self, world: int, rank: int, dst: int = 0, depth: int = 2):
+        self.world, self.rank, self.dst, self.depth = world, rank, dst, max(1, depth)
+        self._send = [None] * self.depth
+        self._recv = [None] * self.depth
+        self._inflight = []      # [(slot, works)] oldest first
+        self._next = 0
+
+    def submit(self, out: Dict[str, torch.Tensor]):
+        done = None
+        if len(self._inflight) >= self.depth:
+            done = self.collect()
+        slot = self._next
+        self._next = (self._next + 1) % self.depth
+        if self.world == 1:
+            self._inflight.append((slot, out))
+            return done
+        import torch.distributed as dist
+        f, seg = pack_maps(out)
+        if self._send[slot] is None or self._send[slot][0].shape != f.shape:
+            self._send[slot] = (torch.empty_like(f), torch.empty_like(seg))
+            if self.rank == self.dst:
+                self._recv[slot] = ([torch.empty_like(f) for _ in range(self.world)],
+                                    [torch.empty_like(seg) for _ in range(self.world)])
+        sf, ss = self._send[slot]
+        sf.copy_(f); ss.copy_(seg)           # the step's own tensors may be reused by the next step
+        rl = self._recv[slot] if self.rank == self.dst else (None, None)
+        works = [dist.gather(sf, rl[0], dst=self.dst, async_op=True), dist.gather(ss, rl[1], dst=self.dst, async_op=True)]
+        self._inflight.append((slot, works))
+        return done
+
+    def collect(self) -> Optional[Dict[str, torch.Tensor]]:
+        if not self._inflight:
+            return None
+        slot, works = self._inflight.pop(0)
+        if self.world == 1:
+            return works
+        for w in works:
+            w.wait()
+        if self.rank != self.dst:
+            return None
+        return unpack_maps(torch.cat(self._recv[slot][0], 0), torch.cat(self._recv[slot][1], 0))
+
+    def flush(self) -> List[Optional[Dict[str, torch.Tensor]]]:
+        res = []
+        while self._inflight:
+            res.append(self.collect())
+        return res
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Member-sharded ensembles (BASELINE config C3: 5 members over 8 GPUs).  Work items are (member, volume-block) pairs
 # dealt round-robin over the ranks; a rank adds the sufficient statistics of its items into one buffer

@@ -55,7 +55,13 @@ def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0):
     (64, 64, 1, 1, (1, 16, 24)), (256, 64, 1, 1, (1, 16, 24)), (96, 48, 1, 1, (2, 8, 15)), (720, 720, 1, 1, (1, 8, 15)),
     (240, 4, 1, 1, (1, 16, 24)), (64, 24, 1, 1, (1, 7, 9)), (16, 128, 3, 1, (1, 5, 7)),
 ])
-def test_conv2d_matches_oracle(cin, cout, ks, s, shape):
+@pytest.mark.parametrize("mode", ["split16", "fp32"])
+def test_conv2d_matches_oracle(cin, cout, ks, s, shape, mode, monkeypatch):
+    # default: split-fp16 schedule (conv2d_s16.hip); VX_CONV_FP32=1: native-fp32 kernels (conv2d_mfma.hip)
+    if mode == "fp32":
+        monkeypatch.setenv("VX_CONV_FP32", "1")
+    else:
+        monkeypatch.delenv("VX_CONV_FP32", raising=False)
     n, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, h, w), 201))
     wt = torch.from_numpy(formula_tensor((cout, cin, ks, ks), 202, scale=(1.0 / (ks * ks * cin)) ** 0.5))

@@ -1,30 +1,24 @@
-// K15: 2D convolutions of HRNet (uncertainty_modeling/models/hrnet_module.py:37-41, 85-93, 349-358, 411-428):
-// 3x3 stride 1, 3x3 stride 2, 1x1 -- channels-last fp32, implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32),
-// same skeleton as conv3d_mfma.hip: persistent 512-thread workgroups over a flat list of (tile, cin-chunk) items,
-// next item's loads in flight in registers (buffer loads, out-of-image pieces steered out of range -> zeros),
-// group-major conflict-free LDS image, weights pre-packed in fragment order.
+// K15, split-precision schedule: the 2D convolutions of conv2d_mfma.hip (HRNet: 3x3 s1, 3x3 s2, 1x1) with every
+// fp32 product evaluated on the fp16 matrix cores by operand splitting, exactly as conv3d_s16.hip does for the 3D
+// network (x = hi + lo * 2^-11; three v_mfma_f32_16x16x32_f16 per K = 32 step; fp32 accumulation in a main and a
+// cross accumulator; measured closer to float64 than the native fp32 matrix instruction).
 //
-//   D[cout][x] = sum_k W[cout][k] X[k][x],  k = (ky, kx, cin);  rows = 16*NT couts, columns = 16 consecutive output x
-//   Workgroup tile = 16 (x) x TY (y) outputs; wave w owns R = TY/8 rows.
-//   Stride 2: output x reads input 2x + kx - 1, so even/odd input columns (and rows) live in separate parity planes
-//   of the LDS image and a tile's 16 columns stay consecutive positions (same trick as the 3D x-pair packing).
-//   1x1: no halo, up to NSUB = 4 sub-blocks of 16 input channels per item (a GEMM with K = 64 per barrier pair).
-//
-// Epilogue: optional bias, raw store, and per-workgroup (sum, sum of squares) partials per channel for the
-// TRAINING-mode BatchNorm that follows every conv (batch statistics over N,H,W) -- deterministic, no
-// atomics; vx_bn_finalize reduces them.
+//   K = 32 step:  3x3: two taps x one sub-block of 16 channels (9 taps + 1 zero-weight pad = 5 steps per sub-block);
+//                 1x1: two sub-blocks of 16 channels (NSUB = 4 -> 2 steps per item)
+//                 lane k-group kg = 2 * (tap or sub-block parity) + channel octet
+//   LDS image:    hi plane + lo plane, each [sub-block][octet][parity plane | position][8 halves]
+//   weights:      [row group][chunk][step][row tile][hi | lo][lane][8 halves]
+// Everything else (work items, register prefetch, stride-2 parity planes, epilogue with BatchNorm batch-statistics
+// partials) is conv2d_mfma.hip's.
 #include "common.h"
 #include <stdlib.h>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// conv2d_s16.hip: the split-fp16 schedule (default; VX_CONV_FP32=1 selects the native-fp32 kernels of this file)
-int64_t vx_conv2d_s16_packed_floats(int Cin, int Cout, int KS);
-int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, hipStream_t s);
-int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s);
-static inline bool c2_split16() { const char* e = getenv("VX_CONV_FP32"); return !(e && atoi(e) != 0); }
-
-struct Conv2dKArgs {
+struct Conv2dSArgs {
   vx_conv2d_args a;
   int OH, OW, tiles_x, tiles_y, nchunks;   // nchunks = ceil(Cin/16 / NSUB)
   unsigned mx, my;
@@ -33,29 +27,44 @@ struct Conv2dKArgs {
 namespace {
 constexpr unsigned K_OOB = 0xFFFFFFF0u;
 constexpr unsigned K_NUMREC = 0x80000000u;
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {   // conv3d_s16.hip: vx_split4
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {
+    const f32x2 x = {v[j], v[j + 1]};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
 }
 
 template <int KS, int S, int NT, int NSUB, int TY>
-__global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
+__global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   constexpr int NW = 8, NTH = 512, TX = 16;
   constexpr int R = TY / NW;
   constexpr int HX = (TX - 1) * S + KS, HY = (TY - 1) * S + KS;   // input halo tile
   constexpr int NPAR = S * S;                                     // parity planes (stride 2: 4)
   constexpr int PXW = (HX + S - 1) / S, PYH = (HY + S - 1) / S;   // positions per parity plane
   constexpr int NPP = PXW * PYH;
-  constexpr int PLANE = ((NPAR * NPP + 15) / 16) * 16;            // positions per (sub, g) plane, 16-aligned
-  constexpr int IN_FLOATS = NSUB * 4 * PLANE * 4;
-  constexpr int NTAP = KS * KS;
-  constexpr int W_SUB = NTAP * NT * 64 * 4;                       // weight floats per sub-block
-  constexpr int W_FLOATS = NSUB * W_SUB;
+  constexpr int PLANE = ((NPAR * NPP + 15) / 16) * 16;            // positions per (sub, octet) plane, 16-aligned
+  constexpr int IMG_H = NSUB * 2 * PLANE * 8;                     // halves per precision plane
+  constexpr int IN_FLOATS = IMG_H;                                // (hi + lo planes = 2 * IMG_H halves = IMG_H floats)
+  constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;            // K = 32 steps per item
+  constexpr int W_STEP = NT * 2 * 64 * 8;                         // weight halves per step
+  constexpr int W_FLOATS = NSTEP * W_STEP / 2;                    // per item (chunk), in floats
+  static_assert(KS == 3 || NSUB % 2 == 0, "1x1: sub-blocks are consumed in pairs");
   constexpr int NPIECE = HX * HY * 4 * NSUB;                      // 16-byte pieces of the input tile
   constexpr int IN_IT = (NPIECE + NTH - 1) / NTH;
   constexpr int W_IT = (W_FLOATS / 4 + NTH - 1) / NTH;
   static_assert(TY % NW == 0 && IN_IT <= 16, "tile config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_in = smem;
-  float* s_w = smem + IN_FLOATS;
+  _Float16* s_hi = reinterpret_cast<_Float16*>(smem);
+  _Float16* s_lo = s_hi + IMG_H;
+  _Float16* s_w = s_hi + 2 * IMG_H;
 
   const vx_conv2d_args& a = ka.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int ly = wave * R + r;
-    vbase[r] = (g * PLANE + ly * PXW + m) * 4;
+    vbase[r] = ly * PXW + m;    // position within a (sub, octet) plane
     ovoff[r] = (unsigned)(((ly * ka.OW + m) * a.out_pitch + a.out_coff + g * 4) * 4);
     if (m >= ka.OW - lastx) obad_xhi |= 1u << r;
     if (ly >= ka.OH - lasty) obad_yhi |= 1u << r;
@@ -95,13 +104,28 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
     const int dxr = hx - KS / 2, dyr = hy - KS / 2;       // input pixel relative to the tile's input origin
     voff[it] = (unsigned)((dyr * rowf + dxr * a.in_pitch + sub * 16 + q * 4 + biasf) * 4);
     const int par = (hy % S) * S + (hx % S);
-    ldst[it] = ((sub * 4 + q) * PLANE + par * NPP + (hy / S) * PXW + hx / S) * 4;
+    ldst[it] = ((sub * 2 + (q >> 1)) * PLANE + par * NPP + (hy / S) * PXW + hx / S) * 8 + (q & 1) * 4;   // halves
     isub[it] = (unsigned)sub;
     if (idx >= NPIECE) ibad_always |= 1u << it;
     if (dxr < 0) ibad_xlo |= 1u << it;
     if (dxr >= a.W - lastx * S) ibad_xhi |= 1u << it;
     if (dyr < 0) ibad_ylo |= 1u << it;
     if (dyr >= a.H - lasty * S) ibad_yhi |= 1u << it;
+  }
+  // this lane's (tap | sub-block, octet) of every step, as a position offset into a precision plane
+  int toff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int oct = g & 1;
+    if (KS == 3) {
+      const int sub = s / 5;
+      int tap = 2 * (s % 5) + (g >> 1);
+      if (tap > 8) tap = 8;                       // zero-weight padding tap: re-read a valid position
+      const int ky = tap / 3, kx = tap % 3;
+      toff[s] = (sub * 2 + oct) * PLANE + ((ky % S) * S + (kx % S)) * NPP + (ky / S) * PXW + kx / S;
+    } else {
+      toff[s] = ((2 * s + (g >> 1)) * 2 + oct) * PLANE;
+    }
   }
   const size_t in_sample = (size_t)a.H * rowf;
   const size_t out_sample = (size_t)ka.OH * ka.OW * a.out_pitch;
@@ -112,7 +136,7 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
     q = ka.tiles_y == 1 ? t : __umulhi(t, ka.my); ty = (int)(t - q * ka.tiles_y); n = (int)q;
   };
 
-  const float* w_cg = a.w_packed + (size_t)cg * nsub_all * W_SUB;
+  const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
   f32x4 ibuf[IN_IT], wbuf[W_IT];
   const bool w_resident = ka.nchunks == 1;
   bool w_fresh = true;
@@ -136,19 +160,24 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
       const unsigned vo = b ? K_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
-    const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * NSUB * W_SUB);
+    const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * W_FLOATS);
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
       const int idx = tid + it * NTH;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (have && with_w && idx < nsub * (W_SUB / 4)) v = src[idx];
+      if (have && with_w && idx < W_FLOATS / 4) v = src[idx];
       wbuf[it] = v;
     }
   };
   auto commit = [&](bool with_w) {
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it)
-      if (tid + it * NTH < NPIECE) *reinterpret_cast<f32x4*>(s_in + ldst[it]) = ibuf[it];
+      if (tid + it * NTH < NPIECE) {
+        f16x4 hi, lo;
+        split4(ibuf[it], hi, lo);
+        *reinterpret_cast<f16x4*>(s_hi + ldst[it]) = hi;
+        *reinterpret_cast<f16x4*>(s_lo + ldst[it]) = lo;
+      }
     if (with_w) {
 #pragma unroll
       for (int it = 0; it < W_IT; ++it) {
@@ -170,11 +199,11 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
   int tile_lin = blockIdx.x, chunk = 0;
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have, true);
-  f32x4 acc[R][NT];
+  f32x4 acc[R][NT], accx[R][NT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   while (have) {
     __syncthreads();
@@ -187,30 +216,38 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
     const bool nhave = ntile < total;
     prefetch(ntile, nchunk, nhave, !w_resident);
 
-    for (int sub = 0; sub < nsub; ++sub) {   // NSUB == 1: a single pass
-      const float* sw = s_w + sub * W_SUB;
-      const float* si = s_in + sub * 4 * PLANE * 4;
-      f32x4 wf[2][NT], xf[2][R];
-      auto load_tap = [&](int t1, int slot) {
-        const int ky = t1 / KS, kx = t1 % KS;
-        const int toff = (((ky % S) * S + (kx % S)) * NPP + (ky / S) * PXW + kx / S) * 4;
+    {
+      // ---- NSTEP steps x 3 x R x NT MFMAs; fragments of step s + 1 are read before the MFMAs of step s.  (1x1:
+      // sub-blocks beyond the layer's Cin were steered out of range by prefetch -> zeros; their weights are zero too)
+      (void)nsub;
+      f16x8 ah[2][NT], al[2][NT], bh[2][R], bl[2][R];
+      auto load_step = [&](int s, int slot) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[slot][nt] = *reinterpret_cast<const f32x4*>(sw + ((t1 * NT + nt) * 64 + lane) * 4);
+        for (int nt = 0; nt < NT; ++nt) {
+          const _Float16* wp = s_w + s * W_STEP + ((nt * 2) * 64 + lane) * 8;
+          ah[slot][nt] = *reinterpret_cast<const f16x8*>(wp);
+          al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) xf[slot][r] = *reinterpret_cast<const f32x4*>(si + vbase[r] + toff);
+        for (int r = 0; r < R; ++r) {
+          const int p = (vbase[r] + toff[s]) * 8;
+          bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
+          bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
+        }
       };
-      load_tap(0, 0);
+      load_step(0, 0);
 #pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        if (tap + 1 < NTAP) load_tap(tap + 1, (tap + 1) & 1);
-        const int cur = tap & 1;
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+        const int cur = s & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][nt][j], xf[cur][r][j], acc[r][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bh[cur][r], acc[r][nt], 0, 0, 0);
+            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bl[cur][r], accx[r][nt], 0, 0, 0);
+            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][nt], bh[cur][r], accx[r][nt], 0, 0, 0);
+          }
       }
     }
 
@@ -234,7 +271,7 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
-          const f32x4 v = acc[r][nt] + bias4[nt];
+          const f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
           if (a.stats_partial && !bad) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
@@ -248,7 +285,7 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
         }
       }
       if (a.stats_partial) {
-        float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW][NT][16][2]
+        float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW][NT][16][2] (floats: image = IMG_H, weights = W_FLOATS)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -281,85 +318,82 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct C2Cfg { int NT, NSUB, TY; };
-static inline C2Cfg c2_config(int KS, int S, int Cout) {
-  C2Cfg c;
+struct C2SCfg { int NT, NSUB, TY; };
+static inline C2SCfg c2s_config(int KS, int S, int Cout) {
+  C2SCfg c;
   c.NT = (Cout % 48 == 0) ? 3 : ((Cout % 32 == 0) ? 2 : 1);
   c.NSUB = KS == 1 ? 4 : 1;
   c.TY = S == 2 ? 8 : 16;
   return c;
 }
+static inline int c2s_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
-__global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cin_pad, int Cout,
-                                   int KS, int NT, int64_t total) {
-  const int ntap = KS * KS, nsub = Cin_pad / 16;
+// torch (Cout, Cin, KS, KS) fp32 -> [row group][chunk][step][nt][hi | lo][lane][8 halves]
+__global__ void pack_conv2d_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int KS,
+                                       int NT, int NSUB, int nchunks, int64_t total) {
+  const int nstep = KS == 3 ? 5 * NSUB : NSUB / 2, ntap = KS * KS;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
-    const int j = r % 4; r /= 4;
+    const int j = r % 8; r /= 8;
     const int lane = r % 64; r /= 64;
+    const int hl = r % 2; r /= 2;
     const int nt = r % NT; r /= NT;
-    const int tap = r % ntap; r /= ntap;
-    const int sub = r % nsub; r /= nsub;
+    const int step = r % nstep; r /= nstep;
+    const int chunk = r % nchunks; r /= nchunks;
     const int rgrp = (int)r;
     const int row = (rgrp * NT + nt) * 16 + (lane & 15);
-    const int ci = sub * 16 + (lane >> 4) * 4 + j;
+    const int kg = lane >> 4;
+    int tap, sub;
+    if (KS == 3) { sub = chunk * NSUB + step / 5; tap = 2 * (step % 5) + (kg >> 1); }
+    else { sub = chunk * NSUB + 2 * step + (kg >> 1); tap = 0; }
+    const int ci = sub * 16 + 8 * (kg & 1) + j;
     float v = 0.f;
-    if (row < Cout && ci < Cin) v = w[((size_t)row * Cin + ci) * ntap + tap];
-    out[i] = v;
+    if (row < Cout && ci < Cin && tap < ntap) v = w[((size_t)row * Cin + ci) * ntap + tap];
+    const _Float16 h = (_Float16)v;
+    out[i] = hl == 0 ? h : (_Float16)((v - (float)h) * 2048.f);
   }
 }
 
-static inline int c2_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
-
-extern "C" int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS) {
-  if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
-  if (c2_split16()) return vx_conv2d_s16_packed_floats(Cin, Cout, KS);
-  const int cin_pad = (Cin + 15) / 16 * 16;
-  C2Cfg c = c2_config(KS, 1, Cout);
-  return (int64_t)c2_rows_padded(Cout, c.NT) * cin_pad * KS * KS;
+int64_t vx_conv2d_s16_packed_floats(int Cin, int Cout, int KS) {
+  const C2SCfg c = c2s_config(KS, 1, Cout);
+  const int nsub_all = (Cin + 15) / 16, nchunks = (nsub_all + c.NSUB - 1) / c.NSUB;
+  const int nstep = KS == 3 ? 5 * c.NSUB : c.NSUB / 2;
+  return (int64_t)(c2s_rows_padded(Cout, c.NT) / 16 / c.NT) * nchunks * nstep * c.NT * 2 * 64 * 8 / 2;
 }
 
-extern "C" int vx_pack_conv2d(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, vx_stream_t stream) {
-  if (!w_torch || !w_packed) VX_FAIL(VX_E_NULL, "vx_pack_conv2d: null pointer");
-  const int64_t total = vx_conv2d_packed_floats(Cin, Cout, KS);
-  if (total < 0) VX_FAIL(VX_E_SHAPE, "vx_pack_conv2d: Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
-  if (c2_split16()) return vx_pack_conv2d_s16(w_torch, w_packed, Cin, Cout, KS, (hipStream_t)stream);
-  C2Cfg c = c2_config(KS, 1, Cout);
+int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, hipStream_t s) {
+  const C2SCfg c = c2s_config(KS, 1, Cout);
+  const int nsub_all = (Cin + 15) / 16, nchunks = (nsub_all + c.NSUB - 1) / c.NSUB;
+  const int64_t total = vx_conv2d_s16_packed_floats(Cin, Cout, KS) * 2;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin,
-                     (Cin + 15) / 16 * 16, Cout, KS, c.NT, total);
-  VX_CHECK_LAUNCH("vx_pack_conv2d");
+  hipLaunchKernelGGL(pack_conv2d_s16_kernel, dim3(blocks), dim3(256), 0, s, w_torch, reinterpret_cast<_Float16*>(w_packed), Cin,
+                     Cout, KS, c.NT, c.NSUB, nchunks, total);
+  VX_CHECK_LAUNCH("vx_pack_conv2d(s16)");
   return VX_OK;
 }
 
-extern "C" int vx_conv2d_tiles(int H, int W, int KS, int S) {
-  const int OH = (H + 2 * (KS / 2) - KS) / S + 1, OW = (W + 2 * (KS / 2) - KS) / S + 1;
-  const int TY = S == 2 ? 8 : 16;
-  return ((OW + 15) / 16) * ((OH + TY - 1) / TY);
-}
-
 template <int KS, int S, int NT, int NSUB, int TY>
-static int launch_c2(const Conv2dKArgs& ka, hipStream_t s) {
+static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
   constexpr int HX = 15 * S + KS, HY = (TY - 1) * S + KS;
   constexpr int NPP = ((HX + S - 1) / S) * ((HY + S - 1) / S);
   constexpr int PLANE = ((S * S * NPP + 15) / 16) * 16;
-  constexpr int IN_FLOATS = NSUB * 4 * PLANE * 4;
-  constexpr int W_FLOATS = NSUB * KS * KS * NT * 64 * 4;
-  constexpr size_t lds = (size_t)(IN_FLOATS + W_FLOATS + 8 * NT * 16 * 2) * sizeof(float);
+  constexpr int IMG_H = NSUB * 2 * PLANE * 8;
+  constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;
+  constexpr size_t lds = (size_t)IMG_H * 4 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)8 * NT * 16 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = conv2d_mfma_kernel<KS, S, NT, NSUB, TY>;
+  auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) VX_FAIL((int)e, "vx_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    if (e != hipSuccess) VX_FAIL((int)e, "vx_conv2d(s16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
   const vx_conv2d_args& a = ka.a;
@@ -367,49 +401,34 @@ static int launch_c2(const Conv2dKArgs& ka, hipStream_t s) {
   const int ygroups = (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 4) per_cu = 4;
+  if (per_cu > 2) per_cu = 2;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(512), lds, s, ka);
-  VX_CHECK_LAUNCH("vx_conv2d");
+  VX_CHECK_LAUNCH("vx_conv2d(s16)");
   return VX_OK;
 }
 
 template <int KS, int S, int NSUB, int TY>
-static int dispatch_c2(const Conv2dKArgs& ka, int NT, hipStream_t s) {
-  if (NT == 3) return launch_c2<KS, S, 3, NSUB, TY>(ka, s);
-  if (NT == 2) return launch_c2<KS, S, 2, NSUB, TY>(ka, s);
-  return launch_c2<KS, S, 1, NSUB, TY>(ka, s);
+static int dispatch_c2s(const Conv2dSArgs& ka, int NT, hipStream_t s) {
+  if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY>(ka, s);
+  if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY>(ka, s);
+  return launch_c2s<KS, S, 1, NSUB, TY>(ka, s);
 }
 
-extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
-  if (!ap) VX_FAIL(VX_E_NULL, "vx_conv2d: null args");
-  const vx_conv2d_args& a = *ap;
-  if (!a.in || !a.w_packed || !a.out) VX_FAIL(VX_E_NULL, "vx_conv2d: null tensor pointer");
-  if (a.N <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv2d: empty tensor");
-  if (a.Cin <= 0 || a.Cin % 16 || a.Cout <= 0 || a.Cout % 4)
-    VX_FAIL(VX_E_SHAPE, "vx_conv2d: Cin=%d must be a multiple of 16 (pad the input), Cout=%d a multiple of 4", a.Cin, a.Cout);
-  if ((a.KS != 1 && a.KS != 3) || (a.S != 1 && a.S != 2) || (a.KS == 1 && a.S != 1))
-    VX_FAIL(VX_E_SHAPE, "vx_conv2d: kernel %d stride %d unsupported (3x3 s1/s2, 1x1 s1)", a.KS, a.S);
-  if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4)
-    VX_FAIL(VX_E_ALIGN, "vx_conv2d: pitches/offsets must be multiples of 4 floats and cover the channels");
-  if (!vx_aligned16(a.in) || !vx_aligned16(a.out) || !vx_aligned16(a.w_packed) || (a.bias && !vx_aligned16(a.bias)))
-    VX_FAIL(VX_E_ALIGN, "vx_conv2d: pointers must be 16-byte aligned");
-  Conv2dKArgs ka;
+// arguments validated by vx_conv2d (conv2d_mfma.hip)
+int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s) {
+  Conv2dSArgs ka;
   ka.a = a;
   ka.OH = (a.H + 2 * (a.KS / 2) - a.KS) / a.S + 1;
   ka.OW = (a.W + 2 * (a.KS / 2) - a.KS) / a.S + 1;
-  if ((int64_t)(a.H + 2) * a.W * a.in_pitch * 4 >= (1ll << 31) || (int64_t)ka.OH * ka.OW * a.out_pitch * 4 >= (1ll << 31))
-    VX_FAIL(VX_E_SHAPE, "vx_conv2d: one image must stay below 2 GiB");
-  if (c2_split16()) return vx_conv2d_s16(a, (hipStream_t)stream);
-  C2Cfg c = c2_config(a.KS, a.S, a.Cout);
+  const C2SCfg c = c2s_config(a.KS, a.S, a.Cout);
   ka.tiles_x = (ka.OW + 15) / 16;
   ka.tiles_y = (ka.OH + c.TY - 1) / c.TY;
   ka.nchunks = (a.Cin / 16 + c.NSUB - 1) / c.NSUB;
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
-  hipStream_t s = (hipStream_t)stream;
-  if (a.KS == 3 && a.S == 1) return dispatch_c2<3, 1, 1, 16>(ka, c.NT, s);
-  if (a.KS == 3 && a.S == 2) return dispatch_c2<3, 2, 1, 8>(ka, c.NT, s);
-  return dispatch_c2<1, 1, 4, 16>(ka, c.NT, s);
+  if (a.KS == 3 && a.S == 1) return dispatch_c2s<3, 1, 1, 16>(ka, c.NT, s);
+  if (a.KS == 3 && a.S == 2) return dispatch_c2s<3, 2, 1, 8>(ka, c.NT, s);
+  return dispatch_c2s<1, 1, 4, 16>(ka, c.NT, s);
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvalues_amd.so")
+LIB_PATH = os.environ.get("VX_LIB_PATH") or os.path.join(_HERE, "libvalues_amd.so")   # VX_LIB_PATH: A/B builds only
 
 VX_F32, VX_F64 = 0, 1
 VX_ACT_NONE, VX_ACT_LRELU, VX_ACT_RELU = 0, 1, 2

@@ -270,7 +270,35 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     const bool nhave = ntile < total;
     if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
 
-    {
+    if constexpr (XP == 1 && TX == 16 && TY % R == 0) {
+      // ---- x-pair, a wave's R column tiles are R consecutive y-rows of one z: the input row (z + kz, y) is the
+      // (ky = 0) operand of output row y, the (ky = 1) operand of y - 1 and the (ky = 2) operand of y - 2, so per kz
+      // the wave reads R + 2 row fragments once instead of 3 R -- the B-operand LDS traffic, which bounds this loop
+      // (one ds_read_b128 pair per 3 MFMAs against 128 B/clk per CU), drops by 3R / (R + 2).
+      const int p0 = vbase[0] + (g & 1) * PLANE + (g >> 1);   // row ly0, kz = ky = 0; x-offset ix = g
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        f16x8 bh[R + 2], bl[R + 2];
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) {
+          const int p = (p0 + (kz * HY + j) * HXP) * 8;
+          bh[j] = *reinterpret_cast<const f16x8*>(s_hi + p);
+          bl[j] = *reinterpret_cast<const f16x8*>(s_lo + p);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const _Float16* wp = s_w + ((((kz * 3 + ky) * NT) * 2) * 64 + lane) * 8;
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], acc[r][0], 0, 0, 0);
+            accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], accx[r][0], 0, 0, 0);
+            accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r][0], 0, 0, 0);
+          }
+        }
+      }
+    } else {
       // ---- NSTEP steps x 3 x R x NT MFMAs; fragments of step s + 1 are read before the MFMAs of step s ----
       f16x8 ah[2][NT], al[2][NT], bh[2][R], bl[2][R];
       auto load_step = [&](int s, int slot) {

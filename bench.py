@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--volumes", type=int, default=16, help="64^3 volumes per GPU per step")
+    ap.add_argument("--volumes", type=int, default=32, help="64^3 volumes per GPU per step")
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")

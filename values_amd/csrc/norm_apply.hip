@@ -142,6 +142,59 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
   }
 }
 
+// Fan-out variant (MC-dropout first layer: x_repeat = T samples share one source volume, no pooling): one thread
+// per SOURCE piece -- one load and one normalise + activation, then T dropout patterns and T fire-and-forget
+// stores.  The per-sample kernel above re-read and re-normalised the source T times with one 16-byte load in
+// flight per thread: latency-bound at 3.2 TB/s written; this one streams at the write roof.
+__global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args a, int x_repeat, NormDecode dc) {
+  const int C4 = a.C / 4;
+  const int PW = a.W * C4;
+  const int ns = blockIdx.y;
+  const size_t out_sample = (size_t)a.D * a.H * a.W * (a.out_xblk ? 2 * a.C : a.out_pitch);
+  const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < dc.per_sample; i += gridDim.x * 256u) {
+    const unsigned row = vx_magic_div(i, dc.mPW);
+    const int p = (int)(i - row * (unsigned)PW);
+    const int x = (int)vx_magic_div((unsigned)p, dc.mC4), c = (p - x * C4) * 4;
+    const int z = (int)vx_magic_div(row, dc.mH);
+    const int y = (int)(row - (unsigned)z * (unsigned)a.H);
+    f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (a.mean) {
+      mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)ns * a.C + c);
+      rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)ns * a.C + c);
+    }
+    const size_t svox = ((size_t)(ns * a.D + z) * a.H + y) * a.W + x;
+    f32x4 t0 = (*reinterpret_cast<const f32x4*>(a.x + svox * a.x_pitch + c) - mu) * rs;
+    if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t0[j] = fmaxf(t0[j], 0.01f * t0[j]);
+    } else if (a.act == VX_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t0[j] = fmaxf(t0[j], 0.f);
+    }
+    const uint32_t e = (uint32_t)(((z * a.H + y) * a.W + x) * a.C + c);
+    size_t off;   // float offset of the piece within a sample's output
+    if (a.out_xblk)
+      off = ((size_t)z * a.H + y) * (2 * (size_t)a.W * a.C) + ((((x >> xs) * 2 + a.out_half) << xs) + (x & (a.out_xblk - 1))) * a.C + c;
+    else
+      off = (((size_t)z * a.H + y) * a.W + x) * a.out_pitch + a.out_coff + c;
+    for (int k = 0; k < x_repeat; ++k) {
+      const int n = ns * x_repeat + k;
+      f32x4 t = t0;
+      if (a.drop_mode == VX_DROP_HASH) {
+        const uint32_t bits = vx_drop_bits4(vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n), e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+      } else if (a.drop_mode == VX_DROP_MASK) {
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (size_t)n * a.D * a.H * a.W * a.C + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * t[j] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.out + (size_t)n * out_sample + off) = t;
+    }
+  }
+}
+
 extern "C" int vx_norm_act_drop_pool(const vx_norm_args* ap, vx_stream_t stream) {
   return vx_norm_act_drop_pool_bcast(ap, 1, stream);
 }
@@ -188,7 +241,14 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
     int bx = (int)((per + 255) / 256);
     const int cap = (16384 + a.N - 1) / a.N;
     if (!pool && bx > cap) bx = cap > 0 ? cap : 1;
-    if (wide)
+    if (!pool && x_repeat > 1) {
+      if (a.N % x_repeat) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: N=%d is not a multiple of x_repeat=%d", a.N, x_repeat);
+      const int ns = a.N / x_repeat;
+      int fx = (int)((per + 255) / 256);
+      const int fcap = (32768 + ns - 1) / ns;
+      if (fx > fcap) fx = fcap;
+      hipLaunchKernelGGL(norm_act_drop_fanout_kernel, dim3(fx, ns), dim3(256), 0, s, a, x_repeat, dc);
+    } else if (wide)
       hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
     else if (pool)
       hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);

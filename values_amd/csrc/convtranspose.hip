@@ -150,8 +150,11 @@ __global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, i
 // a wave store whole 32/64/128-byte voxels of neighbouring output x.  A workgroup keeps the weights of RT row tiles
 // (blockIdx.y picks which) in registers for its whole life and walks column tiles with a grid stride.  The VALU
 // work left is the bias/activation/dropout epilogue, which leaves the kernel HBM-store-bound.
+struct ConvTDecode { unsigned mW, mH, mD; };   // 2^32 / d + 1 (0: d == 1); exact while v * d < 2^32 (launcher checks)
+__device__ __forceinline__ unsigned ct_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
+
 template <int CIN, int RT>
-__global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, int ncoltiles, int nvox_in) {
+__global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, int ncoltiles, int nvox_in, ConvTDecode dc) {
   constexpr int Q = CIN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
     const float* __restrict__ xin = a.in + (size_t)vc * a.in_pitch + 4 * g;
 #pragma unroll
     for (int q = 0; q < Q; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xin + 16 * q);
-    int r = vc;
-    const int x = r % a.W; r /= a.W;
-    const int y = r % a.H; r /= a.H;
-    const int z = r % a.D;
-    const int n = r / a.D;
+    unsigned r = (unsigned)vc, q;
+    q = ct_div(r, dc.mW); const int x = (int)(r - q * (unsigned)a.W); r = q;
+    q = ct_div(r, dc.mH); const int y = (int)(r - q * (unsigned)a.H); r = q;
+    q = ct_div(r, dc.mD); const int z = (int)(r - q * (unsigned)a.D);
+    const int n = (int)q;
     const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -236,10 +239,15 @@ static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   const int ncoltiles = (int)((nvox + 15) / 16);
   const int groups = (a.Cout / 2) / RT;          // 8 * Cout rows = Cout / 2 row tiles
   int bx = (ncoltiles + 3) / 4;
-  const int cap = (256 * 8 + groups - 1) / groups;
+  int per = 32;   // workgroups per CU in the grid: more, shorter address streams write faster (fill: 5.1 TB/s at 2048 WGs, 6.5 at 32768)
+  if (const char* e = getenv("VX_CONVT_WGS")) per = atoi(e) > 0 ? atoi(e) : per;
+  const int cap = (256 * per + groups - 1) / groups;
   if (bx > cap) bx = cap;
+  auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
+  ConvTDecode dc;
+  dc.mW = magic(a.W); dc.mH = magic(a.H); dc.mD = magic(a.D);
   hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
-                     ncoltiles, (int)nvox);
+                     ncoltiles, (int)nvox, dc);
   VX_CHECK_LAUNCH("vx_convT_k2s2(mfma)");
   return VX_OK;
 }
@@ -291,7 +299,10 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_convT_k2s2: mask mode without mask");
   if ((int64_t)a.D * a.H * a.W * 8 * a.Cout >= (1ll << 32)) VX_FAIL(VX_E_SHAPE, "vx_convT_k2s2: sample too large");
   // matrix-core kernel for the channel counts the networks use (row tiles per workgroup: weights stay in <= 128 VGPRs)
-  if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && !getenv("VX_CONVT_NO_MFMA")) {
+  // (flat voxel index * largest dimension < 2^32: the multiply-high divisions of the index decode are then exact)
+  const int64_t dmax = a.W > a.H ? (a.W > a.D ? a.W : a.D) : (a.H > a.D ? a.H : a.D);
+  if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && (int64_t)a.N * a.D * a.H * a.W * dmax < (1ll << 32) &&
+      !getenv("VX_CONVT_NO_MFMA")) {
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.Cout / 2;
     if (a.Cin == 16 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<16, 4>(a, s) : launch_convT_mfma<16, 8>(a, s);

@@ -148,12 +148,7 @@ def test_conv3d_k3_fused_head_matches_separate_kernels(cin, shape, ncls, xb, con
     """expand_1_2 + final (unet3D_module.py:365) in one launch: equal to vx_conv3d_k3 followed by
     vx_conv1x1_ncdhw (bit-identical on the 4x4x1 kernel), including the slot scatter and the TTA un-flip (test_3D.py:445-447)"""
     lib = _lib.load()
-    if conv_mode != "fp32":
-        os.environ["VX_S16_HEAD"] = "1"            # opt-in on the x-pair split-fp16 kernel (no measured gain there)
-    try:
-        _fused_head_case(lib, cin, shape, ncls, xb, conv_mode)
-    finally:
-        os.environ.pop("VX_S16_HEAD", None)
+    _fused_head_case(lib, cin, shape, ncls, xb, conv_mode)
 
 
 def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):

@@ -619,6 +619,8 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.head_out) {
     if (!a.head_w || !a.head_b) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: fused head without weights");
     if (a.head_C < 1 || a.head_C > 8) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: fused head takes 1..8 classes, got %d", a.head_C);
+    if (conv_config(a.Cin, a.Cout).S16 && a.head_C > 4)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the split-fp16 kernel fuses heads of up to 4 classes, got %d", a.head_C);
     if (!vx_conv3d_k3_head_fusable(a.Cin, a.Cout))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: no fused head for Cin=%d Cout=%d (see vx_conv3d_k3_head_fusable)", a.Cin, a.Cout);
     if (a.stats_partial) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: fused head on a layer with InstanceNorm statistics");

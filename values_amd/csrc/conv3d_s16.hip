@@ -250,6 +250,21 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     bias4[nt] = cvalid[nt] ? *reinterpret_cast<const f32x4*>(a.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  // fused head (x-pair only): this lane's 4 of the 8 weights of up to HC classes; the bias rides in the g-even lane
+  constexpr int HC = XP ? 4 : 1;
+  float hw4[HC][4], hb[HC];
+#pragma unroll
+  for (int c = 0; c < HC; ++c) {
+    hb[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hw4[c][k] = 0.f;
+    if (XP && a.head_out && c < a.head_C) {
+      if (!(g & 1)) hb[c] = a.head_b[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hw4[c][k] = a.head_w[c * 8 + (g & 1) * 4 + k];
+    }
+  }
+
   int tile_lin = blockIdx.x, chunk = 0;
   if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
@@ -350,6 +365,13 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       const __amdgpu_buffer_rsrc_t osrd =
           __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
       const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+      const size_t hnvox = (size_t)a.D * a.H * a.W;
+      int hflip = 0;
+      float* hbase = nullptr;
+      if (XP && a.head_out) {
+        hflip = a.head_flip ? a.head_flip[n] : 0;
+        hbase = a.head_out + (size_t)(a.head_dst ? a.head_dst[n] : n) * a.head_C * hnvox;
+      }
 
       float ssum[NT][4], ssq[NT][4];
 #pragma unroll
@@ -388,24 +410,25 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
           }
           if (XP && a.head_out) {
             // fused 1x1x1 head (conv1x1.hip): this lane holds channels 4 (g & 1) .. + 3 of voxel 2p + (g >> 1), the
-            // lane 16 further (g ^ 1) the other four -- one cross-lane add per class, then the g-even lane stores.
-            // Summation order differs from conv1x1.hip's single chain (two partial chains + one add): not bit-equal.
+            // lane 16 further (g ^ 1) the other four -- one cross-lane add per class, then the g-even lane stores
+            // (a wave's stores of one class cover 32 consecutive voxels).  The lane's 4 weights per class and the
+            // bias were selected once per workgroup (hw4 / hb).  Two partial chains + one add: not bit-equal to
+            // conv1x1.hip's single chain.
             const int vv = (wave * R + r) * 16 + m;
             int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
-            const int f = a.head_flip ? a.head_flip[n] : 0;
-            if (f & 1) gz = a.D - 1 - gz;
-            if (f & 2) gy = a.H - 1 - gy;
-            if (f & 4) gx = a.W - 1 - gx;
-            const size_t nvox = (size_t)a.D * a.H * a.W;
-            const int slot = a.head_dst ? a.head_dst[n] : n;
-            float* o = a.head_out + (size_t)slot * a.head_C * nvox + ((size_t)gz * a.H + gy) * a.W + gx;
-            const int k0 = (g & 1) * 4;
-            for (int c = 0; c < a.head_C; ++c) {
-              float part = (g & 1) ? 0.f : a.head_b[c];
+            if (hflip & 1) gz = a.D - 1 - gz;
+            if (hflip & 2) gy = a.H - 1 - gy;
+            if (hflip & 4) gx = a.W - 1 - gx;
+            float* o = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
 #pragma unroll
-              for (int k = 0; k < 4; ++k) part = fmaf(a.head_w[c * 8 + k0 + k], v[k], part);
-              part += __shfl_xor(part, 16, 64);
-              if (!bad && !(g & 1)) o[(size_t)c * nvox] = part;
+            for (int c = 0; c < HC; ++c) {
+              if (c < a.head_C) {
+                float part = hb[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part = fmaf(hw4[c][k], v[k], part);
+                part += __shfl_xor(part, 16, 64);
+                if (!bad && !(g & 1)) o[(size_t)c * hnvox] = part;
+              }
             }
           }
           if (a.out) {
@@ -562,23 +585,10 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
 }
 
 // tiles = those of conv3d_mfma.hip's tile_config (tx columns per row: 16 / 8 / 4 by W, or by W / 2 for x-pair)
-// measured: no gain over the separate conv1x1 kernel (1647 vs 1654 volumes/s) -- the per-class cross-lane adds and the
-// stride-2 logit stores cost what the saved feature-map round trip buys; kept, off unless VX_S16_HEAD=1
-// Tile of a layer: tx columns per row (16 / 8 / 4 by W, or by W / 2 for x-pair) as in conv3d_mfma.hip; large layers
-// (H >= 32) take 16 x 8 x 4 tiles = 4 column tiles per wave: the halo read per output voxel drops from 2.5x to 2.1x
-// and the per-item costs (barriers, decode, masks) halve -- +14..20 % on the 64^3 layers; small layers keep
-// 16 x 4 x 4 so that the 256 CUs still get enough work items.
-void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
-  const int xp = s16_config(8, Cout).XP;
-  const int wcols = xp ? W / 2 : W;
-  const int tx = wcols >= 16 ? 16 : (wcols >= 8 ? 8 : 4);
-  const bool ty8 = tx == 16 && H >= 32 && !getenv("VX_S16_NO_TY8");
-  *txv = xp ? 2 * tx : tx;
-  *ty = (tx == 8 || ty8) ? 8 : 4;
-  *tz = 4;
-}
-
-bool vx_conv3d_s16_head_fusable(int Cin, int Cout) { return s16_config(Cin, Cout).XP != 0 && getenv("VX_S16_HEAD") != nullptr; }
+// +2.6 % end to end over the separate conv1x1 kernel (2088 vs 2036 volumes/s) once the lane's weights are hoisted out of
+// the item loop; a first version with per-piece weight loads measured no gain.  VX_NO_HEAD_FUSION=1 (forward) disables it.
+bool vx_conv3d_s16_head_fusable(int Cin, int Cout) { return s16_config(Cin, Cout).XP != 0; }
+int vx_conv3d_s16_head_max_classes() { return 4; }
 
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   const S16Cfg c = s16_config(a.Cin, a.Cout);

@@ -136,7 +136,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
 
   auto xblk_of = [](int W) { return W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); };
   // head fusion: where the last 3x3x3 conv runs on the kernel that holds a voxel's channels in one lane
-  const bool fuse_head = NC <= 8 && vx_conv3d_k3_head_fusable(F, F) && !getenv("VX_NO_HEAD_FUSION");
+  const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !getenv("VX_NO_HEAD_FUSION");
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk) {
     vx_conv3d_args a;

@@ -37,6 +37,7 @@ struct ConvSArgs {
   unsigned mx, my, mz;
   int no_xcd;
   int ty8;   // 16 x 8 x 4 tiles (vx_conv3d_s16_tile)
+  int w_all; // every chunk's weights fit in LDS next to the image: staged once, never re-staged per item
   int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
 };
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   _Float16* s_hi = reinterpret_cast<_Float16*>(smem_raw);
   _Float16* s_lo = s_hi + IMG_H;
   _Float16* s_w = s_hi + 2 * IMG_H;
-  float* s_red = reinterpret_cast<float*>(smem_raw + IN_BYTES + W_H * 2);
+  float* s_red = reinterpret_cast<float*>(smem_raw + IN_BYTES + (size_t)(ka.w_all ? ka.nchunks : 1) * W_H * 2);
 
   const vx_conv3d_args& a = ka.a;
   const int tid = threadIdx.x;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   const f32x4* w_cg = reinterpret_cast<const f32x4*>(a.w_packed) + (size_t)cg * ka.nchunks * (W_H / 8);
   f32x4 ibuf[IN_IT];
   f32x4 wbuf[W_IT];
-  const bool w_resident = ka.nchunks == 1;
+  const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
 
   auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w) {
@@ -265,10 +266,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     }
   }
 
+  if (ka.w_all && ka.nchunks > 1) {   // all chunks' weights resident: one cooperative copy for the kernel's life
+    for (int i = tid; i < ka.nchunks * (W_H / 8); i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = w_cg[i];
+  }
   int tile_lin = blockIdx.x, chunk = 0;
   if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
-  prefetch(tile_lin, 0, have, true);
+  prefetch(tile_lin, 0, have, !(ka.w_all && ka.nchunks > 1));
+  if (ka.w_all && ka.nchunks > 1) w_fresh = false;
   f32x4 acc[R][NT], accx[R][NT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
     const bool nhave = ntile < total;
     if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+    const _Float16* s_wc = s_w + (ka.w_all ? chunk * W_H : 0);   // this item's weights
 
     if constexpr (XP == 1 && TX == 16 && TY % R == 0) {
       // ---- x-pair, a wave's R column tiles are R consecutive y-rows of one z: the input row (z + kz, y) is the
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const _Float16* wp = s_w + ((((kz * 3 + ky) * NT) * 2) * 64 + lane) * 8;
+          const _Float16* wp = s_wc + ((((kz * 3 + ky) * NT) * 2) * 64 + lane) * 8;
           const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
           const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
 #pragma unroll
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       auto load_step = [&](int s, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const _Float16* wp = s_w + (((s * NT + nt) * 2) * 64 + lane) * 8;
+          const _Float16* wp = s_wc + (((s * NT + nt) * 2) * 64 + lane) * 8;
           ah[slot][nt] = *reinterpret_cast<const f16x8*>(wp);
           al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
         }
@@ -549,19 +555,23 @@ int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Co
 }
 
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
-static int launch_s16(const ConvSArgs& ka, hipStream_t s) {
+static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   constexpr int TXV = XP ? 2 * TX : TX;
   constexpr int NHALO = (TXV + 2) * (TY + 2) * (TZ + 2);
   constexpr int PLANE = (((XP ? NHALO / 2 : NHALO) + 15) / 16) * 16;
   constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
-  constexpr size_t lds = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)NW * NT * 16 * 2 * 4;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * 64 * 8 * 2;
+  constexpr size_t red = (size_t)NW * NT * 16 * 2 * 4;
+  static_assert(img + wch + red <= 160 * 1024, "LDS budget");
+  ConvSArgs ka = ka_in;
+  ka.w_all = (ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0;
+  const size_t lds = img + (ka.w_all ? ka.nchunks : 1) * wch + red;
   auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(s16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    attr_set = true;
+    attr_lds = lds;
   }
   const vx_conv3d_args& a = ka.a;
   const int total_tiles = ka.tiles_x * ka.tiles_y * ka.tiles_z * a.N;

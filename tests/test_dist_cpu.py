@@ -59,8 +59,8 @@ def _worker_pipeline(rank, world, port, q):
         for v in maps.values():
             v.zero_() if v.is_contiguous() else None    # the caller may reuse its tensors right away
         if r is not None:
-            got.append(r)
-    got += [r for r in pipe.flush() if r is not None]
+            got.append({k: v.clone() for k, v in r.items()})   # views of a receive buffer: valid until it is reused
+    got += [{k: v.clone() for k, v in r.items()} for r in pipe.flush() if r is not None]   # (no submit in between)
     if rank == 0:
         ok = len(got) == 5
         for step, res in enumerate(got):

@@ -88,20 +88,25 @@ class MapGatherPipeline:
             self._inflight.append((slot, out))
             return done
         import torch.distributed as dist
-        f, seg = pack_maps(out)
-        if self._send[slot] is None or self._send[slot][0].shape != f.shape:
-            self._send[slot] = (torch.empty_like(f), torch.empty_like(seg))
-            if self.rank == self.dst:
-                self._recv[slot] = ([torch.empty_like(f) for _ in range(self.world)],
-                                    [torch.empty_like(seg) for _ in range(self.world)])
+        parts = [out[k].unsqueeze(1) for k in MAP_KEYS] + [out["mean_softmax"]]
+        seg = out["pred_seg_mean"]
+        fshape = (seg.shape[0], sum(p.shape[1] for p in parts)) + tuple(seg.shape[1:])
+        if self._send[slot] is None or tuple(self._send[slot][0].shape) != fshape:
+            self._send[slot] = (torch.empty(fshape, dtype=torch.float32, device=seg.device), torch.empty_like(seg))
+            if self.rank == self.dst:   # one contiguous receive buffer per dtype: the gathered result is a VIEW of it
+                self._recv[slot] = (torch.empty((self.world,) + fshape, dtype=torch.float32, device=seg.device),
+                                    torch.empty((self.world,) + tuple(seg.shape), dtype=seg.dtype, device=seg.device))
         sf, ss = self._send[slot]
-        sf.copy_(f); ss.copy_(seg)           # the step's own tensors may be reused by the next step
-        rl = self._recv[slot] if self.rank == self.dst else (None, None)
+        torch.cat(parts, dim=1, out=sf)      # pack straight into the send buffer (the step's tensors may be reused)
+        ss.copy_(seg)
+        rl = (list(self._recv[slot][0].unbind(0)), list(self._recv[slot][1].unbind(0))) if self.rank == self.dst else (None, None)
         works = [dist.gather(sf, rl[0], dst=self.dst, async_op=True), dist.gather(ss, rl[1], dst=self.dst, async_op=True)]
         self._inflight.append((slot, works))
         return done
 
     def collect(self) -> Optional[Dict[str, torch.Tensor]]:
+        """Maps of the oldest gather in flight (dst) / None.  The returned tensors are views of the slot's receive
+        buffer: valid until `depth` further submits."""
         if not self._inflight:
             return None
         slot, works = self._inflight.pop(0)
@@ -111,7 +116,8 @@ class MapGatherPipeline:
             w.wait()
         if self.rank != self.dst:
             return None
-        return unpack_maps(torch.cat(self._recv[slot][0], 0), torch.cat(self._recv[slot][1], 0))
+        rf, rs = self._recv[slot]
+        return unpack_maps(rf.view((-1,) + tuple(rf.shape[2:])), rs.view((-1,) + tuple(rs.shape[2:])))
 
     def flush(self) -> List[Optional[Dict[str, torch.Tensor]]]:
         res = []

@@ -280,8 +280,33 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+  int pend_n = -1, pend_tile = 0;   // tile whose per-wave statistics sit in s_red, not yet combined
+  auto flush_stats = [&]() {
+    if (pend_n >= 0 && tid < NT * 16) {
+      const int nt = tid / 16, c = tid % 16;
+      const int co = XP ? c : (cg * NT + nt) * 16 + c;   // x-pair: rows c and c + 8 are the two x of channel c
+      if (co < a.Cout && (!XP || c < 8)) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
+          q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+          if (XP) {
+            s += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 0];
+            q += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 1];
+          }
+        }
+        float* dst = a.stats_partial + (((size_t)pend_n * ntiles + pend_tile) * a.Cout + co) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+    pend_n = -1;
+  };
+
   while (have) {
     if (ka.dbg < 3) __syncthreads();
+    flush_stats();
     if (ka.dbg < 2) commit(w_fresh);
     if (ka.dbg < 3) __syncthreads();
     w_fresh = !w_resident;
@@ -464,27 +489,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
               s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
             }
           }
-        __syncthreads();
-        if (tid < NT * 16) {
-          const int nt = tid / 16, c = tid % 16;
-          const int co = XP ? c : (cg * NT + nt) * 16 + c;   // x-pair: rows c and c + 8 are the two x of channel c
-          if (co < a.Cout && (!XP || c < 8)) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
-              q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
-              if (XP) {
-                s += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 0];
-                q += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 1];
-              }
-            }
-            const int tile = tile_lin - n * ntiles;
-            float* dst = a.stats_partial + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
-            dst[0] = s;
-            dst[1] = q;
-          }
-        }
+        // the cross-wave sum and the global write wait for the NEXT barrier of the item loop (flush_stats): no
+        // extra barrier in the epilogue
+        pend_n = n;
+        pend_tile = tile_lin - n * ntiles;
       }
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -493,6 +501,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     }
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
+  __syncthreads();
+  flush_stats();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -104,6 +104,7 @@ def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=Fals
     (16, 16, (1, 3, 5, 9)),   # ragged small
     (8, 8, (2, 8, 8, 64)), (16, 8, (1, 4, 4, 32)), (16, 8, (1, 5, 7, 38)),  # x-pair packing, full and ragged tiles
     (8, 8, (1, 3, 3, 7)), (16, 8, (2, 2, 2, 2)),                            # x-pair, odd width / tiny
+    (8, 8, (1, 5, 37, 70)), (16, 8, (1, 4, 33, 40)), (16, 16, (1, 6, 35, 18)), (32, 32, (1, 4, 40, 16)),  # H >= 32: 16x8x4 tiles, ragged
 ])
 def test_conv3d_k3_matches_oracle(cin, cout, shape, conv_mode):
     n, d, h, w = shape
@@ -218,7 +219,8 @@ def test_conv3d_k3_epilogue_act_mask_pitch(conv_mode):
 
 
 @pytest.mark.parametrize("c,cout,shape,xb", [(8, 8, (2, 8, 8, 32), 4), (16, 16, (1, 4, 8, 16), 4), (32, 32, (1, 4, 4, 8), 4),
-                                             (64, 64, (1, 6, 6, 6), 2), (8, 8, (1, 3, 5, 7), 1), (16, 16, (1, 4, 4, 12), 4)])
+                                             (64, 64, (1, 6, 6, 6), 2), (8, 8, (1, 3, 5, 7), 1), (16, 16, (1, 4, 4, 12), 4),
+                                             (8, 8, (1, 4, 34, 36), 4), (16, 16, (1, 3, 33, 20), 4)])
 def test_conv3d_k3_reads_xblocked_concat(c, cout, shape, xb, conv_mode):
     """decoder conv on cat([up, skip]) (unet3D_module.py:332-334) reading the two halves from the x-blocked buffer"""
     n, d, h, w = shape

@@ -108,10 +108,10 @@ def test_hrnet_hash_dropout_and_properties():
     yf = m.forward_samples(xf, 1, seeds=[5], hflip_back=True)
     yn = m.forward_samples(xf, 1, seeds=[5])
     assert torch.equal(yf, torch.flip(yn, [-1]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # unsupported variants raise instead of falling back
         from values_amd.hrnet import HighResolutionNet
         cfg = small_cfg()
-        cfg["MODEL"]["EXTRA"] = dict(cfg["MODEL"]["EXTRA"], STAGE2=dict(cfg["MODEL"]["EXTRA"]["STAGE2"], NUM_CHANNELS=[18, 36]))
+        cfg["MODEL"]["ALIGN_CORNERS"] = True
         HighResolutionNet(cfg)
 
 
@@ -188,3 +188,34 @@ def test_hrnet_ssn_head_matches_reference_fixture():
     mean = d0.mean.reshape(B, 1, 4, 64, 96)
     zz = ((z - mean) / torch.from_numpy(g["cov_diag"]).cuda().reshape(B, 1, 4, 64, 96).sqrt()).reshape(-1)
     assert abs(zz.mean().item()) < 0.01 and abs(zz.var().item() - 1.0) < 0.01
+
+
+def test_hrnet_w18_widths_match_reference_fixture():
+    """HRNet-W18 widths (18/36/72/144, 270 concatenated, 5 classes): the zero-padded round16(C) layout of the HIP
+    path gives the reference's logits, with DROPOUT_FINAL masks and without"""
+    from values_amd.formula import HRNET_W18S_EXTRA
+    from values_amd.hrnet import HighResolutionNet
+    g = load_npz("hrnet_w18s.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    x = torch.from_numpy(g["input"]).cuda()
+    for dropout_final in (True, False):
+        cfg = {"MODEL": {"EXTRA": dict(HRNET_W18S_EXTRA, DROPOUT_FINAL=dropout_final), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+               "DATASET": {"NUM_CLASSES": 5}}
+        m = HighResolutionNet(cfg)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+        m.load_state_dict(sd, strict=False)
+        m = m.cuda()
+        if dropout_final:
+            masks = []
+            for t in range(2):
+                per = []
+                for i in range(4):
+                    shape = tuple(int(v) for v in g[f"maskshape_{i}"])
+                    per.append(torch.from_numpy(np.unpackbits(g[f"mask_{t}_{i}"])[:int(np.prod(shape))].astype(bool).reshape(shape)))
+                masks.append(per)
+            y = m.forward_samples(x, 2, dropout_masks=masks).cpu().numpy()
+            assert np.abs(y - g["logits"]).max() < 5e-5, np.abs(y - g["logits"]).max()
+        else:
+            y = m(x).cpu().numpy()
+            assert np.abs(y - g["logits_nodrop"]).max() < 5e-5

@@ -285,3 +285,24 @@ def test_hrnet_ssn_oracle_matches_reference():
     eps_d = formula_tensor(g["samples"].shape, tag=int(g["eps_d_tag"]), scale=1.7).astype(np.float32)
     smp = lowrank_rsample(loc.numpy(), diag.numpy(), fac.numpy(), g["eps_w"], eps_d)
     assert np.abs(smp - g["samples"]).max() < 1e-4
+
+
+def test_hrnet_w18_widths_oracle_matches_reference():
+    """HRNet-W18 widths (18/36/72/144 -> 270; BASELINE config 4): none is a multiple of 16"""
+    import json as _json
+    from oracle.hrnet_oracle import hrnet_forward
+    from values_amd.formula import HRNET_W18S_EXTRA, formula_state_dict_from_shapes
+    g = load_npz("hrnet_w18s.npz")
+    shapes = _json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    x = torch.from_numpy(g["input"])
+    with torch.no_grad():
+        for t in range(2):
+            masks = []
+            for i in range(4):
+                shape = tuple(int(v) for v in g[f"maskshape_{i}"])
+                masks.append(torch.from_numpy(np.unpackbits(g[f"mask_{t}_{i}"])[:int(np.prod(shape))].astype(bool).reshape(shape)))
+            y = hrnet_forward(HRNET_W18S_EXTRA, sd, x, dropout_masks=masks).numpy()
+            assert np.abs(y - g["logits"][t]).max() < 2e-5
+        y = hrnet_forward(dict(HRNET_W18S_EXTRA, DROPOUT_FINAL=False), sd, x).numpy()
+        assert np.abs(y - g["logits_nodrop"]).max() < 2e-5

@@ -3,7 +3,7 @@
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from values_amd.formula import hrnet_w48_extra
+from values_amd.formula import hrnet_w18_extra, hrnet_w48_extra
 from values_amd.hrnet import HighResolutionNet
 
 ap = argparse.ArgumentParser()
@@ -12,9 +12,12 @@ ap.add_argument("--T", type=int, default=4)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--h", type=int, default=256)
 ap.add_argument("--w", type=int, default=478)
+ap.add_argument("--width", type=int, default=48, choices=(18, 48), help="HRNet-W48 (shipped configs) or W18 (BASELINE config 4)")
+ap.add_argument("--classes", type=int, default=24)
 args = ap.parse_args()
-cfg = {"MODEL": {"EXTRA": hrnet_w48_extra(True), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
-       "DATASET": {"NUM_CLASSES": 24}}
+extra = hrnet_w48_extra(True) if args.width == 48 else hrnet_w18_extra(True)
+cfg = {"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+       "DATASET": {"NUM_CLASSES": args.classes}}
 torch.manual_seed(0)
 m = HighResolutionNet(cfg).cuda()
 x = torch.randn(args.batch, 3, args.h, args.w, device="cuda")

@@ -376,6 +376,56 @@ def gen_hrnet_ssn():
           float(samples.min()), float(samples.max()), "diag range", float(dist.cov_diag.min()), float(dist.cov_diag.max()))
 
 
+def gen_hrnet_w18():
+    """G10 hrnet_w18s.npz: the reference HighResolutionNet at the HRNet-W18 widths (18/36/72/144, 270 concatenated;
+    BASELINE config 4), 5 classes, training-mode BN, two passes with DROPOUT_FINAL masks captured + one without."""
+    import copy
+    import uncertainty_modeling.models.hrnet_module as ref_hr
+    from values_amd.formula import HRNET_W18S_EXTRA, formula_state_dict_from_shapes
+    extra = copy.deepcopy(HRNET_W18S_EXTRA)
+    ncls = 5
+    cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+                "DATASET": {"NUM_CLASSES": ncls}})
+    model = ref_hr.HighResolutionNet(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    for k, v in formula_state_dict_from_shapes(shapes).items():
+        full[k] = torch.from_numpy(v).float()
+    model.load_state_dict(full)
+    x = torch.from_numpy(formula_tensor((2, 3, 64, 96), tag=85, scale=1.5)).float()
+    masks = []
+    orig = F.dropout
+
+    def spy(inp, p=0.5, training=True, inplace=False):
+        out = orig(inp, p, training, inplace)
+        masks.append(((out != 0) | (inp == 0)).clone())
+        return out
+
+    ref_hr.F.dropout = spy
+    out = {"input": x.numpy(), "shapes_json": np.frombuffer(json.dumps({k: list(v) for k, v in shapes.items()}).encode(), dtype=np.uint8)}
+    torch.set_grad_enabled(False)
+    logits = []
+    for t in range(2):
+        masks.clear()
+        logits.append(model.forward(x).numpy().copy())
+        for i, m in enumerate(masks):
+            out[f"mask_{t}_{i}"] = np.packbits(m.numpy().astype(np.uint8).ravel())
+            out[f"maskshape_{i}"] = np.array(m.shape)
+    ref_hr.F.dropout = orig
+    out["logits"] = np.stack(logits)
+    extra2 = copy.deepcopy(extra)
+    extra2["DROPOUT_FINAL"] = False
+    cfg2 = _Cfg({"MODEL": {"EXTRA": extra2, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+                 "DATASET": {"NUM_CLASSES": ncls}})
+    m2 = ref_hr.HighResolutionNet(cfg2)
+    m2.load_state_dict(full)
+    out["logits_nodrop"] = m2.forward(x).numpy()
+    torch.set_grad_enabled(True)
+    np.savez_compressed(os.path.join(OUT, "hrnet_w18s.npz"), **out)
+    print("G10 hrnet_w18s.npz", out["logits"].shape, os.path.getsize(os.path.join(OUT, "hrnet_w18s.npz")) / 1e6, "MB; logit range",
+          float(out["logits"].min()), float(out["logits"].max()))
+
+
 def gen_ssn():
     """G7 ssn_16.npz: the reference SsnUNet3D (ssn_unet3D_module.py) + distribution.sample as predict_cases_ssn
     calls it (test_3D.py:373-385), with the standard normals of LowRankMultivariateNormal.rsample replaced by
@@ -504,7 +554,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn", "hrnet_w18"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -525,3 +575,5 @@ if __name__ == "__main__":
         gen_metrics()
     if "hrnet_ssn" in which:
         gen_hrnet_ssn()
+    if "hrnet_w18" in which:
+        gen_hrnet_w18()

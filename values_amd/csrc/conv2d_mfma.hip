@@ -387,11 +387,13 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
   const vx_conv2d_args& a = *ap;
   if (!a.in || !a.w_packed || !a.out) VX_FAIL(VX_E_NULL, "vx_conv2d: null tensor pointer");
   if (a.N <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv2d: empty tensor");
-  if (a.Cin <= 0 || a.Cin % 16 || a.Cout <= 0 || a.Cout % 4)
-    VX_FAIL(VX_E_SHAPE, "vx_conv2d: Cin=%d must be a multiple of 16 (pad the input), Cout=%d a multiple of 4", a.Cin, a.Cout);
+  if (a.Cin <= 0 || a.Cin % 16 || a.Cout <= 0)
+    VX_FAIL(VX_E_SHAPE, "vx_conv2d: Cin=%d must be a positive multiple of 16 (pad the input), Cout=%d positive", a.Cin, a.Cout);
   if ((a.KS != 1 && a.KS != 3) || (a.S != 1 && a.S != 2) || (a.KS == 1 && a.S != 1))
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: kernel %d stride %d unsupported (3x3 s1/s2, 1x1 s1)", a.KS, a.S);
-  if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4)
+  // outputs leave as 16-byte groups of 4 channels: a Cout that is not a multiple of 4 writes its last group up to
+  // round4(Cout) (zeros beyond Cout), which the pitch must cover
+  if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + (a.Cout + 3) / 4 * 4 || a.out_pitch % 4 || a.out_coff % 4)
     VX_FAIL(VX_E_ALIGN, "vx_conv2d: pitches/offsets must be multiples of 4 floats and cover the channels");
   if (!vx_aligned16(a.in) || !vx_aligned16(a.out) || !vx_aligned16(a.w_packed) || (a.bias && !vx_aligned16(a.bias)))
     VX_FAIL(VX_E_ALIGN, "vx_conv2d: pointers must be 16-byte aligned");

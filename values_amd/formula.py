@@ -160,6 +160,19 @@ HRNET_SMALL_EXTRA = {
 }
 
 
+HRNET_W18S_EXTRA = {   # HRNet-W18 widths (BASELINE config 4) with fewer blocks / modules: none is a multiple of 16
+    "DROPOUT_FINAL": True, "FINAL_CONV_KERNEL": 1,
+    "STAGE1": {"NUM_MODULES": 1, "NUM_BRANCHES": 1, "BLOCK": "BOTTLENECK", "NUM_BLOCKS": [1], "NUM_CHANNELS": [32],
+               "FUSE_METHOD": "SUM"},
+    "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "BLOCK": "BASIC", "NUM_BLOCKS": [1, 1], "NUM_CHANNELS": [18, 36],
+               "FUSE_METHOD": "SUM"},
+    "STAGE3": {"NUM_MODULES": 1, "NUM_BRANCHES": 3, "BLOCK": "BASIC", "NUM_BLOCKS": [1, 1, 1],
+               "NUM_CHANNELS": [18, 36, 72], "FUSE_METHOD": "SUM"},
+    "STAGE4": {"NUM_MODULES": 1, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [1, 1, 1, 1],
+               "NUM_CHANNELS": [18, 36, 72, 144], "FUSE_METHOD": "SUM"},
+}
+
+
 def hrnet_w48_extra(dropout_final=True):
     """The shipped configs/model/hrnet_config*.yaml layout (W48)."""
     return {
@@ -173,3 +186,12 @@ def hrnet_w48_extra(dropout_final=True):
         "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4, 4],
                    "NUM_CHANNELS": [48, 96, 192, 384], "FUSE_METHOD": "SUM"},
     }
+
+
+def hrnet_w18_extra(dropout_final=True):
+    """The public HRNet-W18 layout (BASELINE config 4): widths 18/36/72/144, same blocks/modules as W48."""
+    e = hrnet_w48_extra(dropout_final)
+    e["STAGE2"]["NUM_CHANNELS"] = [18, 36]
+    e["STAGE3"]["NUM_CHANNELS"] = [18, 36, 72]
+    e["STAGE4"]["NUM_CHANNELS"] = [18, 36, 72, 144]
+    return e

@@ -110,10 +110,10 @@ class _HRModule(nn.Module):
 
 class _Act:
     """A channels-last activation: tensor [N, H, W, pitch] whose channels [0, C) are valid."""
-    __slots__ = ("t", "C")
+    __slots__ = ("t", "C", "real_c")
 
     def __init__(self, t, c):
-        self.t, self.C = t, c
+        self.t, self.C, self.real_c = t, c, c
 
     @property
     def N(self):
@@ -130,6 +130,19 @@ class _Act:
     @property
     def pitch(self):
         return self.t.shape[3]
+
+
+def _r16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+def _pad_mask(m: torch.Tensor, dev) -> torch.Tensor:
+    """(B, C, H, W) bool keep-mask -> channels-last uint8 with the channel padding of the activations"""
+    t = m.to(dev).permute(0, 2, 3, 1).to(torch.uint8)
+    c = t.shape[-1]
+    if c % 16:
+        t = torch.nn.functional.pad(t, (0, _r16(c) - c))
+    return t.contiguous()
 
 
 class LowRankNormal2D:
@@ -240,9 +253,9 @@ class HighResolutionNet(nn.Module):
         if self.ssn:   # hrnet_module.py:436-453
             self.cov_factor_conv = nn.Sequential(nn.Conv2d(last, last, 1), nn.BatchNorm2d(last), nn.ReLU(inplace=True),
                                                  nn.Conv2d(last, self.num_classes * self.rank, 1))
-        for w in [64, last] + [c for si in (1, 2, 3, 4) for c in self.extra[f"STAGE{si}"]["NUM_CHANNELS"]]:
-            if w % 16:
-                raise NotImplementedError(f"values_amd.HighResolutionNet: width {w} is not a multiple of 16 (HIP path limit)")
+        # widths that are not multiples of 16 (HRNet-W18: 18/36/72/144, 270 concatenated) run zero-padded: every
+        # activation tensor has round16(C) channels whose tail is exactly 0 (zero weight rows, zero BN scale/shift)
+        self._last_parts = list(pre)
         self._packed, self._packed_key = None, None
         self.seed, self._calls = 123, 0
 
@@ -276,6 +289,16 @@ class HighResolutionNet(nn.Module):
         for name, mod in self.named_modules():
             if isinstance(mod, nn.Conv2d):
                 w = mod.weight.detach().to(dev, torch.float32).contiguous()
+                if name in ("last_layer.0", "cov_factor_conv.0") and any(c % 16 for c in self._last_parts):
+                    # the head reads the concat of the four PADDED stage-4 tensors: spread the input channels
+                    wpad = torch.zeros((w.shape[0], sum(_r16(c) for c in self._last_parts)) + tuple(w.shape[2:]),
+                                       dtype=torch.float32, device=dev)
+                    src = dst = 0
+                    for c in self._last_parts:
+                        wpad[:, dst:dst + c] = w[:, src:src + c]
+                        src += c
+                        dst += _r16(c)
+                    w = wpad.contiguous()
                 cout, cin, ks, _ = w.shape
                 wp = torch.empty(lib.vx_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=dev)
                 _lib.check(lib.vx_pack_conv2d(_lib.ptr(w), _lib.ptr(wp), cin, cout, ks, st), "vx_pack_conv2d")
@@ -300,7 +323,11 @@ class HighResolutionNet(nn.Module):
         oh = (h + 2 * (ks // 2) - ks) // stride + 1
         ow = (w + 2 * (ks // 2) - ks) // stride + 1
         pitch = (cout + 3) // 4 * 4
-        out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
+        if cout % 16 and stats:     # feeds another conv: keep the zero-padded round16(C) layout (see __init__)
+            pitch = _r16(cout)
+            out = torch.zeros((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
+        else:
+            out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
         part = None
         a = _lib.Conv2dArgs()
         a.in_ = x.t.data_ptr(); a.in_pitch = x.pitch; a.w_packed = wp.data_ptr()
@@ -313,15 +340,19 @@ class HighResolutionNet(nn.Module):
             a.stats_partial = part.data_ptr()
         _lib.check(lib.vx_conv2d(C.byref(a), self._st), "vx_conv2d " + name)
         self._hold += [out, part]
-        return _Act(out, cout), part, ntiles
+        act = _Act(out, pitch if (cout % 16 and stats) else cout)
+        act.real_c = cout
+        return act, part, ntiles
 
     def _conv_bn(self, x: _Act, conv_name, bn_name):
         lib = _lib.load()
         raw, part, ntiles = self._conv(x, conv_name)
         gamma, beta = self._pk[bn_name]
-        scale = torch.empty(raw.C, dtype=torch.float32, device=raw.t.device)
-        shift = torch.empty(raw.C, dtype=torch.float32, device=raw.t.device)
-        _lib.check(lib.vx_bn_finalize(_lib.ptr(part), ntiles, raw.C, raw.N * raw.H * raw.W, 1e-5, _lib.ptr(gamma),
+        creal = raw.real_c
+        alloc = torch.zeros if creal != raw.C else torch.empty
+        scale = alloc(raw.C, dtype=torch.float32, device=raw.t.device)
+        shift = alloc(raw.C, dtype=torch.float32, device=raw.t.device)
+        _lib.check(lib.vx_bn_finalize(_lib.ptr(part), ntiles, creal, raw.N * raw.H * raw.W, 1e-5, _lib.ptr(gamma),
                                       _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), self._st), "vx_bn_finalize " + bn_name)
         self._hold += [scale, shift]
         return raw, scale, shift
@@ -532,7 +563,7 @@ class HighResolutionNet(nn.Module):
             seed = 0
             if self.dropout_final and dropout_masks is not None:
                 mode = _lib.VX_DROP_MASK
-                masks = [m.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.uint8) for m in dropout_masks[t]]
+                masks = [_pad_mask(m, dev) for m in dropout_masks[t]]
                 self._hold += masks
             elif self.dropout_final:  # F.dropout(..., training=True): live even in eval mode (hrnet_module.py:642-646)
                 mode = _lib.VX_DROP_HASH
@@ -572,7 +603,7 @@ class HighResolutionNet(nn.Module):
         mode, masks, sd = _lib.VX_DROP_NONE, None, 0
         if self.dropout_final and dropout_masks is not None:
             mode = _lib.VX_DROP_MASK
-            masks = [m.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.uint8) for m in dropout_masks]
+            masks = [_pad_mask(m, dev) for m in dropout_masks]
             self._hold += masks
         elif self.dropout_final:
             mode = _lib.VX_DROP_HASH

@@ -282,6 +282,10 @@ int vx_softmax_accumulate(const float* logits, int B, int T, int C, int P0, int 
 int vx_aleatoric_sample(const float* mu_s, const float* eps, uint32_t seed, int N, int T, int C, int64_t nvox,
                         float* out, float* sigma, vx_stream_t stream);
 
+/* Softmax variance (BASELINE.json north_star; no counterpart in the reference): x [B][T][C][nvox] float32 logits
+ * (from_logits != 0) or probabilities -> out [B][nvox] = mean over classes of the population variance over T. */
+int vx_softmax_variance(const float* x, int from_logits, int B, int T, int C, int64_t nvox, float* out, vx_stream_t stream);
+
 /* SSN sampling (SsnUNet3D.forward + distribution.sample, ssn_unet3D_module.py:39-70; test_3D.py:361-396):
  * head [N][(2+R)*C][nvox] = the three 1x1x1 heads run as one conv (mean | log_cov_diag | cov_factor, factor channel
  * r*C + c); out [N][S][C][nvox] = mean + sum_r factor_r * eps_w[s][n][r] + sqrt(exp(log_cov_diag) + epsilon) *

@@ -524,3 +524,16 @@ def test_aggregations_match_reference_fixture():
     assert [list(b) for b in mine["bounding_box"]] == [list(b) for b in g["img2d"]["patch10"]["bounding_box"]]
     with pytest.raises(Exception):
         agg.threshold_aggregation(img2)
+
+
+def test_softmax_variance_matches_numpy():
+    """north_star's softmax-variance map (no reference counterpart): mean over classes of the variance over samples"""
+    from values_amd.uncertainty import softmax_variance
+    logits = formula_tensor((2, 6, 3, 5, 7, 9), 301, scale=2.0).astype(np.float32)
+    e = np.exp(logits.astype(np.float64) - logits.max(2, keepdims=True))
+    p = e / e.sum(2, keepdims=True)
+    want = p.var(axis=1).mean(axis=1)
+    got = softmax_variance(torch.from_numpy(logits).cuda(), from_logits=True).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-6
+    got = softmax_variance(torch.from_numpy(p.astype(np.float32)).cuda(), from_logits=False).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-6

@@ -113,6 +113,7 @@ SIGNATURES = {
     "vx_soft_metric_sums": (_i, [_p, _p, _i, _i, _i64, _p, _p, _p]),
     "vx_ssn2d_lowres": (_i, [_p, _i, _p, _i, _p, _u32, _i, _i64, _i, _i, _i, _p, _p, _p]),
     "vx_ssn2d_add_diag": (_i, [_p, _p, _p, _u32, _i, _i, _i64, C.c_float, _p]),
+    "vx_softmax_variance": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p]),
     "vx_ssn_sample": (_i, [_p, _p, _p, _u32, _i, _i, _i, _i, _i64, C.c_float, _p, _p]),
     "vx_conv2d_packed_floats": (_i64, [_i, _i, _i]),
     "vx_pack_conv2d": (_i, [_p, _p, _i, _i, _i, _p]),

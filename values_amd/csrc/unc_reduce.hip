@@ -488,3 +488,51 @@ extern "C" int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, v
   VX_CHECK_LAUNCH("vx_one_minus_msr");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Softmax variance (named in BASELINE.json's north_star; the reference computes none, SURVEY D3 -- so the definition
+// is this build's: the population variance over the T samples of each class probability, averaged over classes):
+//     var[v] = 1/C * sum_c ( 1/T sum_t p_tc^2 - (1/T sum_t p_tc)^2 )
+// One pass over the logits (softmax fused) or probabilities, float32 in / out, fp32 accumulation per voxel.
+__global__ __launch_bounds__(256) void softmax_variance_kernel(const float* __restrict__ x, int from_logits, int B, int T, int C,
+                                                               int64_t nvox, float* __restrict__ out) {
+  const int64_t total = (int64_t)B * nvox;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / nvox, v = i - b * nvox;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const float* px = x + ((size_t)(b * T + t) * C) * nvox + v;
+        float p;
+        if (from_logits) {
+          float mx = px[0];
+          for (int k = 1; k < C; ++k) mx = fmaxf(mx, px[(size_t)k * nvox]);
+          float den = 0.f;
+          for (int k = 0; k < C; ++k) den += expf(px[(size_t)k * nvox] - mx);
+          p = expf(px[(size_t)c * nvox] - mx) / den;
+        } else {
+          p = px[(size_t)c * nvox];
+        }
+        s1 += p;
+        s2 = fmaf(p, p, s2);
+      }
+      const float m = s1 / (float)T;
+      acc += fmaxf(s2 / (float)T - m * m, 0.f);
+    }
+    out[i] = acc / (float)C;
+  }
+}
+
+extern "C" int vx_softmax_variance(const float* x, int from_logits, int B, int T, int C, int64_t nvox, float* out,
+                                   vx_stream_t stream) {
+  if (B <= 0 || T <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_softmax_variance: bad shape");
+  if (nvox == 0) return VX_OK;
+  if (!x || !out) VX_FAIL(VX_E_NULL, "vx_softmax_variance: null pointer");
+  const int64_t total = (int64_t)B * nvox;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(softmax_variance_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, x, from_logits, B, T, C, nvox, out);
+  VX_CHECK_LAUNCH("vx_softmax_variance");
+  return VX_OK;
+}

@@ -53,6 +53,23 @@ def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool
     return out
 
 
+def softmax_variance(x: torch.Tensor, from_logits: bool = False) -> torch.Tensor:
+    """x (B, T, C, *spatial) float32 probabilities or logits -> (B, *spatial): mean over classes of the variance over the
+    T samples.  Named in BASELINE.json's north_star; the reference has no such map, so the definition is ours."""
+    lib = _lib.load()
+    xd, dev = _dev_tensor(x)
+    xd = xd.to(torch.float32).contiguous()
+    B, T, Cc = xd.shape[:3]
+    spatial = tuple(xd.shape[3:])
+    nvox = 1
+    for s_ in spatial:
+        nvox *= s_
+    out = torch.empty((B,) + spatial, dtype=torch.float32, device=dev)
+    _lib.check(lib.vx_softmax_variance(_lib.ptr(xd), int(from_logits), B, T, Cc, nvox, _lib.ptr(out), _lib.stream_ptr()),
+               "vx_softmax_variance")
+    return out
+
+
 def calculate_uncertainty(softmax_preds: torch.Tensor, ssn: bool = False) -> Dict[str, torch.Tensor]:
     """test_3D.py:486-518.  softmax_preds: (T, C, *spatial).  Returns float32 maps on the input's device
     under the reference's keys; `ssn=True` swaps aleatoric/epistemic like test_3D.py:510-516."""

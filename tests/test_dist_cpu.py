@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -50,6 +51,7 @@ def _worker_pipeline(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from values_amd.dist import MapGatherPipeline
     pipe = MapGatherPipeline(world, rank, depth=2)
+    pipe._use_all_gather = bool(int(os.environ.get("VX_TEST_ALL_GATHER", "0")))   # the fallback path of a backend without gather
     got = []
     n_vol = 4
     for step in range(5):    # more steps than buffers: every send / receive buffer is reused
@@ -76,8 +78,10 @@ def _worker_pipeline(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_map_gather_pipeline_world2_gloo():
-    """the overlapped gather of bench.py --gpus N: order of results, buffer reuse, flush"""
+@pytest.mark.parametrize("all_gather", ["0", "1"])
+def test_map_gather_pipeline_world2_gloo(all_gather, monkeypatch):
+    """the overlapped gather of bench.py --gpus N: order of results, buffer reuse, flush (and the all_gather fallback)"""
+    monkeypatch.setenv("VX_TEST_ALL_GATHER", all_gather)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -77,6 +77,12 @@ class MapGatherPipeline:
         self._recv = [None] * self.depth
         self._inflight = []      # [(slot, works)] oldest first
         self._next = 0
+        self._use_all_gather = False
+
+    def _resubmit(self, out, slot, done):
+        self._next = slot
+        r = self.submit(out)
+        return done if done is not None else r
 
     def submit(self, out: Dict[str, torch.Tensor]):
         done = None
@@ -99,8 +105,22 @@ class MapGatherPipeline:
         sf, ss = self._send[slot]
         torch.cat(parts, dim=1, out=sf)      # pack straight into the send buffer (the step's tensors may be reused)
         ss.copy_(seg)
-        rl = (list(self._recv[slot][0].unbind(0)), list(self._recv[slot][1].unbind(0))) if self.rank == self.dst else (None, None)
-        works = [dist.gather(sf, rl[0], dst=self.dst, async_op=True), dist.gather(ss, rl[1], dst=self.dst, async_op=True)]
+        if self._use_all_gather and self._recv[slot] is None:
+            self._recv[slot] = (torch.empty((self.world,) + fshape, dtype=torch.float32, device=seg.device),
+                                torch.empty((self.world,) + tuple(seg.shape), dtype=seg.dtype, device=seg.device))
+        have_recv = self._recv[slot] is not None
+        rl = (list(self._recv[slot][0].unbind(0)), list(self._recv[slot][1].unbind(0))) if have_recv else (None, None)
+        if not self._use_all_gather:
+            try:
+                works = [dist.gather(sf, rl[0] if self.rank == self.dst else None, dst=self.dst, async_op=True),
+                         dist.gather(ss, rl[1] if self.rank == self.dst else None, dst=self.dst, async_op=True)]
+            except RuntimeError:
+                # a backend without gather: all_gather is universally available (every rank then holds the maps);
+                # the switch is collective-safe because every rank hits the same error on the same call
+                self._use_all_gather = True
+                return self._resubmit(out, slot, done)
+        if self._use_all_gather:
+            works = [dist.all_gather(rl[0], sf, async_op=True), dist.all_gather(rl[1], ss, async_op=True)]
         self._inflight.append((slot, works))
         return done
 

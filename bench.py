@@ -60,7 +60,7 @@ def kernel_name(kind, ci, co, edge):
             return f"conv3d_k3_c1_kernel<{co}>"
         fp32 = int(os.environ.get("VX_CONV_FP32", "0") or 0)
         if fp32 == 0 or (fp32 == 2 and co != 8):
-            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP>, split-fp16 products on v_mfma_f32_16x16x32_f16;
+            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP, DB>, split-fp16 products on v_mfma_f32_16x16x32_f16;
             # Cout = 8 layers: x-pair packing (XP = 1) in chunks of 8 channels, a column is a voxel pair
             xp = 1 if co == 8 else 0
             cb = 8 if xp else (16 if ci % 16 == 0 else 8)
@@ -70,7 +70,9 @@ def kernel_name(kind, ci, co, edge):
                 tile, nw = ("16,8,4" if edge >= 32 else "16,4,4"), 8
             else:
                 tile, nw = ("8,8,4", 8) if ex >= 8 else ("4,4,4", 4)
-            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp}>"
+            # DB = 2: single-chunk x-pair layers on the large tile run the double-buffered, staggered variant
+            db = 2 if (xp and tile == "16,8,4" and ci == cb and not os.environ.get("VX_S16_NO_DB")) else 0
+            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp},{db}>"
         if co == 8 and ci in (8, 16):
             # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)
             tile = "32,4,4" if edge >= 32 else ("16,8,4" if edge >= 16 else "8,4,4")

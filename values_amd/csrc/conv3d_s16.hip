@@ -64,7 +64,17 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 // (weight W[kx = ix - dx], zero outside 0..2): 9 steps for two voxels per column instead of 2 x 7, all 16 rows and
 // all four lane groups of the epilogue useful.  Even / odd x live in two parity planes so that columns stay
 // consecutive positions.
-template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
+// DB (x-pair, single-chunk layers with the 16x8x4 tile): TWO LDS images and ONE barrier per item.  Item k + 1 is
+// converted and written into the other image while item k is being multiplied.  DB = 1: every wave stages right after
+// the barrier (measured: no gain over two barriers, the waves still move through the phases together).  DB = 2 adds
+// a stagger between the two waves that share a SIMD (w and w + 4): waves 0..3 run stage, multiply, epilogue; waves
+// 4..7 run the PREVIOUS item's epilogue, multiply, stage -- one wave's stores / conversions under the other's MFMAs
+// (MI355X_MICROARCH.md, two waves per SIMD, item 9).  +2.9 % end to end on the 64^3 network; results bit-identical.
+// EPI: the epilogue's features fixed at compile time for the large-tile instances (fewer scalar registers to spill --
+// 76 -> 8 for the plain one -- and a shorter epilogue: contr_1_2 1.72 -> 1.57 ms).  0 = plain (bias, statistics,
+// store: the layers an InstanceNorm follows); 1 = LeakyReLU + hash dropout (decoder layers); 2 = 1 + the fused
+// 1x1x1 head; 3 = everything chosen at run time from vx_conv3d_args (all other instances).
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
   constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
@@ -91,10 +101,17 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16* s_hi = reinterpret_cast<_Float16*>(smem_raw);
   _Float16* s_lo = s_hi + IMG_H;
-  _Float16* s_w = s_hi + 2 * IMG_H;
-  float* s_red = reinterpret_cast<float*>(smem_raw + IN_BYTES + (size_t)(ka.w_all ? ka.nchunks : 1) * W_H * 2);
+  constexpr int BUF_H = 2 * IMG_H;                 // halves of one image (hi + lo planes)
+  _Float16* s_w = s_hi + (DB ? 2 : 1) * BUF_H;
+  float* s_red = reinterpret_cast<float*>(smem_raw + (DB ? 2 : 1) * IN_BYTES + (size_t)(ka.w_all ? ka.nchunks : 1) * W_H * 2);
 
   const vx_conv3d_args& a = ka.a;
+  const bool f_lrelu = EPI == 3 ? a.act == VX_ACT_LRELU : (EPI == 1 || EPI == 2);
+  const bool f_relu = EPI == 3 && a.act == VX_ACT_RELU;
+  const bool f_dhash = EPI == 3 ? a.drop_mode == VX_DROP_HASH : (EPI == 1 || EPI == 2);
+  const bool f_dmask = EPI == 3 && a.drop_mode == VX_DROP_MASK;
+  const bool f_head = XP && (EPI == 3 ? a.head_out != nullptr : EPI == 2);
+  const bool f_store = (EPI == 0 || EPI == 1) ? true : a.out != nullptr;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -223,14 +240,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       wbuf[it] = v;
     }
   };
-  auto commit = [&](bool with_w) {
+  auto commit = [&](bool with_w, int bofs = 0) {
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
       if (tid + it * NTH < NHALO * Q) {
         f16x4 hi, lo;
         vx_split4(ibuf[it], hi, lo);
-        *reinterpret_cast<f16x4*>(s_hi + ldst[it]) = hi;
-        *reinterpret_cast<f16x4*>(s_lo + ldst[it]) = lo;
+        *reinterpret_cast<f16x4*>(s_hi + bofs + ldst[it]) = hi;
+        *reinterpret_cast<f16x4*>(s_lo + bofs + ldst[it]) = lo;
       }
     }
     if (with_w) {
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     hb[c] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) hw4[c][k] = 0.f;
-    if (XP && a.head_out && c < a.head_C) {
+    if (f_head && c < a.head_C) {
       if (!(g & 1)) hb[c] = a.head_b[c];
 #pragma unroll
       for (int k = 0; k < 4; ++k) hw4[c][k] = a.head_w[c * 8 + (g & 1) * 4 + k];
@@ -280,40 +297,210 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-  int pend_n = -1, pend_tile = 0;   // tile whose per-wave statistics sit in s_red, not yet combined
-  auto flush_stats = [&]() {
-    if (pend_n >= 0 && tid < NT * 16) {
+  // tiles whose per-wave statistics sit in s_red, not yet combined.  B = the item of the latest epilogue; A (DB == 2
+  // only) = the one before, whose waves 4..7 wrote their part one barrier later.  s_red holds 1 / 2 / 3 items' slots
+  // for DB = 0 / 1 / 2.
+  constexpr int RED_F = NW * NT * 32;   // floats of one item's slots
+  int pendA_n = -1, pendA_tile = 0, pendA_red = 0, pendB_n = -1, pendB_tile = 0, pendB_red = 0;
+  auto flush_one = [&](int pn, int ptile, int pred) {
+    if (pn >= 0 && tid < NT * 16) {
       const int nt = tid / 16, c = tid % 16;
       const int co = XP ? c : (cg * NT + nt) * 16 + c;   // x-pair: rows c and c + 8 are the two x of channel c
       if (co < a.Cout && (!XP || c < 8)) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-          s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
-          q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+          s += s_red[pred + ((w * NT + nt) * 16 + c) * 2 + 0];
+          q += s_red[pred + ((w * NT + nt) * 16 + c) * 2 + 1];
           if (XP) {
-            s += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 0];
-            q += s_red[((w * NT + nt) * 16 + c + 8) * 2 + 1];
+            s += s_red[pred + ((w * NT + nt) * 16 + c + 8) * 2 + 0];
+            q += s_red[pred + ((w * NT + nt) * 16 + c + 8) * 2 + 1];
           }
         }
-        float* dst = a.stats_partial + (((size_t)pend_n * ntiles + pend_tile) * a.Cout + co) * 2;
+        float* dst = a.stats_partial + (((size_t)pn * ntiles + ptile) * a.Cout + co) * 2;
         dst[0] = s;
         dst[1] = q;
       }
     }
-    pend_n = -1;
+  };
+  // after a barrier of the item loop: combine what is complete
+  auto flush_stats = [&]() {
+    if constexpr (DB == 2) {
+      flush_one(pendA_n, pendA_tile, pendA_red);
+      pendA_n = pendB_n; pendA_tile = pendB_tile; pendA_red = pendB_red;
+    } else {
+      flush_one(pendB_n, pendB_tile, pendB_red);
+    }
+    pendB_n = -1;
   };
 
+  // ---- epilogue of item tl (conv3d_mfma.hip); its statistics go to the s_red slots at redo ----
+  auto epilogue = [&](int tl, int redo) {
+    // ---- epilogue (conv3d_mfma.hip) ----
+    int n, tx, ty, tz;
+    decode(tl, n, tx, ty, tz);
+    unsigned obad = 0;
+    if (tx == ka.tiles_x - 1) obad |= obad_xhi;
+    if (ty == ka.tiles_y - 1) obad |= obad_yhi;
+    if (tz == ka.tiles_z - 1) obad |= obad_zhi;
+    const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TXV);
+    const unsigned osoff = vox0 * (unsigned)a.out_pitch * 4u;
+    const unsigned e0 = vox0 * (unsigned)a.Cout;
+    const __amdgpu_buffer_rsrc_t osrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
+    const uint32_t dkey = f_dhash ? vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n) : 0u;
+    const size_t hnvox = (size_t)a.D * a.H * a.W;
+    int hflip = 0;
+    float* hbase = nullptr;
+    if (f_head) {
+      hflip = a.head_flip ? a.head_flip[n] : 0;
+      hbase = a.head_out + (size_t)(a.head_dst ? a.head_dst[n] : n) * a.head_C * hnvox;
+    }
+
+    float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned cshift = XP ? 0u : (unsigned)((cg * NT + nt) * 16);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
+        f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
+        if (a.stats_partial && !bad) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
+        }
+        if (f_lrelu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.01f * v[j]);
+        } else if (f_relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        const unsigned e = e0 + eoff[r] + cshift;
+        if (f_dhash) {
+          const uint32_t bits = vx_drop_bits4(dkey, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+        } else if (f_dmask) {
+          uint32_t mk = 0;
+          if (!bad) mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (size_t)n * a.D * a.H * a.W * a.Cout + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
+        }
+        if (f_head) {
+          // fused 1x1x1 head (conv1x1.hip): this lane holds channels 4 (g & 1) .. + 3 of voxel 2p + (g >> 1), the
+          // lane 16 further (g ^ 1) the other four -- one cross-lane add per class, then the g-even lane stores
+          // (a wave's stores of one class cover 32 consecutive voxels).  The lane's 4 weights per class and the
+          // bias were selected once per workgroup (hw4 / hb).  Two partial chains + one add: not bit-equal to
+          // conv1x1.hip's single chain.
+          const int vv = (wave * R + r) * 16 + m;
+          int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
+          if (hflip & 1) gz = a.D - 1 - gz;
+          if (hflip & 2) gy = a.H - 1 - gy;
+          if (hflip & 4) gx = a.W - 1 - gx;
+          float* o = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
+#pragma unroll
+          for (int c = 0; c < HC; ++c) {
+            if (c < a.head_C) {
+              float part = hb[c];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) part = fmaf(hw4[c][k], v[k], part);
+              part += __shfl_xor(part, 16, 64);
+              if (!bad && !(g & 1)) o[(size_t)c * hnvox] = part;
+            }
+          }
+        }
+        if (f_store) {
+          const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
+          // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 3" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    if (a.stats_partial) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s = ssum[nt][j], q = ssq[nt][j];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) {
+            s += __shfl_xor(s, off, 64);
+            q += __shfl_xor(q, off, 64);
+          }
+          if (m == 0) {
+            s_red[redo + ((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
+            s_red[redo + ((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
+          }
+        }
+      // the cross-wave sum and the global write wait for the NEXT barrier of the item loop (flush_stats): no
+      // extra barrier in the epilogue
+      pendB_n = n;
+      pendB_red = redo;
+      pendB_tile = tl - n * ntiles;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  };
+
+  // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
+  // one): waves 4..7 run the epilogue of item k after the barrier of item k + 1, so their stores and statistics
+  // overlap the MFMA loop of waves 0..3 and vice versa instead of every wave hitting the same phase together.
+  const bool late = DB == 2 && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+  int red_cur = 0, red_prev = 0, prev_tile = 0;
+  bool have_prev = false;
+  // DB: item 0 goes into image 0 before the loop, item 1's loads are in flight
+  int db_cur = 0, db_ntile = 0;
+  bool db_nhave = false;
+  if constexpr (DB != 0) {
+    commit(true, 0);
+    w_fresh = false;
+    db_ntile = tile_lin + (int)gridDim.x;
+    db_nhave = db_ntile < total;
+    prefetch(db_ntile, 0, db_nhave, false);
+  }
+
   while (have) {
-    if (ka.dbg < 3) __syncthreads();
-    flush_stats();
-    if (ka.dbg < 2) commit(w_fresh);
-    if (ka.dbg < 3) __syncthreads();
-    w_fresh = !w_resident;
-    int ntile = tile_lin, nchunk = chunk + 1;
-    if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
-    const bool nhave = ntile < total;
-    if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+    int ntile, nchunk;
+    bool nhave;
+    int cofs = 0;    // halves offset of the image this item reads
+    if constexpr (DB != 0) {
+      __syncthreads();       // image db_cur is complete; everyone is done reading image db_cur ^ 1
+      flush_stats();
+      if constexpr (DB == 2) {
+        if (late && have_prev) epilogue(prev_tile, red_prev);
+      }
+      ntile = db_ntile; nchunk = 0; nhave = db_nhave;
+      db_ntile = ntile + (int)gridDim.x;
+      db_nhave = db_ntile < total;
+      cofs = db_cur * BUF_H;
+      db_cur ^= 1;
+      if (!late) {
+        if (nhave) commit(false, db_cur * BUF_H);            // next item -> the other image (waits for its loads)
+        prefetch(db_ntile, 0, db_nhave, false);              // the item after next -> registers
+      }
+    } else {
+      if (ka.dbg < 3) __syncthreads();
+      flush_stats();
+      if (ka.dbg < 2) commit(w_fresh);
+      if (ka.dbg < 3) __syncthreads();
+      w_fresh = !w_resident;
+      ntile = tile_lin; nchunk = chunk + 1;
+      if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
+      nhave = ntile < total;
+      if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+    }
     const _Float16* s_wc = s_w + (ka.w_all ? chunk * W_H : 0);   // this item's weights
 
     if constexpr (XP == 1 && TX == 16 && TY % R == 0) {
@@ -328,8 +515,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
         for (int j = 0; j < R + 2; ++j) {
           const int p = (p0 + (kz * HY + j) * HXP) * 8;
-          bh[j] = *reinterpret_cast<const f16x8*>(s_hi + p);
-          bl[j] = *reinterpret_cast<const f16x8*>(s_lo + p);
+          bh[j] = *reinterpret_cast<const f16x8*>(s_hi + cofs + p);
+          bl[j] = *reinterpret_cast<const f16x8*>(s_lo + cofs + p);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -377,132 +564,36 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       }
     }
 
+    if constexpr (DB == 2) {   // waves 4..7 stage the next item after their MFMA loop: E M C against C M E of waves 0..3
+      if (late) {
+        if (nhave) commit(false, db_cur * BUF_H);
+        prefetch(db_ntile, 0, db_nhave, false);
+      }
+    }
     if (ka.dbg >= 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" :: "v"(acc[r][nt]), "v"(accx[r][nt]));
     } else if (chunk == ka.nchunks - 1) {
-      // ---- epilogue (conv3d_mfma.hip) ----
-      int n, tx, ty, tz;
-      decode(tile_lin, n, tx, ty, tz);
-      unsigned obad = 0;
-      if (tx == ka.tiles_x - 1) obad |= obad_xhi;
-      if (ty == ka.tiles_y - 1) obad |= obad_yhi;
-      if (tz == ka.tiles_z - 1) obad |= obad_zhi;
-      const unsigned vox0 = (unsigned)(((tz * TZ) * a.H + ty * TY) * a.W + tx * TXV);
-      const unsigned osoff = vox0 * (unsigned)a.out_pitch * 4u;
-      const unsigned e0 = vox0 * (unsigned)a.Cout;
-      const __amdgpu_buffer_rsrc_t osrd =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
-      const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
-      const size_t hnvox = (size_t)a.D * a.H * a.W;
-      int hflip = 0;
-      float* hbase = nullptr;
-      if (XP && a.head_out) {
-        hflip = a.head_flip ? a.head_flip[n] : 0;
-        hbase = a.head_out + (size_t)(a.head_dst ? a.head_dst[n] : n) * a.head_C * hnvox;
+      if constexpr (DB == 2) {
+        if (!late) epilogue(tile_lin, red_cur);
+        prev_tile = tile_lin; have_prev = true;
+        red_prev = red_cur;
+        red_cur = red_cur == 2 * RED_F ? 0 : red_cur + RED_F;
+      } else {
+        epilogue(tile_lin, red_cur);
+        if constexpr (DB == 1) red_cur ^= RED_F;
       }
-
-      float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
-
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const unsigned cshift = XP ? 0u : (unsigned)((cg * NT + nt) * 16);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
-          f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
-          if (a.stats_partial && !bad) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
-          }
-          if (a.act == VX_ACT_LRELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.01f * v[j]);
-          } else if (a.act == VX_ACT_RELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          const unsigned e = e0 + eoff[r] + cshift;
-          if (a.drop_mode == VX_DROP_HASH) {
-            const uint32_t bits = vx_drop_bits4(dkey, e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
-          } else if (a.drop_mode == VX_DROP_MASK) {
-            uint32_t mk = 0;
-            if (!bad) mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (size_t)n * a.D * a.H * a.W * a.Cout + e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * v[j] : 0.f;
-          }
-          if (XP && a.head_out) {
-            // fused 1x1x1 head (conv1x1.hip): this lane holds channels 4 (g & 1) .. + 3 of voxel 2p + (g >> 1), the
-            // lane 16 further (g ^ 1) the other four -- one cross-lane add per class, then the g-even lane stores
-            // (a wave's stores of one class cover 32 consecutive voxels).  The lane's 4 weights per class and the
-            // bias were selected once per workgroup (hw4 / hb).  Two partial chains + one add: not bit-equal to
-            // conv1x1.hip's single chain.
-            const int vv = (wave * R + r) * 16 + m;
-            int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
-            if (hflip & 1) gz = a.D - 1 - gz;
-            if (hflip & 2) gy = a.H - 1 - gy;
-            if (hflip & 4) gx = a.W - 1 - gx;
-            float* o = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
-#pragma unroll
-            for (int c = 0; c < HC; ++c) {
-              if (c < a.head_C) {
-                float part = hb[c];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part = fmaf(hw4[c][k], v[k], part);
-                part += __shfl_xor(part, 16, 64);
-                if (!bad && !(g & 1)) o[(size_t)c * hnvox] = part;
-              }
-            }
-          }
-          if (a.out) {
-            const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
-            // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 3" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-
-      if (a.stats_partial) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float s = ssum[nt][j], q = ssq[nt][j];
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-              s += __shfl_xor(s, off, 64);
-              q += __shfl_xor(q, off, 64);
-            }
-            if (m == 0) {
-              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
-              s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
-            }
-          }
-        // the cross-wave sum and the global write wait for the NEXT barrier of the item loop (flush_stats): no
-        // extra barrier in the epilogue
-        pend_n = n;
-        pend_tile = tile_lin - n * ntiles;
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
+  if constexpr (DB == 2) {
+    if (late && have_prev) epilogue(prev_tile, red_prev);
+  }
   __syncthreads();
   flush_stats();
+  if constexpr (DB == 2) flush_stats();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,19 +655,19 @@ int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Co
   return VX_OK;
 }
 
-template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP>
+template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   constexpr int TXV = XP ? 2 * TX : TX;
   constexpr int NHALO = (TXV + 2) * (TY + 2) * (TZ + 2);
   constexpr int PLANE = (((XP ? NHALO / 2 : NHALO) + 15) / 16) * 16;
   constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
   constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * 64 * 8 * 2;
-  constexpr size_t red = (size_t)NW * NT * 16 * 2 * 4;
-  static_assert(img + wch + red <= 160 * 1024, "LDS budget");
+  constexpr size_t red = (size_t)(DB + 1) * NW * NT * 16 * 2 * 4;
+  static_assert((DB ? 2 : 1) * img + wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
-  ka.w_all = (ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0;
-  const size_t lds = img + (ka.w_all ? ka.nchunks : 1) * wch + red;
-  auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP>;
+  ka.w_all = (!DB && ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0;
+  const size_t lds = (DB ? 2 : 1) * img + (ka.w_all ? ka.nchunks : 1) * wch + red;
+  auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP, DB, EPI>;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -598,7 +689,29 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
 
 template <int CB, int NT, int XP>
 static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
-  if (tx == 16 && ka.ty8) return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);   // large layers: 4 column tiles per wave
+  // epilogue specialisation of the large-tile instances (EPI in the kernel's header)
+  const vx_conv3d_args& a = ka.a;
+  int epi = 3;
+  if (!getenv("VX_S16_NO_EPI")) {
+    if (a.act == VX_ACT_NONE && a.drop_mode == VX_DROP_NONE && !a.head_out && a.out) epi = 0;
+    else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && !a.head_out && a.out) epi = 1;
+    else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
+  }
+  if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
+    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !getenv("VX_S16_NO_DB")) {
+      if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 0>(ka, s);
+      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
+      if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 2>(ka, s);
+      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 3>(ka, s);
+    }
+  }
+  if (tx == 16 && ka.ty8) {   // large layers: 4 column tiles per wave
+    if constexpr (NT == 1) {
+      if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 0, 0>(ka, s);
+      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 0, 1>(ka, s);
+    }
+    return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);
+  }
   if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
   if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
   return launch_s16<CB, NT, 4, 4, 4, 4, XP>(ka, s);

@@ -52,11 +52,37 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
   for (int j = 0; j < 4; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 h = __builtin_convertvector(x, f16x2);
+#ifdef VX_SPLIT_PLAIN
     const f32x2 hf = __builtin_convertvector(h, f32x2);
     const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
+#else
+    // lo = fp16(2048 x - 2048 hi) as one mixed-precision fma per element, reading hi as the fp16 it is and writing
+    // the fp16 half directly: 8 instead of 14 VALU instructions per 16-byte piece, the same bits (2048 x, 2048 hi
+    // and their difference are all exact in fp32; tools/micro/split_mix.hip compares the two forms)
+    const f32x2 xs = x * 2048.f;
+    const float m2048 = -2048.f;
+    const uint32_t hv = __builtin_bit_cast(uint32_t, h);
+    uint32_t lv = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[1]));
+    const f16x2 l = __builtin_bit_cast(f16x2, lv);
+#endif
     hi[j] = h[0]; hi[j + 1] = h[1];
     lo[j] = l[0]; lo[j + 1] = l[1];
   }
+}
+
+// lane i of every 16-lane row <- lane (i + rot) % 16 of the same row
+__device__ __forceinline__ float vx_row_ror(float x, int rot) {
+  const int v = __builtin_bit_cast(int, x);
+  int r;
+  switch (rot) {
+    case 8: r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(float, r);
 }
 
 // XP (Cout == 8, CB == 8): x-pair packing as in conv3d_mfma.hip -- rows = (dx, cout), columns = voxel pairs
@@ -433,9 +459,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         for (int j = 0; j < 4; ++j) {
           float s = ssum[nt][j], q = ssq[nt][j];
 #pragma unroll
-          for (int off = 1; off < 16; off <<= 1) {
-            s += __shfl_xor(s, off, 64);
-            q += __shfl_xor(q, off, 64);
+          for (int rot = 8; rot >= 1; rot >>= 1) {   // sum over the row group's 16 columns: DPP row rotations, no LDS-queue shuffles
+            s += vx_row_ror(s, rot);
+            q += vx_row_ror(q, rot);
           }
           if (m == 0) {
             s_red[redo + ((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
@@ -448,10 +474,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       pendB_red = redo;
       pendB_tile = tl - n * ntiles;
     }
+    if constexpr (DB == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
   };
 
   // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
@@ -525,8 +553,11 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
           const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], acc[r][0], 0, 0, 0);
-            accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], accx[r][0], 0, 0, 0);
+            // DB: one item = one tile, so the first step starts from zero (no accumulator clearing in the epilogue)
+            const bool fresh = DB != 0 && kz == 0 && ky == 0;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? zero : acc[r][0], 0, 0, 0);
+            accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r][0], 0, 0, 0);
             accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r][0], 0, 0, 0);
           }
         }

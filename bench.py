@@ -54,13 +54,13 @@ def layer_table(F=8, S=64):
     return t
 
 
-def kernel_name(kind, ci, co, edge):
+def kernel_name(kind, ci, co, edge, label=""):
     if kind == "conv":
         if ci == 1:
             return f"conv3d_k3_c1_kernel<{co}>"
         fp32 = int(os.environ.get("VX_CONV_FP32", "0") or 0)
         if fp32 == 0 or (fp32 == 2 and co != 8):
-            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP, DB>, split-fp16 products on v_mfma_f32_16x16x32_f16;
+            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP, DB, EPI>, split-fp16 products on v_mfma_f32_16x16x32_f16;
             # Cout = 8 layers: x-pair packing (XP = 1) in chunks of 8 channels, a column is a voxel pair
             xp = 1 if co == 8 else 0
             cb = 8 if xp else (16 if ci % 16 == 0 else 8)
@@ -72,7 +72,14 @@ def kernel_name(kind, ci, co, edge):
                 tile, nw = ("8,8,4", 8) if ex >= 8 else ("4,4,4", 4)
             # DB = 2: single-chunk x-pair layers on the large tile run the double-buffered, staggered variant
             db = 2 if (xp and tile == "16,8,4" and ci == cb and not os.environ.get("VX_S16_NO_DB")) else 0
-            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp},{db}>"
+            # EPI: compile-time epilogue of the large-tile instances -- 0 plain (encoder: an InstanceNorm follows),
+            # 1 LeakyReLU + hash dropout (decoder), 2 = 1 + fused 1x1x1 head (expand_1_2), 3 run-time (all others)
+            epi = 3
+            if tile == "16,8,4" and nt == 1 and not os.environ.get("VX_S16_NO_EPI"):
+                epi = 0 if label.startswith("contr") else 1
+                if label == "expand_1_2" and not os.environ.get("VX_NO_HEAD_FUSION"):
+                    epi = 2
+            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp},{db},{epi}>"
         if co == 8 and ci in (8, 16):
             # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)
             tile = "32,4,4" if edge >= 32 else ("16,8,4" if edge >= 16 else "8,4,4")
@@ -143,7 +150,7 @@ def roofline_leg(model, x, T, reps=3):
             per_label.setdefault(label, []).append(ms)
             if label in tab:
                 kind, ci, co, edge = tab[label]
-                name = kernel_name(kind, ci, co, edge)
+                name = kernel_name(kind, ci, co, edge, label)
                 # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
                 fl, by = launch_cost(kind, ci, co, edge, V if label == "contr_1_1" else N)
             else:

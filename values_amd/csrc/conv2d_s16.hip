@@ -33,8 +33,14 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {   
   for (int j = 0; j < 4; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 h = __builtin_convertvector(x, f16x2);
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
+    // lo = fp16(2048 x - 2048 hi): one mixed-precision fma per element (same bits as the cvt / sub / mul / cvt form)
+    const f32x2 xs = x * 2048.f;
+    const float m2048 = -2048.f;
+    const uint32_t hv = __builtin_bit_cast(uint32_t, h);
+    uint32_t lv = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[1]));
+    const f16x2 l = __builtin_bit_cast(f16x2, lv);
     hi[j] = h[0]; hi[j + 1] = h[1];
     lo[j] = l[0]; lo[j + 1] = l[1];
   }

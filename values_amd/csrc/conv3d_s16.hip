@@ -103,6 +103,8 @@ __device__ __forceinline__ float vx_row_ror(float x, int rot) {
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
+  constexpr bool SINGLE = DB == 1 || DB == 2;      // double-buffered, every item a whole tile (one chunk)
+  constexpr bool STAG = DB >= 2;                   // staggered waves (DB = 3: also for several chunks per tile)
   constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
   constexpr int NVT = TX * TY * TZ / 16;
   constexpr int R = NVT / NW;
@@ -118,7 +120,13 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int IMG_H = (XP ? 2 : OCT) * PLANE * 8;  // halves per precision plane
   static_assert(!XP || (CB == 8 && NT == 1), "x-pair packing is for Cout == 8 in chunks of 8 channels");
   constexpr int IN_BYTES = 2 * IMG_H * 2;
-  constexpr int W_H = NSTEP * NT * 2 * 64 * 8;     // halves of one chunk's weights
+  // halves of one chunk's weights.  x-pair: the two x-rows (dx = 0, 1) of an output channel hold the SAME three taps,
+  // shifted by one k-group, and one k-group of each is zero -- so a (step, precision) block is [kx 4][co 8] pieces
+  // (kx = 3: zeros) = 512 B instead of 64 lanes x 16 B, and lane (m, g) reads piece (kx = (g - dx) & 3, co) with
+  // dx = m >> 3, co = m & 7.  Two lanes per piece (an LDS broadcast); pieces ordered [co >> 2][kx][co & 3] so that
+  // each of ds_read_b128's four lane groups {0-3,12-15,20-27}, ... touches 64 distinct banks
+  constexpr int WL = XP ? 32 : 64;                 // 16-byte pieces per (step, nt, precision) block
+  constexpr int W_H = NSTEP * NT * 2 * WL * 8;
   constexpr int Q = CB / 4;                        // 16-byte fp32 pieces per voxel
   constexpr int IN_IT = (NHALO * Q + NTH - 1) / NTH;
   constexpr int W_IT = (W_H / 8 + NTH - 1) / NTH;  // 16-byte pieces per thread
@@ -143,6 +151,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   const int wave = tid >> 6;
   const int m = lane & 15;
   const int g = lane >> 4;      // k-group of the operands; D rows 4g..4g+3
+  // the lane's piece of a weight block; x-pair: [co >> 2][kx][co & 3], conflict-free within ds_read_b128's lane groups
+  const int wslot = XP ? ((((m & 7) >> 2) * 4 + ((g - (m >> 3)) & 3)) * 4 + (m & 3)) : lane;
   const int cg = blockIdx.y;
   const int ntiles = ka.tiles_x * ka.tiles_y * ka.tiles_z;
   const int total = ntiles * a.N;
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   };
   // after a barrier of the item loop: combine what is complete
   auto flush_stats = [&]() {
-    if constexpr (DB == 2) {
+    if constexpr (STAG) {
       flush_one(pendA_n, pendA_tile, pendA_red);
       pendA_n = pendB_n; pendA_tile = pendB_tile; pendA_red = pendB_red;
     } else {
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       pendB_red = redo;
       pendB_tile = tl - n * ntiles;
     }
-    if constexpr (DB == 0) {
+    if constexpr (!SINGLE) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -485,18 +495,19 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
   // one): waves 4..7 run the epilogue of item k after the barrier of item k + 1, so their stores and statistics
   // overlap the MFMA loop of waves 0..3 and vice versa instead of every wave hitting the same phase together.
-  const bool late = DB == 2 && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+  const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
   int red_cur = 0, red_prev = 0, prev_tile = 0;
   bool have_prev = false;
   // DB: item 0 goes into image 0 before the loop, item 1's loads are in flight
-  int db_cur = 0, db_ntile = 0;
+  int db_cur = 0, db_ntile = 0, db_nchunk = 0;   // the item whose loads are in flight
   bool db_nhave = false;
   if constexpr (DB != 0) {
-    commit(true, 0);
+    commit(w_fresh, 0);
     w_fresh = false;
-    db_ntile = tile_lin + (int)gridDim.x;
+    db_ntile = tile_lin; db_nchunk = 1;
+    if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = tile_lin + (int)gridDim.x; }
     db_nhave = db_ntile < total;
-    prefetch(db_ntile, 0, db_nhave, false);
+    prefetch(db_ntile, db_nchunk, db_nhave, false);
   }
 
   while (have) {
@@ -506,17 +517,18 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     if constexpr (DB != 0) {
       __syncthreads();       // image db_cur is complete; everyone is done reading image db_cur ^ 1
       flush_stats();
-      if constexpr (DB == 2) {
-        if (late && have_prev) epilogue(prev_tile, red_prev);
+      if constexpr (STAG) {
+        if (late && have_prev) { epilogue(prev_tile, red_prev); have_prev = false; }
       }
-      ntile = db_ntile; nchunk = 0; nhave = db_nhave;
-      db_ntile = ntile + (int)gridDim.x;
+      ntile = db_ntile; nchunk = db_nchunk; nhave = db_nhave;   // the next item: its loads are in flight
+      db_nchunk = nchunk + 1; db_ntile = ntile;                  // and the one after it
+      if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = ntile + (int)gridDim.x; }
       db_nhave = db_ntile < total;
       cofs = db_cur * BUF_H;
       db_cur ^= 1;
       if (!late) {
-        if (nhave) commit(false, db_cur * BUF_H);            // next item -> the other image (waits for its loads)
-        prefetch(db_ntile, 0, db_nhave, false);              // the item after next -> registers
+        if (nhave) commit(false, db_cur * BUF_H);                // next item -> the other image (waits for its loads)
+        prefetch(db_ntile, db_nchunk, db_nhave, false);          // the item after next -> registers
       }
     } else {
       if (ka.dbg < 3) __syncthreads();
@@ -548,13 +560,13 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const _Float16* wp = s_wc + ((((kz * 3 + ky) * NT) * 2) * 64 + lane) * 8;
+          const _Float16* wp = s_wc + ((((kz * 3 + ky) * NT) * 2) * WL + wslot) * 8;
           const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
-          const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(wp + WL * 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             // DB: one item = one tile, so the first step starts from zero (no accumulator clearing in the epilogue)
-            const bool fresh = DB != 0 && kz == 0 && ky == 0;
+            const bool fresh = SINGLE && kz == 0 && ky == 0;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? zero : acc[r][0], 0, 0, 0);
             accx[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r][0], 0, 0, 0);
@@ -568,9 +580,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       auto load_step = [&](int s, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const _Float16* wp = s_wc + (((s * NT + nt) * 2) * 64 + lane) * 8;
+          const _Float16* wp = s_wc + (((s * NT + nt) * 2) * WL + wslot) * 8;
           ah[slot][nt] = *reinterpret_cast<const f16x8*>(wp);
-          al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+          al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + WL * 8);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -595,10 +607,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       }
     }
 
-    if constexpr (DB == 2) {   // waves 4..7 stage the next item after their MFMA loop: E M C against C M E of waves 0..3
+    if constexpr (STAG) {   // waves 4..7 stage the next item after their MFMA loop: E M C against C M E of waves 0..3
       if (late) {
         if (nhave) commit(false, db_cur * BUF_H);
-        prefetch(db_ntile, 0, db_nhave, false);
+        prefetch(db_ntile, db_nchunk, db_nhave, false);
       }
     }
     if (ka.dbg >= 1) {
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" :: "v"(acc[r][nt]), "v"(accx[r][nt]));
     } else if (chunk == ka.nchunks - 1) {
-      if constexpr (DB == 2) {
+      if constexpr (STAG) {
         if (!late) epilogue(tile_lin, red_cur);
         prev_tile = tile_lin; have_prev = true;
         red_prev = red_cur;
@@ -619,12 +631,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     }
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
-  if constexpr (DB == 2) {
+  if constexpr (STAG) {
     if (late && have_prev) epilogue(prev_tile, red_prev);
   }
   __syncthreads();
   flush_stats();
-  if constexpr (DB == 2) flush_stats();
+  if constexpr (STAG) flush_stats();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,25 +644,26 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 __global__ void pack_conv3d_k3_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int CB,
                                           int NT, int XP, int64_t total) {
   const int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS, nchunks = Cin / CB;
+  const int WL = XP ? 32 : 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int j = r % 8; r /= 8;
-    const int lane = r % 64; r /= 64;
+    const int lane = r % WL; r /= WL;
     const int hl = r % 2; r /= 2;
     const int nt = r % NT; r /= NT;
     const int step = r % NSTEP; r /= NSTEP;
     const int chunk = r % nchunks; r /= nchunks;
     const int rgrp = (int)r;
-    const int row = (rgrp * NT + nt) * 16 + (lane & 15);
-    const int kg = lane >> 4;
-    const int tap = CB == 16 ? 2 * step + (kg >> 1) : 4 * step + kg;
-    const int ci = chunk * CB + (CB == 16 ? 8 * (kg & 1) + j : j);
     float v = 0.f;
-    if (XP) {   // row = dx * 8 + co, step = (kz, ky), k-group = ix
-      const int dx = row >> 3, co = row & 7, kx = kg - dx;
-      if (kx >= 0 && kx <= 2) v = w[((size_t)co * Cin + ci) * 27 + step * 3 + kx];
-    } else if (row < Cout && tap < 27) {
-      v = w[((size_t)row * Cin + ci) * 27 + tap];
+    if (XP) {   // piece [co >> 2][kx][co & 3] of step (kz, ky); kx = 3 is the zero k-group
+      const int kx = (lane >> 2) & 3, co = (lane >> 4) * 4 + (lane & 3), ci = chunk * CB + j;
+      if (kx <= 2) v = w[((size_t)co * Cin + ci) * 27 + step * 3 + kx];
+    } else {
+      const int row = (rgrp * NT + nt) * 16 + (lane & 15);
+      const int kg = lane >> 4;
+      const int tap = CB == 16 ? 2 * step + (kg >> 1) : 4 * step + kg;
+      const int ci = chunk * CB + (CB == 16 ? 8 * (kg & 1) + j : j);
+      if (row < Cout && tap < 27) v = w[((size_t)row * Cin + ci) * 27 + tap];
     }
     const float c = fminf(fmaxf(v, -65504.f), 65504.f);
     const _Float16 h = (_Float16)c;
@@ -671,7 +684,7 @@ static inline int s16_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 
 int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout) {
   const S16Cfg c = s16_config(Cin, Cout);
   const int TPS = 32 / c.CB, NSTEP = c.XP ? 9 : (27 + TPS - 1) / TPS;
-  const int64_t halves = (int64_t)(s16_rows_padded(Cout, c.NT) / 16) * (Cin / c.CB) * NSTEP * 2 * 64 * 8;
+  const int64_t halves = (int64_t)(s16_rows_padded(Cout, c.NT) / 16) * (Cin / c.CB) * NSTEP * 2 * (c.XP ? 32 : 64) * 8;
   return halves / 2;
 }
 
@@ -692,11 +705,12 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   constexpr int NHALO = (TXV + 2) * (TY + 2) * (TZ + 2);
   constexpr int PLANE = (((XP ? NHALO / 2 : NHALO) + 15) / 16) * 16;
   constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
-  constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * 64 * 8 * 2;
-  constexpr size_t red = (size_t)(DB + 1) * NW * NT * 16 * 2 * 4;
-  static_assert((DB ? 2 : 1) * img + wch + red <= 160 * 1024, "LDS budget");
+  constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * (XP ? 32 : 64) * 8 * 2;
+  constexpr size_t red = (size_t)(DB >= 2 ? 3 : DB + 1) * NW * NT * 16 * 2 * 4;
+  static_assert((DB ? 2 : 1) * img + (DB == 3 ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
-  ka.w_all = (!DB && ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0;
+  ka.w_all = DB ? (ka.nchunks > 1 ? 1 : 0)   // double-buffered variants: the dispatch made sure everything fits
+                : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0);
   const size_t lds = (DB ? 2 : 1) * img + (ka.w_all ? ka.nchunks : 1) * wch + red;
   auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP, DB, EPI>;
   static size_t attr_lds = 0;
@@ -734,6 +748,10 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
       if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 2>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 3>(ka, s);
+    }
+    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !getenv("VX_S16_NO_DB") && !getenv("VX_S16_NO_DB3")) {   // 16 -> 8 channels
+      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 1>(ka, s);
+      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 3>(ka, s);
     }
   }
   if (tx == 16 && ka.ty8) {   // large layers: 4 column tiles per wave

@@ -66,7 +66,8 @@ def test_host_only_queries(lib):
         cb = 8 if xp else (16 if cin % 16 == 0 else 8)
         steps = 9 if xp else -(-27 // (32 // cb))
         rows = -(-cout // (16 * nt)) * 16 * nt
-        return (rows // 16) * (cin // cb) * steps * 2 * 64 * 8 // 2
+        pieces = 32 if xp else 64           # x-pair blocks are [co >> 2][kx 4][co & 3] pieces, not one per lane
+        return (rows // 16) * (cin // cb) * steps * 2 * pieces * 8 // 2
     for cin, cout in ((16, 8), (24, 8), (16, 16), (32, 32), (128, 64)):
         assert lib.vx_conv3d_k3_packed_floats(cin, cout) == s16(cin, cout)
     os.environ["VX_CONV_FP32"] = "1"      # native-fp32 kernels: their own packings

@@ -754,12 +754,12 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 3>(ka, s);
     }
   }
-  if (tx == 16 && ka.ty8) {   // large layers: 4 column tiles per wave
-    if constexpr (NT == 1) {
+  if constexpr (NT == 1) {   // large layers: 4 column tiles per wave (vx_conv3d_s16_tile: never with two row tiles)
+    if (tx == 16 && ka.ty8) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 0, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 0, 1>(ka, s);
+      return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);
     }
-    return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);
   }
   if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
   if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
@@ -775,7 +775,10 @@ void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
   const int xp = s16_config(8, Cout).XP;
   const int wcols = xp ? W / 2 : W;
   const int tx = wcols >= 16 ? 16 : (wcols >= 8 ? 8 : 4);
-  const bool ty8 = tx == 16 && H >= 32 && !getenv("VX_S16_NO_TY8");
+  // two row tiles per wave (Cout % 32 == 0) on the large tile would need > 256 registers (75 spilled): small tile there
+  // (measured 32->32 @64^3: 321 TFLOP/s on 16x4x4 tiles against 204 on the spilling 16x8x4 instance)
+  const bool nt2 = !xp && Cout % 32 == 0;
+  const bool ty8 = tx == 16 && H >= 32 && !nt2 && !getenv("VX_S16_NO_TY8");
   *txv = xp ? 2 * tx : tx;
   *ty = (tx == 8 || ty8) ? 8 : 4;
   *tz = 4;

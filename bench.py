@@ -67,11 +67,13 @@ def kernel_name(kind, ci, co, edge, label=""):
             nt = 2 if co % 32 == 0 else 1
             ex = edge // 2 if xp else edge
             if ex >= 16:   # vx_conv3d_s16_tile: large layers (H >= 32) take 16 x 8 x 4 tiles
-                tile, nw = ("16,8,4" if edge >= 32 else "16,4,4"), 8
+                tile, nw = ("16,8,4" if (edge >= 32 and nt == 1) else "16,4,4"), 8
             else:
                 tile, nw = ("8,8,4", 8) if ex >= 8 else ("4,4,4", 4)
-            # DB = 2: single-chunk x-pair layers on the large tile run the double-buffered, staggered variant
-            db = 2 if (xp and tile == "16,8,4" and ci == cb and not os.environ.get("VX_S16_NO_DB")) else 0
+            # DB = 2: x-pair layers on the large tile run the double-buffered, staggered variant
+            db = 0
+            if xp and tile == "16,8,4" and not os.environ.get("VX_S16_NO_DB"):
+                db = 2 if ci == cb else (3 if ci == 2 * cb else 0)   # 3: the same for two chunks per tile (16 -> 8)
             # EPI: compile-time epilogue of the large-tile instances -- 0 plain (encoder: an InstanceNorm follows),
             # 1 LeakyReLU + hash dropout (decoder), 2 = 1 + fused 1x1x1 head (expand_1_2), 3 run-time (all others)
             epi = 3

@@ -69,12 +69,15 @@ class MapGatherPipeline:
     kernels overlap the transfer -- at ~1 900 volumes/s a step of 16 volumes is 8 ms of compute and 88 MB of maps
     per rank, i.e. 0.6 GB into rank 0 per step at 8 GPUs); `collect()` waits for the OLDEST gather in flight and
     returns its maps on dst (None elsewhere).  submit() collects first when `depth` gathers are already in flight,
-    so a send buffer is never overwritten while it is being read.  world == 1: submit/collect are a FIFO."""
+    so a send buffer is never overwritten while it is being read.  There are depth + 1 buffer slots: the maps a
+    submit() hands back are views of the receive buffer of the gather it just collected, and the gather it starts must
+    not land in that same buffer -- they stay valid until the NEXT submit().  world == 1: submit/collect are a FIFO."""
 
     def __init__(self, world: int, rank: int, dst: int = 0, depth: int = 2):
         self.world, self.rank, self.dst, self.depth = world, rank, dst, max(1, depth)
-        self._send = [None] * self.depth
-        self._recv = [None] * self.depth
+        self._slots = self.depth + 1
+        self._send = [None] * self._slots
+        self._recv = [None] * self._slots
         self._inflight = []      # [(slot, works)] oldest first
         self._next = 0
         self._use_all_gather = False
@@ -89,7 +92,7 @@ class MapGatherPipeline:
         if len(self._inflight) >= self.depth:
             done = self.collect()
         slot = self._next
-        self._next = (self._next + 1) % self.depth
+        self._next = (self._next + 1) % self._slots
         if self.world == 1:
             self._inflight.append((slot, out))
             return done
@@ -126,7 +129,7 @@ class MapGatherPipeline:
 
     def collect(self) -> Optional[Dict[str, torch.Tensor]]:
         """Maps of the oldest gather in flight (dst) / None.  The returned tensors are views of the slot's receive
-        buffer: valid until `depth` further submits."""
+        buffer: valid until the next submit()."""
         if not self._inflight:
             return None
         slot, works = self._inflight.pop(0)

@@ -202,6 +202,68 @@ def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):
         assert (got[int(dst[i])].cpu().double() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,shape,xb", [
+    (8, 8, (3, 8, 32, 64), 0), (8, 8, (2, 5, 37, 70), 0),        # one chunk per tile: double-buffered, staggered (DB = 2)
+    (16, 8, (2, 8, 32, 64), 4), (16, 8, (3, 4, 33, 40), 0),       # two chunks per tile (DB = 3), x-blocked concat input
+    (16, 16, (2, 6, 35, 34), 0), (8, 16, (2, 8, 32, 32), 0),      # plain large-tile instances (EPI only)
+])
+@pytest.mark.parametrize("mode", ["plain_stats", "lrelu_hash", "lrelu_hash_head"])
+def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mode, monkeypatch):
+    """The large-tile instances of conv3d_s16.hip with compile-time epilogues (EPI 0 / 1 / 2) and the double-buffered,
+    staggered item loop (DB 2 / 3) must give the bits of the generic kernel (two barriers per item, run-time
+    epilogue: VX_S16_NO_DB=1 VX_S16_NO_EPI=1) -- output, statistics partials and fused head, hash dropout included."""
+    if mode == "lrelu_hash_head" and cout != 8:
+        pytest.skip("the head rides in x-pair epilogues only")
+    lib = _lib.load()
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 171))
+    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 172, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((cout,), 173, scale=0.2))
+    xd = (to_xblk(x[:, :cin // 2].float(), x[:, cin // 2:].float(), xb) if xb else cl(x.float())).to(dev())
+    wd, bd = wt.float().contiguous().to(dev()), b.float().to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wd), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+    ncls = 2
+    hw = torch.from_numpy(formula_tensor((ncls, 8, 1, 1, 1), 174, scale=0.3)).float().contiguous().to(dev())
+    hb = torch.from_numpy(formula_tensor((ncls,), 175, scale=0.2)).float().to(dev())
+    flip = torch.tensor([(3 * i + 1) % 8 for i in range(n)], dtype=torch.int32, device=dev())
+    nt = lib.vx_conv3d_k3_tiles_for(d, h, w, cout)
+
+    def run():
+        out = torch.full((n, d, h, w, cout), -3.0, dtype=torch.float32, device=dev())
+        st = torch.zeros((n, nt, cout, 2), dtype=torch.float32, device=dev())
+        head = torch.full((n, ncls, d, h, w), -5.0, dtype=torch.float32, device=dev())
+        a = _lib.ConvArgs()
+        a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+        a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+        a.in_xblk = xb
+        if mode == "plain_stats":
+            a.stats_partial = st.data_ptr()
+        else:
+            a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 77, 5
+        if mode == "lrelu_hash_head":
+            a.out = None
+            a.head_out, a.head_w, a.head_b, a.head_C = head.data_ptr(), hw.data_ptr(), hb.data_ptr(), ncls
+            a.head_flip = flip.data_ptr()
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+        torch.cuda.synchronize()
+        return out, st, head
+
+    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    got = run()
+    monkeypatch.setenv("VX_S16_NO_DB", "1")
+    monkeypatch.setenv("VX_S16_NO_EPI", "1")
+    ref = run()
+    for g, r in zip(got, ref):
+        assert torch.equal(g, r)
+    if mode == "plain_stats":   # and the statistics are the sums of what was stored
+        tot = got[1].double().sum(1)
+        o = got[0].double()
+        assert torch.allclose(tot[..., 0], o.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(tot[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
 def test_conv3d_k3_epilogue_act_mask_pitch(conv_mode):
     x = torch.from_numpy(formula_tensor((1, 16, 8, 8, 16), 111))
     wt = torch.from_numpy(formula_tensor((8, 16, 3, 3, 3), 112, scale=0.05))

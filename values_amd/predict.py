@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _lib
-from .uncertainty import uncertainty_maps
+from .uncertainty import alloc_uncertainty_maps, uncertainty_maps
 
 # flip code bit0 = dim 2 (D), bit1 = dim 3 (H), bit2 = dim 4 (W); order of test_3D.py:430
 FLIP_DIMS = [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]
@@ -58,11 +58,33 @@ def predict_logits_ssn(model, x: torch.Tensor, n_pred: int = 1, eps_w=None, eps_
     return dist.sample_volumes(n_pred, eps_w=eps_w, eps_d=eps_d, seed=seed)
 
 
+_side_streams: Dict[int, list] = {}
+
+
+def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, samples_per_volume: int = 1):
+    """[(v0, v1)] volume ranges, one per HIP stream.  Two half batches on two streams hide most of one half's HBM-bound
+    launches (normalise / pool, transposed convs) under the other's convolutions: +3..5 % on the 64^3 MC-dropout
+    batch (tools/exp_streams.py); more streams do not add to it.  One stream when masks / noise are injected per
+    sample (parity tests) or the batch is too small to split."""
+    import os
+    if n_streams is None:
+        n_streams = int(os.environ.get("VX_STREAMS", "2"))
+    n = 1 if (pinned_inputs or V < 4) else max(1, min(int(n_streams), V // 2))
+    while n > 1 and (V // n) * samples_per_volume < 64:   # small sample batches lose more in the kernels than overlap wins
+        n -= 1
+    from .dist import shard_range
+    return [shard_range(V, n, k) for k in range(n)]
+
+
 def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
                    x_noise: Optional[torch.Tensor] = None, dropout_masks=None, seeds=None,
-                   n_aleatoric_samples: int = 10, eps=None, **kw_ssn) -> torch.Tensor:
+                   n_aleatoric_samples: int = 10, eps=None, n_streams: Optional[int] = None, _after_chunk=None,
+                   **kw_ssn) -> torch.Tensor:
     """x: (V,1,D,H,W).  Returns logits (V, n_total, C, D,H,W) f32 on the device, n_total = passes per volume in
-    pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests)."""
+    pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests).  n_streams: volume chunks
+    run concurrently on that many HIP streams (default: VX_STREAMS or 2), each with its own workspace; every chunk
+    writes straight into its pred_idx slots of the one logits tensor.  _after_chunk(logits, v0, v1): called on the
+    chunk's stream once its forwards are enqueued (predict_uncertainty reduces the chunk there)."""
     _lib.require_gpu()
     dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
     x = x.to(dev, torch.float32)
@@ -80,28 +102,51 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
     C = models[0].num_classes
     logits = torch.empty((V, n_total, C, D, H, W), dtype=torch.float32, device=dev)
     flat = logits.view(V * n_total, C, D, H, W)
-    vidx = torch.arange(V, device=dev, dtype=torch.int32)
-    for mi, model in enumerate(models):
-        base = mi * per_model
-        if tta:
-            if x_noise is None:
-                x_noise = gaussian_noise_view(x)
-            xin = torch.cat([x, x_noise.to(dev, torch.float32)], 0)  # volumes [0,V) orig, [V,2V) noisy
-            k = torch.arange(16, device=dev, dtype=torch.int32)
-            codes = torch.tensor(TTA_FLIP_CODES * 2, device=dev, dtype=torch.int32)
-            src = (vidx[:, None] + (k[None, :] // 8) * V).reshape(-1)           # sample (v,k) reads orig / noisy v
-            flip = codes[None, :].expand(V, 16).reshape(-1)
-            dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
-            model(xin, src=src, flip=flip, dst=dst, out=flat)
-        else:
-            k = torch.arange(n_pred, device=dev, dtype=torch.int32)
-            dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
-            kw = {}
-            if dropout_masks is not None:
-                kw["dropout_masks"] = dropout_masks[mi]
-            if seeds is not None:
-                kw["seed"] = seeds[mi]
-            model(x, n_samples=n_pred, dst=dst, out=flat, **kw)
+    if tta and x_noise is None:
+        x_noise = gaussian_noise_view(x)
+    if tta:
+        x_noise = x_noise.to(dev, torch.float32)
+    chunks = _volume_chunks(V, n_streams, pinned_inputs=dropout_masks is not None, samples_per_volume=per_model)
+    main = torch.cuda.current_stream(dev)
+    side = [main]
+    if len(chunks) > 1:
+        pool = _side_streams.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+        while len(pool) < len(chunks):
+            pool.append(torch.cuda.Stream(device=dev))
+        side = pool[:len(chunks)]
+        for st in side:
+            st.wait_stream(main)          # x, x_noise and the logits buffer were produced on the caller's stream
+    for ci, ((v0, v1), st) in enumerate(zip(chunks, side)):
+        with torch.cuda.stream(st):
+            Vc = v1 - v0
+            vidx = torch.arange(v0, v1, device=dev, dtype=torch.int32)
+            xc = x[v0:v1]
+            for mi, model in enumerate(models):
+                base = mi * per_model
+                if tta:
+                    xin = torch.cat([xc, x_noise[v0:v1]], 0)  # volumes [0,Vc) orig, [Vc,2Vc) noisy
+                    k = torch.arange(16, device=dev, dtype=torch.int32)
+                    codes = torch.tensor(TTA_FLIP_CODES * 2, device=dev, dtype=torch.int32)
+                    lidx = torch.arange(Vc, device=dev, dtype=torch.int32)
+                    src = (lidx[:, None] + (k[None, :] // 8) * Vc).reshape(-1)      # sample (v,k) reads orig / noisy v
+                    flip = codes[None, :].expand(Vc, 16).reshape(-1)
+                    dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
+                    model(xin, src=src, flip=flip, dst=dst, out=flat)
+                else:
+                    k = torch.arange(n_pred, device=dev, dtype=torch.int32)
+                    dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
+                    kw = {}
+                    if dropout_masks is not None:
+                        kw["dropout_masks"] = dropout_masks[mi]
+                    if seeds is not None:
+                        # one hash-dropout stream per (member seed, chunk): sample indices restart in every chunk
+                        kw["seed"] = (int(seeds[mi]) + 0x9E3779B1 * ci) & 0xFFFFFFFF
+                    model(xc, n_samples=n_pred, dst=dst, out=flat, **kw)
+            if _after_chunk is not None:
+                _after_chunk(logits, v0, v1)
+    if len(chunks) > 1:
+        for st in side:
+            main.wait_stream(st)
     return logits
 
 
@@ -112,8 +157,25 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
     """Forward passes + fused reduction.  Returns device tensors keyed like the reference's results:
     pred_entropy / aleatoric_uncertainty / epistemic_uncertainty (V,D,H,W) f32 (test_3D.py:509-516),
     mean_softmax (V,C,D,H,W), pred_seg_mean (V,D,H,W) u8 (data_carrier_3D.py:254-255), logits."""
-    logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, **kw)
-    m = uncertainty_maps(logits, from_logits=True, want_sample_argmax=want_sample_argmax)
+    m = None
+    one_batch = (hasattr(models[0], "rank") and hasattr(models[0], "cov_factor_conv")) or \
+        (bool(getattr(models[0], "aleatoric_loss", False)) and not tta)      # SSN / aleatoric head: no volume chunks
+    if not one_batch:
+        # the batch's maps, allocated on the caller's stream; every volume chunk reduces into its rows on its own stream
+        _lib.require_gpu()
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        n_total = (16 if tta else n_pred) * len(models)
+        m = alloc_uncertainty_maps(x.shape[0], n_total, models[0].num_classes, tuple(x.shape[2:]), dev,
+                                   want_sample_argmax=want_sample_argmax)
+
+    def reduce_chunk(lg, v0, v1):
+        uncertainty_maps(lg[v0:v1], from_logits=True, want_sample_argmax=want_sample_argmax,
+                         out={k: t[v0:v1] for k, t in m.items()})
+
+    logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise,
+                            _after_chunk=None if one_batch else reduce_chunk, **kw)
+    if one_batch:
+        m = uncertainty_maps(logits, from_logits=True, want_sample_argmax=want_sample_argmax)
     out = {"pred_entropy": m["pred_entropy"], "mean_softmax": m["mean_softmax"], "pred_seg_mean": m["argmax"],
            "logits": logits}
     if not ssn:

@@ -22,18 +22,7 @@ def _dev_tensor(t: torch.Tensor):
     return t.detach().to(dev).contiguous(), dev
 
 
-def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool = True, want_argmax: bool = True,
-                     want_sample_argmax: bool = False) -> Dict[str, torch.Tensor]:
-    """x: (B, T, C, *spatial) probabilities or logits (f32/f64) -> dict of device tensors:
-    pred_entropy, expected_entropy, mutual_information (B,*spatial) f32, mean_softmax (B,C,*spatial) f32,
-    argmax (B,*spatial) u8, sample_argmax (B,T,*spatial) u8."""
-    lib = _lib.load()
-    xd, dev = _dev_tensor(x)
-    B, T, Cc = xd.shape[:3]
-    spatial = tuple(xd.shape[3:])
-    nvox = 1
-    for s in spatial:
-        nvox *= s
+def alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean=True, want_argmax=True, want_sample_argmax=False):
     out = {
         "pred_entropy": torch.empty((B,) + spatial, dtype=torch.float32, device=dev),
         "expected_entropy": torch.empty((B,) + spatial, dtype=torch.float32, device=dev),
@@ -45,6 +34,28 @@ def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool
         out["argmax"] = torch.empty((B,) + spatial, dtype=torch.uint8, device=dev)
     if want_sample_argmax:
         out["sample_argmax"] = torch.empty((B, T) + spatial, dtype=torch.uint8, device=dev)
+    return out
+
+
+def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool = True, want_argmax: bool = True,
+                     want_sample_argmax: bool = False, out: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """x: (B, T, C, *spatial) probabilities or logits (f32/f64) -> dict of device tensors:
+    pred_entropy, expected_entropy, mutual_information (B,*spatial) f32, mean_softmax (B,C,*spatial) f32,
+    argmax (B,*spatial) u8, sample_argmax (B,T,*spatial) u8.  `out`: write into these (contiguous, e.g. the rows of a
+    larger batch's maps from alloc_uncertainty_maps) instead of allocating."""
+    lib = _lib.load()
+    xd, dev = _dev_tensor(x)
+    B, T, Cc = xd.shape[:3]
+    spatial = tuple(xd.shape[3:])
+    nvox = 1
+    for s in spatial:
+        nvox *= s
+    if out is None:
+        out = alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean, want_argmax, want_sample_argmax)
+    else:
+        for k, t in out.items():
+            if not t.is_contiguous() or t.shape[0] != B or t.device != dev:
+                raise ValueError(f"uncertainty_maps: out[{k!r}] must be a contiguous device tensor with {B} rows")
     rc = lib.vx_unc_reduce(_lib.ptr(xd), _lib.VX_F64 if xd.dtype == torch.float64 else _lib.VX_F32, int(from_logits),
                            B, T, Cc, nvox, _lib.ptr(out.get("mean_softmax")), _lib.ptr(out["pred_entropy"]),
                            _lib.ptr(out["expected_entropy"]), _lib.ptr(out["mutual_information"]),

@@ -140,12 +140,17 @@ class UNet3D(nn.Module):
         return sd[head + ".weight"].reshape(sd[head + ".weight"].shape[0], -1).contiguous(), sd[head + ".bias"]
 
     def _workspace(self, N, D, H, W, device):
-        key = (N, D, H, W, str(device))
-        ws = self._ws.get(key)
-        if ws is None:
+        # one workspace per stream (forwards of volume chunks may be in flight on several streams), each keeping the
+        # last geometry it was used with
+        geo = (N, D, H, W, str(device))
+        sid = torch.cuda.current_stream(device).cuda_stream
+        ent = self._ws.get(sid)
+        if ent is None or ent[0] != geo:
             nbytes = _lib.load().vx_unet3d_workspace_bytes(N, D, H, W, self.initial_filter_size)
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
-            self._ws = {key: ws}  # keep one geometry resident
+            self._ws.pop(sid, None)
+            ent = (geo, torch.empty(nbytes + 256, dtype=torch.uint8, device=device))
+            self._ws[sid] = ent
+        ws = ent[1]
         off = (-ws.data_ptr()) % 256
         return ws, off, ws.numel() - 256
 

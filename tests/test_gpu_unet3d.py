@@ -241,6 +241,39 @@ def test_full_size_properties_64_T10():
     assert (a["mean_softmax"] - c["mean_softmax"]).abs().mean().item() < 0.05
 
 
+def test_volume_chunks_on_two_streams_equal_one_stream():
+    """predict's n_streams: two volume chunks on two HIP streams (own workspace, own map reduction) give the bits of the
+    one-stream run -- everything for a deterministic network, the first chunk's rows with hash dropout (the second
+    chunk draws its masks from another hash stream); TTA views and small batches included."""
+    from values_amd import predict_uncertainty
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1, 16, 16, 16), tag=40 + i) for i in range(8)], 0)).float().cuda()
+    keys = KEYS + ("mean_softmax", "pred_seg_mean", "logits")
+    det = make_model(do_dropout=False)
+    a = predict_uncertainty([det], x, n_pred=16, n_streams=1)
+    b = predict_uncertainty([det], x, n_pred=16, n_streams=2)      # 2 chunks x 4 volumes x 16 passes
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k
+    a = predict_uncertainty([det], x, tta=True, x_noise=x * 1.01, n_streams=1)
+    b = predict_uncertainty([det], x, tta=True, x_noise=x * 1.01, n_streams=2)
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k
+    mc = make_model(do_dropout=True)
+    a = predict_uncertainty([mc], x, n_pred=16, seeds=[5], n_streams=1)
+    b = predict_uncertainty([mc], x, n_pred=16, seeds=[5], n_streams=2)
+    c = predict_uncertainty([mc], x, n_pred=16, seeds=[5], n_streams=2)
+    for k in keys:
+        assert torch.equal(a[k][:4], b[k][:4]), k
+        assert torch.equal(b[k], c[k]), k                               # and the chunked run is reproducible
+        assert not torch.isnan(b[k].float()).any()
+    assert not torch.equal(a["logits"][4:], b["logits"][4:])
+    assert abs(a["epistemic_uncertainty"][4:].mean().item() - b["epistemic_uncertainty"][4:].mean().item()) < \
+        0.5 * a["epistemic_uncertainty"][4:].mean().item()
+    # too few samples per chunk: stays on one stream, same result object layout
+    s1 = predict_uncertainty([det], x[:3], n_pred=2, n_streams=2)
+    s0 = predict_uncertainty([det], x[:3], n_pred=2, n_streams=1)
+    assert torch.equal(s0["pred_entropy"], s1["pred_entropy"])
+
+
 def test_hash_dropout_is_the_same_distribution_as_torch_dropout_16():
     """Our dropout bit generator cannot reproduce torch's CPU bernoulli stream ("Dropout RNG parity"),
     so compare DISTRIBUTIONS: the oracle with T_ref independent numpy-drawn Bernoulli(0.5) masks vs our hash

@@ -63,8 +63,8 @@ _side_streams: Dict[int, list] = {}
 
 def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, samples_per_volume: int = 1):
     """[(v0, v1)] volume ranges, one per HIP stream.  Two half batches on two streams hide most of one half's HBM-bound
-    launches (normalise / pool, transposed convs) under the other's convolutions: +3..5 % on the 64^3 MC-dropout
-    batch (tools/exp_streams.py); more streams do not add to it.  One stream when masks / noise are injected per
+    launches (normalise / pool, transposed convs) under the other's convolutions: +2 % on the 64^3 MC-dropout
+    batch of bench.py (un-joined streams: +3..5 %, tools/exp_streams.py); more streams do not add to it.  One stream when masks / noise are injected per
     sample (parity tests) or the batch is too small to split."""
     import os
     if n_streams is None:
@@ -73,7 +73,13 @@ def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, sample
     while n > 1 and (V // n) * samples_per_volume < 64:   # small sample batches lose more in the kernels than overlap wins
         n -= 1
     from .dist import shard_range
-    return [shard_range(V, n, k) for k in range(n)]
+    # several chunks per stream (round robin) let the two streams drift out of lockstep after the join that starts a
+    # step: 3 per stream measured best on the 64^3 T = 10 batch (+1.5 % over one); chunks stay >= 48 samples
+    per = os.environ.get("VX_CHUNKS_PER_STREAM")
+    per = int(per) if per else min(3, ((V // n) * samples_per_volume) // 48)
+    nc = n * max(1, per) if n > 1 else 1
+    nc = max(n, min(nc, V))
+    return [shard_range(V, nc, k) for k in range(nc)], n
 
 
 def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
@@ -106,18 +112,18 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
         x_noise = gaussian_noise_view(x)
     if tta:
         x_noise = x_noise.to(dev, torch.float32)
-    chunks = _volume_chunks(V, n_streams, pinned_inputs=dropout_masks is not None, samples_per_volume=per_model)
+    chunks, n_side = _volume_chunks(V, n_streams, pinned_inputs=dropout_masks is not None, samples_per_volume=per_model)
     main = torch.cuda.current_stream(dev)
     side = [main]
     if len(chunks) > 1:
         pool = _side_streams.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
-        while len(pool) < len(chunks):
+        while len(pool) < n_side:
             pool.append(torch.cuda.Stream(device=dev))
-        side = pool[:len(chunks)]
+        side = pool[:n_side]
         for st in side:
             st.wait_stream(main)          # x, x_noise and the logits buffer were produced on the caller's stream
-    for ci, ((v0, v1), st) in enumerate(zip(chunks, side)):
-        with torch.cuda.stream(st):
+    for ci, (v0, v1) in enumerate(chunks):
+        with torch.cuda.stream(side[ci % len(side)]):
             Vc = v1 - v0
             vidx = torch.arange(v0, v1, device=dev, dtype=torch.int32)
             xc = x[v0:v1]

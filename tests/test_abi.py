@@ -84,6 +84,16 @@ def test_host_only_queries(lib):
     assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
     assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 8 * 16   # split-fp16 x-pair tiles of large layers: 32 x 8 x 4
     assert lib.vx_conv3d_k3_tiles_for(16, 16, 16, 16) == 1 * 4 * 4  # small layers: 16 x 4 x 4
+    # vx_conv3d_k3_tiles sizes stats_partial for any layer: an upper bound of every tiling, in both modes (for
+    # 8 <= W < 16 the x-pair tiling makes the most tiles, elsewhere the plain one: tools/fuzz_conv.py found the gap)
+    for mode in ("0", "1"):
+        os.environ["VX_CONV_FP32"] = mode
+        try:
+            for d, h, w in ((8, 52, 13), (3, 5, 9), (4, 40, 15), (64, 64, 64), (5, 37, 70), (1, 1, 1), (6, 33, 16), (7, 31, 33)):
+                for cout in (8, 16, 32, 64):
+                    assert lib.vx_conv3d_k3_tiles(d, h, w) >= lib.vx_conv3d_k3_tiles_for(d, h, w, cout), (mode, d, h, w, cout)
+        finally:
+            del os.environ["VX_CONV_FP32"]
     assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised shapes through vx_conv3d_k3: the default (specialised, double-buffered) instances must equal the generic
+split-fp16 kernel bit for bit and the native-fp32 kernels within 2e-5.    python tools/fuzz_conv.py [cases] [seed]"""
+import ctypes as C, os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from values_amd import _lib
+
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(cases):
+    cin, cout = rng.choice([(8, 8), (16, 8), (8, 8), (16, 8), (16, 16), (8, 16), (32, 16), (32, 32), (24, 8)])
+    big = rng.random() < 0.6
+    d = rng.randint(1, 9)
+    h = rng.randint(32, 70) if big else rng.randint(1, 31)
+    w = rng.randint(1, 70)
+    n = rng.randint(1, 40 if rng.random() < 0.2 else 4)
+    mode = rng.choice(["plain_stats", "lrelu_hash", "head", "relu"])
+    if mode == "head" and (cout != 8 or cin not in (8, 16)):
+        mode = "lrelu_hash"
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn((n, d, h, w, cin), generator=g).to(dev)
+    wt = (torch.randn((cout, cin, 3, 3, 3), generator=g) * (1.0 / (27 * cin)) ** 0.5).to(dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    hw = (torch.randn((2, 8), generator=g) * 0.3).contiguous().to(dev)
+    hb = torch.randn((2,), generator=g).to(dev)
+    nt = lib.vx_conv3d_k3_tiles(d, h, w)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("VX_S16_NO_DB", "VX_S16_NO_EPI", "VX_CONV_FP32")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+            out = torch.full((n, d, h, w, cout), -3.0, device=dev)
+            st = torch.zeros((n, nt, cout, 2), device=dev)
+            head = torch.full((n, 2, d, h, w), -5.0, device=dev)
+            a = _lib.ConvArgs()
+            a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
+            a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+            a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+            if mode == "plain_stats":
+                a.stats_partial = st.data_ptr()
+            elif mode == "relu":
+                a.act = _lib.VX_ACT_RELU
+            else:
+                a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 9, 3
+            if mode == "head":
+                a.out = None
+                a.head_out, a.head_w, a.head_b, a.head_C = head.data_ptr(), hw.data_ptr(), hb.data_ptr(), 2
+            _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+            torch.cuda.synchronize()
+            return out, st, head
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(f"case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}", flush=True)
+    got = run({})
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("  default ok", flush=True)
+    gen = run({"VX_S16_NO_DB": "1", "VX_S16_NO_EPI": "1"})
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("  generic ok", flush=True)
+    f32 = run({"VX_CONV_FP32": "1"})
+    ok = all(torch.equal(p, q) for p, q in zip(got, gen))
+    tile_counts_differ = False
+    err = max((got[0] - f32[0]).abs().max().item(), (got[2] - f32[2]).abs().max().item())
+    serr = 0.0
+    if mode == "plain_stats":   # tilings differ between the two modes: compare the totals
+        serr = (got[1].double().sum((0, 1)) - f32[1].double().sum((0, 1))).abs().max().item() / max(1.0, n * d * h * w) ** 0.5
+    if not ok or err > 2e-5 or serr > 1e-4 or torch.isnan(got[0]).any():
+        bad += 1
+        print(f"FAIL case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}: bit-equal={ok} err_vs_fp32={err:.2e} stats={serr:.2e}")
+print(f"{cases} cases, {bad} failures")
+sys.exit(1 if bad else 0)

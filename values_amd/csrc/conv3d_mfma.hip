@@ -553,9 +553,22 @@ static int conv_tiles(int D, int H, int W, int Cout) {
   return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
 }
 extern "C" int vx_conv3d_k3_tiles(int D, int H, int W) {
-  // upper bound over every packing and mode (stats_partial sizing): the plain 16 x 4 x 4 tiling has the most tiles
-  const TileCfg t = tile_config(W, 0);
-  return ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
+  // upper bound over every packing, Cout and mode (stats_partial sizing).  Neither tiling dominates: for 8 <= W < 16
+  // the x-pair tile (4 pairs x 4 x 4) makes twice the tiles of the plain 8 x 8 x 4 one, for W >= 16 it is the reverse
+  int best = 0;
+  for (int xp = 0; xp < 2; ++xp) {
+    const TileCfg t = tile_config(W, xp);
+    const int n = ((W + t.TXV - 1) / t.TXV) * ((H + t.TY - 1) / t.TY) * ((D + t.TZ - 1) / t.TZ);
+    if (n > best) best = n;
+  }
+  const int couts[3] = {8, 16, 32};   // split-fp16: x-pair / one row tile (large tile) / two row tiles
+  for (int i = 0; i < 3; ++i) {
+    int txv, ty, tz;
+    vx_conv3d_s16_tile(H, W, couts[i], &txv, &ty, &tz);
+    const int n = ((W + txv - 1) / txv) * ((H + ty - 1) / ty) * ((D + tz - 1) / tz);
+    if (n > best) best = n;
+  }
+  return best;
 }
 extern "C" int vx_conv3d_k3_tiles_for(int D, int H, int W, int Cout) { return conv_tiles(D, H, W, Cout); }
 

@@ -274,6 +274,21 @@ def test_volume_chunks_on_two_streams_equal_one_stream():
     assert torch.equal(s0["pred_entropy"], s1["pred_entropy"])
 
 
+def test_mode_switch_repacks_the_weights(monkeypatch):
+    """The packed weight layout belongs to the kernel family: switching VX_CONV_FP32 on a live model must re-pack
+    (the cache is keyed on _lib.pack_mode()), not feed split-fp16 blocks to the native-fp32 kernels."""
+    model = make_model(do_dropout=False)
+    x = torch.from_numpy(formula_volume((2, 1, 16, 16, 16), tag=51)).float().cuda()
+    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    a = model(x)
+    monkeypatch.setenv("VX_CONV_FP32", "1")
+    b = model(x)
+    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    c = model(x)
+    assert (a - b).abs().max().item() < LOGIT_TOL
+    assert torch.equal(a, c)
+
+
 def test_hash_dropout_is_the_same_distribution_as_torch_dropout_16():
     """Our dropout bit generator cannot reproduce torch's CPU bernoulli stream ("Dropout RNG parity"),
     so compare DISTRIBUTIONS: the oracle with T_ref independent numpy-drawn Bernoulli(0.5) masks vs our hash

@@ -280,7 +280,7 @@ class HighResolutionNet(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def _ensure_packed(self, dev):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters()) + (_lib.pack_mode(),)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         lib = _lib.load()

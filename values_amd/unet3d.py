@@ -90,7 +90,7 @@ class UNet3D(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in self.parameters()) + (_lib.pack_mode(),)
 
     def _ensure_packed(self, device):
         key = self._param_key()

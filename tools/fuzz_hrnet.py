@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised image sizes / batches through the small HRNet of the tests: split-fp16 (default) against the native-fp32
+kernels (one model instance per mode: weights are packed per kernel family), same hash-dropout seeds.
+    python tools/fuzz_hrnet.py [cases] [seed]"""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from tests.test_gpu_hrnet import make
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+os.environ.pop("VX_CONV_FP32", None)
+m16, _, _ = make(dropout_final=True)
+m32, _, _ = make(dropout_final=True)
+bad = 0
+for case in range(cases):
+    n = rng.randint(1, 4)
+    h, w = 32 * rng.randint(1, 6), 32 * rng.randint(1, 8)
+    if rng.random() < 0.3:      # not a multiple of 32: the strided convs round like the reference's
+        h += rng.choice([2, 4, 6, 10, 16])
+        w += rng.choice([2, 4, 8, 14, 16])
+    T = rng.randint(1, 3)
+    x = torch.randn((n, 3, h, w), generator=torch.Generator().manual_seed(case)).cuda()
+    tag = f"case {case}: n={n} {h}x{w} T={T}"
+    try:
+        os.environ.pop("VX_CONV_FP32", None)
+        a = m16.forward_samples(x, T, seeds=list(range(T)))
+        os.environ["VX_CONV_FP32"] = "1"
+        b = m32.forward_samples(x, T, seeds=list(range(T)))
+        torch.cuda.synchronize()
+    except Exception as e:
+        print(f"ERROR {tag}: {type(e).__name__}: {e}")
+        bad += 1
+        continue
+    finally:
+        os.environ.pop("VX_CONV_FP32", None)
+    err = (a - b).abs().max().item()
+    scale = max(1.0, a.abs().max().item())
+    if a.shape != b.shape or err > 5e-4 * scale or torch.isnan(a).any():
+        bad += 1
+        print(f"FAIL {tag}: err {err:.2e} scale {scale:.1f} shape {tuple(a.shape)}")
+    elif os.environ.get("FUZZ_VERBOSE"):
+        print(f"ok   {tag}: err {err:.2e} scale {scale:.1f}")
+print(f"{cases} cases, {bad} failures")
+sys.exit(1 if bad else 0)

@@ -476,6 +476,27 @@ def test_conv1x1_slots_and_unflip():
 
 
 # ------------------------------------------------------------------------------------------- reduction
+def test_unc_reduce_from_logits_with_more_than_eight_classes():
+    """uncertainty_maps(from_logits=True) for wide heads (19 Cityscapes classes): planar softmax + probability
+    reduction on the device, same maps as the fused logit kernel gives for narrow heads (test_3D.py:486-518)."""
+    from values_amd.uncertainty import uncertainty_maps
+    for C_, T_ in ((19, 5), (9, 3), (8, 4)):
+        x = torch.from_numpy(formula_tensor((2, T_, C_, 5, 7, 3), 300 + C_, scale=3.0)).float()
+        m = uncertainty_maps(x.cuda(), from_logits=True, want_sample_argmax=True)
+        p = torch.softmax(x.double(), 2)
+        mean = p.mean(1)
+        pe = -(mean * torch.log(mean)).sum(1)
+        ee = -(p * torch.log(p)).sum(2).mean(1)
+        assert (m["pred_entropy"].cpu().double() - pe).abs().max().item() < 2e-5
+        assert (m["expected_entropy"].cpu().double() - ee).abs().max().item() < 2e-5
+        assert (m["mutual_information"].cpu().double() - (pe - ee)).abs().max().item() < 2e-5
+        assert (m["mean_softmax"].cpu().double() - mean).abs().max().item() < 1e-6
+        assert torch.equal(m["argmax"].cpu().long(), mean.argmax(1))
+        assert torch.equal(m["sample_argmax"].cpu().long(), p.argmax(2))
+    with pytest.raises(ValueError):
+        uncertainty_maps(torch.zeros((1, 2, 9, 4), dtype=torch.float64).cuda(), from_logits=True)
+
+
 @pytest.mark.parametrize("case", ["hand", "r3d", "r2d", "ex"])
 def test_unc_reduce_matches_reference_fixtures(case):
     from values_amd import calculate_uncertainty

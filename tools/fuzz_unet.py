@@ -14,7 +14,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
     f = rng.choice([8, 8, 8, 16, 4])
-    ncls = rng.choice([2, 2, 3, 5])
+    ncls = rng.choice([2, 2, 3, 5, 8, 9, 12, 19])
     dims = [16 * rng.randint(1, 5 if f <= 8 else 3) for _ in range(3)]
     V = rng.randint(1, 6)
     T = rng.choice([1, 2, 5, 10, 16])

@@ -50,6 +50,14 @@ def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool
     nvox = 1
     for s in spatial:
         nvox *= s
+    if from_logits and Cc > 8:
+        # the fused logit kernel keeps a voxel's C logits of one sample in registers (C <= 8); wider heads (Cityscapes:
+        # 19 classes) take the planar softmax kernel first and the probability reduction after, as predict2d does
+        if xd.dtype != torch.float32:
+            raise ValueError("uncertainty_maps: from_logits with more than 8 classes needs float32 logits")
+        probs = torch.empty_like(xd)
+        _lib.check(lib.vx_softmax_planar(_lib.ptr(xd), B * T, Cc, nvox, _lib.ptr(probs), _lib.stream_ptr()), "vx_softmax_planar")
+        xd, from_logits = probs, False
     if out is None:
         out = alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean, want_argmax, want_sample_argmax)
     else:

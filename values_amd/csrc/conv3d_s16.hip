@@ -72,6 +72,15 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
   }
 }
 
+// x + (x of lane ^ 16): two copies, v_permlane16_swap_b32 exchanges row 1 of the first with row 0 of the second (and
+// row 3 with row 2), so a = [r0, r0, r2, r2], b = [r1, r1, r3, r3] -- no LDS-queue ds_bpermute as __shfl_xor(x, 16) takes
+// (tools/micro/permlane_swap.hip); the same bits as x + __shfl_xor(x, 16)
+__device__ __forceinline__ float vx_add_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 // lane i of every 16-lane row <- lane (i + rot) % 16 of the same row
 __device__ __forceinline__ float vx_row_ror(float x, int rot) {
   const int v = __builtin_bit_cast(int, x);
@@ -388,9 +397,22 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     const size_t hnvox = (size_t)a.D * a.H * a.W;
     int hflip = 0;
     float* hbase = nullptr;
+    // row-reuse layout (a wave's R column tiles = R consecutive y-rows of one z): the head's output address of
+    // column tile r is that of tile 0 plus r rows (minus, under a y-flip) -- computed once per item
+    constexpr bool HROWS = XP == 1 && TX == 16 && TY % R == 0;
+    float* ho0 = nullptr;
+    int hystep = 0;
     if (f_head) {
       hflip = a.head_flip ? a.head_flip[n] : 0;
       hbase = a.head_out + (size_t)(a.head_dst ? a.head_dst[n] : n) * a.head_C * hnvox;
+      if constexpr (HROWS) {
+        int gx = tx * TXV + 2 * m + (g >> 1), gy = ty * TY + (wave * R) % TY, gz = tz * TZ + (wave * R) / TY;
+        if (hflip & 1) gz = a.D - 1 - gz;
+        if (hflip & 2) gy = a.H - 1 - gy;
+        if (hflip & 4) gx = a.W - 1 - gx;
+        ho0 = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
+        hystep = (hflip & 2) ? -a.W : a.W;
+      }
     }
 
     float ssum[NT][4], ssq[NT][4];
@@ -434,19 +456,24 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
           // (a wave's stores of one class cover 32 consecutive voxels).  The lane's 4 weights per class and the
           // bias were selected once per workgroup (hw4 / hb).  Two partial chains + one add: not bit-equal to
           // conv1x1.hip's single chain.
-          const int vv = (wave * R + r) * 16 + m;
-          int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
-          if (hflip & 1) gz = a.D - 1 - gz;
-          if (hflip & 2) gy = a.H - 1 - gy;
-          if (hflip & 4) gx = a.W - 1 - gx;
-          float* o = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
+          float* o;
+          if constexpr (HROWS) {
+            o = ho0 + (ptrdiff_t)r * hystep;
+          } else {
+            const int vv = (wave * R + r) * 16 + m;
+            int gx = tx * TXV + 2 * (vv % TX) + (g >> 1), gy = ty * TY + (vv / TX) % TY, gz = tz * TZ + vv / (TX * TY);
+            if (hflip & 1) gz = a.D - 1 - gz;
+            if (hflip & 2) gy = a.H - 1 - gy;
+            if (hflip & 4) gx = a.W - 1 - gx;
+            o = hbase + ((size_t)gz * a.H + gy) * a.W + gx;
+          }
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
             if (c < a.head_C) {
               float part = hb[c];
 #pragma unroll
               for (int k = 0; k < 4; ++k) part = fmaf(hw4[c][k], v[k], part);
-              part += __shfl_xor(part, 16, 64);
+              part = vx_add_xor16(part);
               if (!bad && !(g & 1)) o[(size_t)c * hnvox] = part;
             }
           }

@@ -47,6 +47,19 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {   
 }
 }
 
+// lane i of every 16-lane row <- lane (i + rot) % 16 of the same row (DPP; conv3d_s16.hip: vx_row_ror)
+__device__ __forceinline__ float row_ror(float x, int rot) {
+  const int v = __builtin_bit_cast(int, x);
+  int r;
+  switch (rot) {
+    case 8: r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(float, r);
+}
+
 template <int KS, int S, int NT, int NSUB, int TY>
 __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   constexpr int NW = 8, NTH = 512, TX = 16;
@@ -211,8 +224,32 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+  // statistics of the tile finished last: its per-wave sums sit in s_red and are combined after the NEXT barrier
+  // of the item loop (no barrier of their own in the epilogue; conv3d_s16.hip)
+  float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW][NT][16][2] (floats: image = IMG_H, weights = W_FLOATS)
+  int pend_tile = -1;
+  auto flush_stats = [&]() {
+    if (pend_tile >= 0 && tid < NT * 16) {
+      const int nt = tid / 16, c = tid % 16;
+      const int co = (cg * NT + nt) * 16 + c;
+      if (co < a.Cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
+          q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
+        }
+        float* dst = a.stats_partial + ((size_t)pend_tile * a.Cout + co) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+    pend_tile = -1;
+  };
+
   while (have) {
     __syncthreads();
+    flush_stats();
     commit(w_fresh);
     __syncthreads();
     w_fresh = !w_resident;
@@ -291,35 +328,19 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         }
       }
       if (a.stats_partial) {
-        float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW][NT][16][2] (floats: image = IMG_H, weights = W_FLOATS)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float s = ssum[nt][j], q = ssq[nt][j];
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+            for (int rot = 8; rot >= 1; rot >>= 1) { s += row_ror(s, rot); q += row_ror(q, rot); }
             if (m == 0) {
               s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 0] = s;
               s_red[((wave * NT + nt) * 16 + g * 4 + j) * 2 + 1] = q;
             }
           }
-        __syncthreads();
-        if (tid < NT * 16) {
-          const int nt = tid / 16, c = tid % 16;
-          const int co = (cg * NT + nt) * 16 + c;
-          if (co < a.Cout) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              s += s_red[((w * NT + nt) * 16 + c) * 2 + 0];
-              q += s_red[((w * NT + nt) * 16 + c) * 2 + 1];
-            }
-            float* dst = a.stats_partial + ((size_t)tile_lin * a.Cout + co) * 2;
-            dst[0] = s;
-            dst[1] = q;
-          }
-        }
+        pend_tile = tile_lin;
       }
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -328,6 +349,8 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     }
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
+  __syncthreads();
+  flush_stats();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -20,7 +20,9 @@
 //   LDS image:    hi plane and lo plane, each [channel octet][halo position][8 halves]; a lane's B fragment for a
 //                 step is one ds_read_b128 per plane at (position of its column + its k-group's tap offset).
 //   weights:      [chunk][step][row tile][hi | lo][lane][8 halves], one ds_read_b128 per (step, row tile, plane).
-// The loop is LDS-bandwidth-bound ((2 NT + 2 R) KiB per 3 R NT MFMAs), not issue- or power-bound.
+// The loop reads (2 NT + 2 R) KiB of LDS per 3 R NT MFMAs.  Around it (x-pair layers on the large tile): two LDS images,
+// one barrier per item, staggered SIMD partners (DB), compile-time epilogues (EPI) -- see the kernel's header below and
+// DESIGN.md section 5, round-1g, for the counters behind each step.
 #include "common.h"
 #include <stdlib.h>
 
@@ -43,9 +45,8 @@ struct ConvSArgs {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// x -> (hi, lo) with x = hi + lo * 2^-11 (see the header).  Two elements at a time so that the conversions and the
-// residual arithmetic use the packed instructions (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32): 12 VALU
-// instructions per 16-byte piece.  No clamping: |x| >= 65520 turns into inf and the output into NaN -- loud, and
+// x -> (hi, lo) with x = hi + lo * 2^-11 (see the header).  Two elements at a time: one v_cvt_pk_f16_f32, one
+// v_pk_mul_f32 and a mixed-precision fma per element -- 8 VALU instructions per 16-byte piece.  No clamping: |x| >= 65520 turns into inf and the output into NaN -- loud, and
 // out of reach for activations that went through InstanceNorm / a dropout-scaled LeakyReLU.
 __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 #pragma unroll

@@ -116,6 +116,8 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
     main = torch.cuda.current_stream(dev)
     side = [main]
     if len(chunks) > 1:
+        for model in models:          # pack the weights on the caller's stream: every chunk stream waits for it below
+            model._ensure_packed(dev)
         pool = _side_streams.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
         while len(pool) < n_side:
             pool.append(torch.cuda.Stream(device=dev))

@@ -439,3 +439,25 @@ def test_ssn_matches_reference_fixture_and_generated_noise_is_standard_normal():
     assert abs(z0.mean().item()) < 0.01 and abs(z0.var().item() - 1.0) < 0.01
     assert abs((z0 ** 4).mean().item() - 3.0) < 0.1       # kurtosis of a normal
     assert not torch.equal(dist.sample_volumes(2, seed=5)[0, 0], dist.sample_volumes(2, seed=6)[0, 0])
+
+
+def test_host_pipeline_returns_every_step_in_order():
+    """values_amd.HostPipeline (pinned host in, pinned host out, copies on their own streams, a step's download enqueued
+    after the next step's upload): same maps as predict_uncertainty + .cpu(), every step exactly once, in order."""
+    from values_amd import HostPipeline, predict_uncertainty
+    model = make_model(do_dropout=True)
+    xs = [torch.from_numpy(np.concatenate([formula_volume((1, 1, 16, 16, 16), tag=60 + 3 * s + i) for i in range(3)], 0)).float()
+          for s in range(5)]
+    hp = HostPipeline([model], n_pred=4)
+    got = []
+    for s, xh in enumerate(xs):
+        r = hp.submit(xh, seeds=[s])
+        if r is not None:
+            got.append({k: v.copy() for k, v in r.items()})     # views of pinned buffers: valid until the next submit
+    got += [{k: v.copy() for k, v in r.items()} for r in hp.flush()]
+    assert len(got) == len(xs)
+    for s, xh in enumerate(xs):
+        ref = predict_uncertainty([model], xh.cuda(), n_pred=4, seeds=[s])
+        for k in HostPipeline.KEYS:
+            assert np.array_equal(got[s][k], ref[k].cpu().numpy()), (s, k)
+    assert hp.flush() == []

@@ -64,55 +64,40 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
 
 
 class MapGatherPipeline:
-    """gather_maps with the collective OFF the compute path: `submit(out)` packs the step's maps into one of
-    `depth` send buffers and starts an asynchronous gather (RCCL runs it on its own stream, so the next step's
-    kernels overlap the transfer -- at ~1 900 volumes/s a step of 16 volumes is 8 ms of compute and 88 MB of maps
-    per rank, i.e. 0.6 GB into rank 0 per step at 8 GPUs); `collect()` waits for the OLDEST gather in flight and
-    returns its maps on dst (None elsewhere).  submit() collects first when `depth` gathers are already in flight,
-    so a send buffer is never overwritten while it is being read.  There are depth + 1 buffer slots: the maps a
-    submit() hands back are views of the receive buffer of the gather it just collected, and the gather it starts must
-    not land in that same buffer -- they stay valid until the NEXT submit().  world == 1: submit/collect are a FIFO."""
+    """gather_maps with the collective OFF the compute path: `submit(out)` packs the step's maps into a send buffer;
+    the asynchronous gather of a step (RCCL runs it on its own stream, so later steps' kernels overlap the transfer --
+    at ~2 300 volumes/s a step of 32 volumes is 14 ms of compute and 176 MB of maps per rank, i.e. 1.2 GB into rank 0
+    per step at 8 GPUs) is started one submit LATER, once the host has seen the step's completion event: a collective
+    enqueued right behind its step would sit blocked in a hardware queue that kernels of the next step may share (see
+    values_amd.predict.HostPipeline, which measured exactly that with copies).  `collect()` waits for the OLDEST gather
+    in flight and returns its maps on dst (None elsewhere); submit() collects first when `depth` gathers are in flight.
+    Buffer slots: depth gathers in flight + the step packed but not yet started + the result the caller still holds as
+    zero-copy views of a receive buffer (valid until the NEXT submit()).  world == 1: submit/collect are a FIFO."""
 
     def __init__(self, world: int, rank: int, dst: int = 0, depth: int = 2):
         self.world, self.rank, self.dst, self.depth = world, rank, dst, max(1, depth)
-        self._slots = self.depth + 1
+        self._slots = self.depth + 2
         self._send = [None] * self._slots
         self._recv = [None] * self._slots
         self._inflight = []      # [(slot, works)] oldest first
+        self._pending = None     # (slot, completion event or None) of the step packed last
         self._next = 0
         self._use_all_gather = False
 
-    def _resubmit(self, out, slot, done):
-        self._next = slot
-        r = self.submit(out)
-        return done if done is not None else r
-
-    def submit(self, out: Dict[str, torch.Tensor]):
-        done = None
-        if len(self._inflight) >= self.depth:
-            done = self.collect()
-        slot = self._next
-        self._next = (self._next + 1) % self._slots
-        if self.world == 1:
-            self._inflight.append((slot, out))
-            return done
+    def _start(self):
+        """start the gather of the pending step"""
         import torch.distributed as dist
-        parts = [out[k].unsqueeze(1) for k in MAP_KEYS] + [out["mean_softmax"]]
-        seg = out["pred_seg_mean"]
-        fshape = (seg.shape[0], sum(p.shape[1] for p in parts)) + tuple(seg.shape[1:])
-        if self._send[slot] is None or tuple(self._send[slot][0].shape) != fshape:
-            self._send[slot] = (torch.empty(fshape, dtype=torch.float32, device=seg.device), torch.empty_like(seg))
-            if self.rank == self.dst:   # one contiguous receive buffer per dtype: the gathered result is a VIEW of it
-                self._recv[slot] = (torch.empty((self.world,) + fshape, dtype=torch.float32, device=seg.device),
-                                    torch.empty((self.world,) + tuple(seg.shape), dtype=seg.dtype, device=seg.device))
+        slot, ev = self._pending
+        self._pending = None
+        if ev is not None:
+            ev.synchronize()     # host-side: nothing the collective waits for is still running
         sf, ss = self._send[slot]
-        torch.cat(parts, dim=1, out=sf)      # pack straight into the send buffer (the step's tensors may be reused)
-        ss.copy_(seg)
-        if self._use_all_gather and self._recv[slot] is None:
-            self._recv[slot] = (torch.empty((self.world,) + fshape, dtype=torch.float32, device=seg.device),
-                                torch.empty((self.world,) + tuple(seg.shape), dtype=seg.dtype, device=seg.device))
+        if self._recv[slot] is None and (self.rank == self.dst or self._use_all_gather):
+            self._recv[slot] = (torch.empty((self.world,) + tuple(sf.shape), dtype=sf.dtype, device=sf.device),
+                                torch.empty((self.world,) + tuple(ss.shape), dtype=ss.dtype, device=ss.device))
         have_recv = self._recv[slot] is not None
         rl = (list(self._recv[slot][0].unbind(0)), list(self._recv[slot][1].unbind(0))) if have_recv else (None, None)
+        works = None
         if not self._use_all_gather:
             try:
                 works = [dist.gather(sf, rl[0] if self.rank == self.dst else None, dst=self.dst, async_op=True),
@@ -121,10 +106,39 @@ class MapGatherPipeline:
                 # a backend without gather: all_gather is universally available (every rank then holds the maps);
                 # the switch is collective-safe because every rank hits the same error on the same call
                 self._use_all_gather = True
-                return self._resubmit(out, slot, done)
-        if self._use_all_gather:
+                self._pending = (slot, None)
+                return self._start()
+        else:
             works = [dist.all_gather(rl[0], sf, async_op=True), dist.all_gather(rl[1], ss, async_op=True)]
         self._inflight.append((slot, works))
+
+    def submit(self, out: Dict[str, torch.Tensor]):
+        done = None
+        if self.world == 1:
+            if len(self._inflight) >= self.depth:
+                done = self.collect()
+            self._inflight.append((0, out))
+            return done
+        if self._pending is not None:
+            if len(self._inflight) >= self.depth:
+                done = self.collect()
+            self._start()
+        slot = self._next
+        self._next = (self._next + 1) % self._slots
+        parts = [out[k].unsqueeze(1) for k in MAP_KEYS] + [out["mean_softmax"]]
+        seg = out["pred_seg_mean"]
+        fshape = (seg.shape[0], sum(p.shape[1] for p in parts)) + tuple(seg.shape[1:])
+        if self._send[slot] is None or tuple(self._send[slot][0].shape) != fshape:
+            self._send[slot] = (torch.empty(fshape, dtype=torch.float32, device=seg.device), torch.empty_like(seg))
+            self._recv[slot] = None
+        sf, ss = self._send[slot]
+        torch.cat(parts, dim=1, out=sf)      # pack straight into the send buffer (the step's tensors may be reused)
+        ss.copy_(seg)
+        ev = None
+        if seg.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(seg.device))
+        self._pending = (slot, ev)
         return done
 
     def collect(self) -> Optional[Dict[str, torch.Tensor]]:
@@ -144,6 +158,10 @@ class MapGatherPipeline:
 
     def flush(self) -> List[Optional[Dict[str, torch.Tensor]]]:
         res = []
+        if self.world > 1 and self._pending is not None:
+            if len(self._inflight) >= self.depth:
+                res.append(self.collect())
+            self._start()
         while self._inflight:
             res.append(self.collect())
         return res

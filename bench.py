@@ -139,26 +139,34 @@ def profiled_forward(model, x, n_samples, seed):
 
 
 def roofline_leg(model, x, T, reps=3):
+    """Per-launch HIP-event times of the forwards one step launches: the SAME volume chunks the timed path runs
+    (values_amd.predict splits a batch into chunks on two streams), one after the other on this stream -- so the
+    average launch duration is the one a rocprofv3 trace of this command shows for the kernel."""
+    from values_amd.predict import _volume_chunks
     tab = layer_table()
     V = x.shape[0]
     N = V * T
+    chunks, _ = _volume_chunks(V, None, False, T)
     acc = {}
     per_label = {}
     for rep in range(reps + 1):
-        rows = profiled_forward(model, x, T, 1000 + rep)
-        if rep == 0:
-            continue  # warm-up
-        for label, ms in rows:
-            per_label.setdefault(label, []).append(ms)
-            if label in tab:
-                kind, ci, co, edge = tab[label]
-                name = kernel_name(kind, ci, co, edge, label)
-                # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
-                fl, by = launch_cost(kind, ci, co, edge, V if label == "contr_1_1" else N)
-            else:
-                name, fl, by = label.split(":")[0], 0.0, 0.0
-            a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+        for ci_, (v0, v1) in enumerate(chunks):
+            rows = profiled_forward(model, x[v0:v1].contiguous(), T, 1000 + 16 * rep + ci_)
+            if rep == 0:
+                continue  # warm-up
+            Vc = v1 - v0
+            for label, ms in rows:
+                per_label.setdefault(label, []).append(ms)
+                if label in tab:
+                    kind, ci, co, edge = tab[label]
+                    name = kernel_name(kind, ci, co, edge, label)
+                    # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
+                    fl, by = launch_cost(kind, ci, co, edge, Vc if label == "contr_1_1" else Vc * T)
+                else:
+                    name, fl, by = label.split(":")[0], 0.0, 0.0
+                a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+    per_label = {k: [sum(v) / reps] for k, v in per_label.items()}     # per step: the chunks' launches summed
     total_ms = sum(a["ms"] for a in acc.values()) / reps
     dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
     name, a = dom
@@ -172,6 +180,7 @@ def roofline_leg(model, x, T, reps=3):
                           "products per fp32 product; the native-fp32 matrix peak is 157.3 TF") if split else
                          "fp32 matrix peak, dense",
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_step": a["launches"] // reps,
+            "samples_per_launch": round(N / len(chunks), 1),
             "share_of_forward": round(a["ms"] / reps / total_ms, 3), "traffic": None}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):

@@ -62,13 +62,15 @@ _side_streams: Dict[int, list] = {}
 
 
 def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, samples_per_volume: int = 1):
-    """[(v0, v1)] volume ranges, one per HIP stream.  Two half batches on two streams hide most of one half's HBM-bound
+    """[(v0, v1)] volume ranges dealt over n_streams HIP streams.  OPT-IN (n_streams=2 or VX_STREAMS=2; the default is
+    one stream: per-kernel timings stay clean and every sample of a batch draws from one hash-dropout stream).
+    Two half batches on two streams hide most of one half's HBM-bound
     launches (normalise / pool, transposed convs) under the other's convolutions: +2 % on the 64^3 MC-dropout
     batch of bench.py (un-joined streams: +3..5 %, tools/exp_streams.py); more streams do not add to it.  One stream when masks / noise are injected per
     sample (parity tests) or the batch is too small to split."""
     import os
     if n_streams is None:
-        n_streams = int(os.environ.get("VX_STREAMS", "2"))
+        n_streams = int(os.environ.get("VX_STREAMS", "1"))
     n = 1 if (pinned_inputs or V < 4) else max(1, min(int(n_streams), V // 2))
     while n > 1 and (V // n) * samples_per_volume < 64:   # small sample batches lose more in the kernels than overlap wins
         n -= 1
@@ -88,7 +90,7 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
                    **kw_ssn) -> torch.Tensor:
     """x: (V,1,D,H,W).  Returns logits (V, n_total, C, D,H,W) f32 on the device, n_total = passes per volume in
     pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests).  n_streams: volume chunks
-    run concurrently on that many HIP streams (default: VX_STREAMS or 2), each with its own workspace; every chunk
+    run concurrently on that many HIP streams (default: VX_STREAMS or 1), each with its own workspace; every chunk
     writes straight into its pred_idx slots of the one logits tensor.  _after_chunk(logits, v0, v1): called on the
     chunk's stream once its forwards are enqueued (predict_uncertainty reduces the chunk there)."""
     _lib.require_gpu()

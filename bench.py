@@ -283,7 +283,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((V, 1, S, S, S), generator=g).to(dev)  # z-scored synthetic volumes, resident in HBM
 
-    # maps are collected on rank 0 with the gather of step i overlapping the kernels of step i + 1 (two buffers);
+    # maps are collected on rank 0 with the gather of step i overlapping the kernels of the following steps;
     # everything is flushed before the closing barrier, so the timed region contains every transfer
     pipe = MapGatherPipeline(world, rank, depth=2)
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised inputs through values_amd.metrics / values_amd.aggregation against the CPU oracle restatements
-(oracle/metrics_oracle.py, oracle/aggregation_oracle.py -- checkers, as in the tests).   python tools/fuzz_metrics.py [cases] [seed]"""
+(oracle/metrics_oracle.py, oracle/aggregation_oracle.py -- which is why this checker lives under tests/).   python tests/fuzz/fuzz_metrics.py [cases] [seed]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised volume shapes, widths, class counts and injected dropout masks: the HIP forward + fused reduction against
-the float64 CPU oracle (oracle/unet3d_oracle.py -- test infrastructure; this is a checker, like the tests).
-    python tools/fuzz_vs_oracle.py [cases] [seed]"""
+the float64 CPU oracle (oracle/unet3d_oracle.py -- test infrastructure, which is why this checker lives under tests/).
+    python tests/fuzz/fuzz_vs_oracle.py [cases] [seed]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -267,8 +267,11 @@ def gen_patch_index():
 
     # accumulate: 32^3 image, patch 16, overlap 0.5, through the reference concat_data
     size, patch = 24, 16
-    from oracle.predict_oracle import crop_indices  # only for the LIST; pinned above against the reference
-    crops = crop_indices((size, size, size), patch, 0.5)
+    # the crop LIST of get_val_test_data_samples for this cube (z outermost, x innermost, step int(patch * overlap));
+    # patch_index.json above pins the same order against the reference's own function
+    step = int(patch * 0.5)
+    starts = list(range(0, size - patch + 1, step))
+    crops = [((x, x + patch), (y, y + patch), (z, z + patch)) for z in starts for y in starts for x in starts]
     dc = DataCarrier3D()
     T = 3
     fake = formula_tensor((len(crops), T, 2, patch, patch, patch), tag=55, scale=1.0)

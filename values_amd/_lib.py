@@ -157,7 +157,7 @@ def pack_mode():
     """The environment knobs that select the kernel family and with it the PACKED WEIGHT LAYOUT (conv_config() in
     conv3d_mfma.hip, s16_config() in conv3d_s16.hip, c2_split16() in conv2d_mfma.hip).  Models key their packed-weight
     cache on it: weights packed for one family fed to another would be silently wrong."""
-    return tuple(os.environ.get(k, "") for k in ("VX_CONV_FP32", "VX_CONV_NO_C8", "VX_S16_NO_XP"))
+    return tuple(os.environ.get(k, "") for k in ("VX_CONV_FP32", "VX_CONV_NO_C8", "VX_S16_NO_XP", "VX_C2S_NO_NT5"))
 
 
 def check(rc: int, what: str = ""):

@@ -358,6 +358,9 @@ struct C2SCfg { int NT, NSUB, TY; };
 static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   C2SCfg c;
   c.NT = (Cout % 48 == 0) ? 3 : ((Cout % 32 == 0) ? 2 : 1);
+  // wide 1x1 layers (the 720 -> 720 head conv): five row tiles per workgroup -- the input tile is re-staged once per
+  // group of output channels, 9 times instead of 15
+  if (KS == 1 && Cout % 80 == 0 && Cout >= 240 && !getenv("VX_C2S_NO_NT5")) c.NT = 5;
   c.NSUB = KS == 1 ? 4 : 1;
   c.TY = S == 2 ? 8 : 16;
   return c;
@@ -440,6 +443,9 @@ static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
 
 template <int KS, int S, int NSUB, int TY>
 static int dispatch_c2s(const Conv2dSArgs& ka, int NT, hipStream_t s) {
+  if constexpr (KS == 1) {
+    if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
+  }
   if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY>(ka, s);
   if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY>(ka, s);
   return launch_c2s<KS, S, 1, NSUB, TY>(ka, s);

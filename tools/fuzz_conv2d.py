@@ -15,7 +15,7 @@ bad = 0
 for case in range(cases):
     ks, s = rng.choice([(3, 1), (3, 1), (3, 2), (1, 1)])
     cin = rng.choice([3, 16, 18, 32, 36, 48, 64, 72, 96, 144, 192, 270]) if ks == 3 else rng.choice([16, 18, 48, 64, 96, 256, 270, 720])
-    cout = rng.choice([16, 18, 32, 36, 48, 64, 72, 96, 144, 19, 4, 24, 128])
+    cout = rng.choice([16, 18, 32, 36, 48, 64, 72, 96, 144, 19, 4, 24, 128] + ([240, 320, 720] if ks == 1 else []))
     n = rng.randint(1, 3)
     h, w = rng.randint(1, 40), rng.randint(1, 70)
     g = torch.Generator().manual_seed(case)

@@ -52,6 +52,30 @@ int vx_version(void);
 const char* vx_last_error_string(void);
 
 /* ---------------------------------------------------------------------------------
+ * Library configuration: which kernel family runs a layer (and with it the PACKED WEIGHT LAYOUT) plus tuning knobs.
+ * Read ONCE from the environment on first use (variable VX_<FIELD NAME IN CAPITALS>, e.g. VX_CONV_FP32=1), never per
+ * launch; vx_set_config replaces it (not while launches of another thread are being issued).  Weights are bound to
+ * the family they were packed for: see `w_family` in the args structs -- a launch whose weights were packed under a
+ * different configuration fails with VX_E_DTYPE instead of computing with the wrong layout. */
+typedef struct vx_config {
+  int32_t conv_fp32;      /* 0: split-fp16 products on the f16 matrix cores (default); 1: native fp32 matrix kernels;
+                             2: native fp32 only for Cout == 8 layers */
+  int32_t conv_no_c8;     /* fp32 mode: x-pair kernel instead of the 4x4x1 kernel for Cout == 8 */
+  int32_t conv_dma;       /* fp32 mode: LDS-DMA double-buffered schedule (conv3d_dma.hip) */
+  int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
+  int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
+  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm;
+  int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
+  int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
+  int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
+} vx_config;
+int vx_get_config(vx_config* out);
+int vx_set_config(const vx_config* cfg);
+/* kernel family (= packed layout) a layer's weights must be packed for under the current configuration; > 0 */
+int vx_conv3d_k3_family(int Cin, int Cout);
+int vx_conv2d_family(int Cin, int Cout, int KS);
+
+/* ---------------------------------------------------------------------------------
  * K10/K11/K12: fused softmax -> {mean prob, predictive entropy, expected entropy,
  * mutual information, argmax} reduction over T predictions, one pass over the input.
  * Replaces calculate_uncertainty (uncertainty_modeling/test_3D.py:486-518), the mean /
@@ -67,6 +91,21 @@ const char* vx_last_error_string(void);
 int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
                   float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
                   uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream);
+
+/* The same pass with its optional extras (all nullable):
+ *   variance [B][nvox]: mean over classes of the population variance over the T samples of each class probability
+ *            (BASELINE.json north_star's "softmax-variance"; the reference computes none, SURVEY D3: definition is this build's)
+ *   in_count [B][nvox]: probabilities are divided by max(count, 1) on load  (sliding-window sums, normalised mode)
+ *   out_count[B][nvox]: entropies / MI / mean_prob divided by max(count, 1) on store -- DataCarrier3D.save_data's division
+ *            of maps computed on UN-normalised sums (data_carrier_3D.py:323-337); variance by its square */
+typedef struct vx_unc_outputs {
+  float* mean_prob; float* pred_entropy; float* exp_entropy; float* mutual_info;
+  float* variance;
+  uint8_t* argmax; uint8_t* sample_argmax;
+  const float* in_count; const float* out_count;
+} vx_unc_outputs;
+int vx_unc_reduce_ex(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
+                     const vx_unc_outputs* outputs, vx_stream_t stream);
 
 /* The same reduction split for member-/sample-sharded ensembles (BASELINE config C3): every rank
  * ADDS the sufficient statistics of its own passes into stats [B][C+1][nvox] (planes 0..C-1: sum_t p_tc, plane C:
@@ -116,6 +155,7 @@ typedef struct vx_conv3d_args {
   const uint8_t* drop_mask; /* [N][D][H][W][Cout] when VX_DROP_MASK */
   float* stats_partial; /* nullable: [N][ntiles][Cout][2] (sum, sumsq of out before act) */
   int32_t in_xblk;      /* 0 = plain input; 1, 2 or 4 = x-block size of a concat input */
+  int32_t w_family;     /* vx_conv3d_k3_family(Cin, Cout) at the time w_packed was packed */
   /* Optional fused head (only where vx_conv3d_k3_head_fusable(Cin, Cout)): the 1x1x1 conv of
    * vx_conv1x1_ncdhw applied to this layer's output (after act / dropout) in the epilogue, same
    * arguments and the same bits; `out` may then be NULL and the feature map is never stored. */
@@ -201,6 +241,7 @@ typedef struct vx_unet3d_weights {
   const float* final_b;
   int32_t F;            /* initial_filter_size */
   int32_t num_classes;
+  int32_t conv_family[18]; /* vx_conv3d_k3_family of each packed conv at pack time (entry 0, the Cin == 1 layer: 0) */
 } vx_unet3d_weights;
 
 typedef struct vx_unet3d_run {
@@ -236,6 +277,7 @@ typedef struct vx_conv2d_args {
   float* out; int32_t out_pitch, out_coff;
   int32_t N, H, W, Cin, Cout, KS, S;        /* KS in {1,3}; S in {1,2} (1x1: S = 1) */
   float* stats_partial;                     /* nullable */
+  int32_t w_family;                         /* vx_conv2d_family(Cin, Cout, KS) at the time w_packed was packed */
 } vx_conv2d_args;
 int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS);
 int vx_pack_conv2d(const float* w_torch /* (Cout,Cin,KS,KS) */, float* w_packed, int Cin, int Cout, int KS, vx_stream_t stream);
@@ -334,12 +376,13 @@ int vx_ssn2d_add_diag(float* out, const float* diag, const float* eps_d, uint32_
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and
  *                first (C-order) index with isclose(value, max); result[0]=max, idx[0..2]
  *   vx_sum_thr : image_level_aggregation (:34-37) + threshold_aggregation (:61-67):
- *                sums[0]=sum(map), sums[1]=sum(map[map>=thr]), sums[2]=count(map>=thr)
- * map is f32 [D][H][W] (2D maps: D = 1, pd = 1). workspace: 2 * D*H*W doubles.
+ *                sums[0]=sum(map), sums[1]=sum(map[map>=thr]), sums[2]=count(map>=thr); map VX_F32 or VX_F64 (a map
+ *                read back from NIfTI is float64), the comparison (double)map >= thr runs in float64 like the reference's
+ * vx_box_max: map is f32 [D][H][W] (2D maps: D = 1, pd = 1). workspace: 2 * D*H*W doubles.
  */
 int vx_box_max(const float* map, int D, int H, int W, int pd, int ph, int pw, double* result, int32_t* idx,
                void* workspace, size_t workspace_bytes, vx_stream_t stream);
-int vx_sum_thr(const float* map, int64_t n, float thr, double* sums, vx_stream_t stream);
+int vx_sum_thr(const void* map, int dtype, int64_t n, double thr, double* sums, vx_stream_t stream);
 
 #ifdef __cplusplus
 }

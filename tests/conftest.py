@@ -24,3 +24,38 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+class _VxCfg:
+    """Switch libvalues_amd.so's configuration (vx_config) for one test.  The library reads its VX_* variables once, at
+    first use, so tests address the fields directly; the names map VX_CONV_FP32 -> conv_fp32 and so on."""
+
+    def __init__(self):
+        from values_amd import _lib
+        self._lib = _lib
+        self._saved = _lib.get_config()
+
+    def set(self, **fields):
+        import ctypes
+        c = self._lib.get_config()
+        for k, v in fields.items():
+            assert hasattr(c, k), k
+            setattr(c, k, int(v))
+        self._lib.check(self._lib.load().vx_set_config(ctypes.byref(c)), "vx_set_config")
+
+    def setenv(self, name, value):
+        self.set(**{name[3:].lower(): int(value)})
+
+    def delenv(self, name, raising=False):
+        self.set(**{name[3:].lower(): 0})
+
+    def restore(self):
+        import ctypes
+        self._lib.check(self._lib.load().vx_set_config(ctypes.byref(self._saved)), "vx_set_config")
+
+
+@pytest.fixture
+def vxcfg():
+    c = _VxCfg()
+    yield c
+    c.restore()

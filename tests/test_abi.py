@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.vx_version() >= 100
+    assert lib.vx_version() >= 200
 
 
 def test_struct_sizes_match_c(lib):
@@ -44,8 +44,9 @@ def test_struct_sizes_match_c(lib):
     code = r'''
 #include <stdio.h>
 #include "values_amd.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx_norm_args), sizeof(vx_convT_args),
- sizeof(vx_unet3d_weights), sizeof(vx_unet3d_run), sizeof(vx_conv2d_args), sizeof(vx_affine_args)); return 0;}
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx_norm_args), sizeof(vx_convT_args),
+ sizeof(vx_unet3d_weights), sizeof(vx_unet3d_run), sizeof(vx_conv2d_args), sizeof(vx_affine_args), sizeof(vx_config),
+ sizeof(vx_unc_outputs)); return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "s.c")
@@ -54,11 +55,11 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), s
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])  # header is plain C
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(c) for c in (_lib.ConvArgs, _lib.NormArgs, _lib.ConvTArgs, _lib.UNet3DWeights, _lib.UNet3DRun,
-                                        _lib.Conv2dArgs, _lib.AffineArgs)]
+                                        _lib.Conv2dArgs, _lib.AffineArgs, _lib.Config, _lib.UncOutputs)]
     assert mine == sizes
 
 
-def test_host_only_queries(lib):
+def test_host_only_queries(lib, vxcfg):
     # default = split-fp16 schedule: [row groups][chunks of CB][K=32 steps][NT][hi|lo][64 lanes][8 halves], in floats
     def s16(cin, cout):
         nt = 2 if cout % 32 == 0 else 1
@@ -70,15 +71,17 @@ def test_host_only_queries(lib):
         return (rows // 16) * (cin // cb) * steps * 2 * pieces * 8 // 2
     for cin, cout in ((16, 8), (24, 8), (16, 16), (32, 32), (128, 64)):
         assert lib.vx_conv3d_k3_packed_floats(cin, cout) == s16(cin, cout)
-    os.environ["VX_CONV_FP32"] = "1"      # native-fp32 kernels: their own packings
-    try:
-        assert lib.vx_conv3d_k3_packed_floats(16, 8) == 27 * 16 * 8   # Cout == 8, Cin in {8, 16}: 4x4x1 kernel, dense
-        assert lib.vx_conv3d_k3_packed_floats(24, 8) == 16 * 24 * 36  # other Cout == 8: x-pair packing, 16 rows x (9*4 taps)
-        assert lib.vx_conv3d_k3_packed_floats(16, 16) == 16 * 16 * 27
-        assert lib.vx_conv3d_k3_packed_floats(32, 32) == 32 * 32 * 27
-        assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 16 * 16  # x-pair / 4x4x1 tiles are 32 voxels wide
-    finally:
-        del os.environ["VX_CONV_FP32"]
+    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (3, 8))] == [2, 1, 0]
+    assert [lib.vx_conv2d_family(64, co, ks) for co, ks in ((64, 3), (720, 1), (64, 5))] == [1, 2, 0]
+    vxcfg.set(conv_fp32=1)      # native-fp32 kernels: their own packings and families
+    assert lib.vx_conv3d_k3_packed_floats(16, 8) == 27 * 16 * 8   # Cout == 8, Cin in {8, 16}: 4x4x1 kernel, dense
+    assert lib.vx_conv3d_k3_packed_floats(24, 8) == 16 * 24 * 36  # other Cout == 8: x-pair packing, 16 rows x (9*4 taps)
+    assert lib.vx_conv3d_k3_packed_floats(16, 16) == 16 * 16 * 27
+    assert lib.vx_conv3d_k3_packed_floats(32, 32) == 32 * 32 * 27
+    assert lib.vx_conv3d_k3_tiles_for(64, 64, 64, 8) == 2 * 16 * 16  # x-pair / 4x4x1 tiles are 32 voxels wide
+    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (24, 8), (16, 16))] == [5, 4, 3]
+    assert lib.vx_conv2d_family(64, 64, 3) == 3
+    vxcfg.set(conv_fp32=0)
     assert lib.vx_conv3d_k3_packed_floats(3, 8) == -1
     assert lib.vx_convT_k2s2_packed_floats(16, 8) == 16 * 8 * 8
     assert lib.vx_conv3d_k3_tiles(64, 64, 64) == 4 * 16 * 16
@@ -86,14 +89,12 @@ def test_host_only_queries(lib):
     assert lib.vx_conv3d_k3_tiles_for(16, 16, 16, 16) == 1 * 4 * 4  # small layers: 16 x 4 x 4
     # vx_conv3d_k3_tiles sizes stats_partial for any layer: an upper bound of every tiling, in both modes (for
     # 8 <= W < 16 the x-pair tiling makes the most tiles, elsewhere the plain one: tools/fuzz_conv.py found the gap)
-    for mode in ("0", "1"):
-        os.environ["VX_CONV_FP32"] = mode
-        try:
-            for d, h, w in ((8, 52, 13), (3, 5, 9), (4, 40, 15), (64, 64, 64), (5, 37, 70), (1, 1, 1), (6, 33, 16), (7, 31, 33)):
-                for cout in (8, 16, 32, 64):
-                    assert lib.vx_conv3d_k3_tiles(d, h, w) >= lib.vx_conv3d_k3_tiles_for(d, h, w, cout), (mode, d, h, w, cout)
-        finally:
-            del os.environ["VX_CONV_FP32"]
+    for mode in (0, 1):
+        vxcfg.set(conv_fp32=mode)
+        for d, h, w in ((8, 52, 13), (3, 5, 9), (4, 40, 15), (64, 64, 64), (5, 37, 70), (1, 1, 1), (6, 33, 16), (7, 31, 33)):
+            for cout in (8, 16, 32, 64):
+                assert lib.vx_conv3d_k3_tiles(d, h, w) >= lib.vx_conv3d_k3_tiles_for(d, h, w, cout), (mode, d, h, w, cout)
+    vxcfg.set(conv_fp32=0)
     assert lib.vx_unet3d_workspace_bytes(1, 64, 64, 64, 8) > 40e6
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 

@@ -42,12 +42,12 @@ def from_xblk(buf, half, n, c, d, h, w, xb):
 
 
 @pytest.fixture(params=["split16", "fp32"])
-def conv_mode(request, monkeypatch):
+def conv_mode(request, vxcfg):
     """the default split-fp16 schedule (conv3d_s16.hip) and the native-fp32 kernels (VX_CONV_FP32=1)"""
     if request.param == "fp32":
-        monkeypatch.setenv("VX_CONV_FP32", "1")
+        vxcfg.setenv("VX_CONV_FP32", "1")
     else:
-        monkeypatch.delenv("VX_CONV_FP32", raising=False)
+        vxcfg.delenv("VX_CONV_FP32", raising=False)
     return request.param
 
 
@@ -73,6 +73,7 @@ def run_conv(x, w, b, act=0, drop_mode=0, mask=None, seed=0, layer=0, stats=Fals
     _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wd), _lib.ptr(wp), Cin, Cout, _lib.stream_ptr()), "pack")
     out = torch.full((N, D, H, W, out_pitch), -77.0, dtype=torch.float32, device=dev())
     a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(Cin, Cout)
     a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
     a.in_pitch, a.out_pitch, a.out_coff = in_pitch, out_pitch, out_coff
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, D, H, W, Cin, Cout
@@ -125,10 +126,10 @@ def test_conv3d_k3_matches_oracle(cin, cout, shape, conv_mode):
     (8, 8, (2, 8, 8, 64), 0), (16, 8, (1, 5, 7, 38), 0), (16, 16, (1, 8, 8, 16), 0), (32, 16, (1, 6, 9, 20), 0),
     (8, 16, (1, 16, 16, 16), 0), (16, 8, (2, 8, 8, 32), 4), (32, 16, (1, 4, 8, 16), 4),
 ])
-def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeypatch):
+def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, vxcfg):
     """the opt-in double-buffered LDS-DMA schedule (conv3d_dma.hip) gives the same result as the default kernel"""
-    monkeypatch.setenv("VX_CONV_FP32", "1")     # the LDS-DMA schedule is a variant of the native-fp32 kernels
-    monkeypatch.setenv("VX_CONV_DMA", "1")
+    vxcfg.setenv("VX_CONV_FP32", "1")     # the LDS-DMA schedule is a variant of the native-fp32 kernels
+    vxcfg.setenv("VX_CONV_DMA", "1")
     n, d, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 105))
     wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 106, scale=(1.0 / (27 * cin)) ** 0.5))
@@ -138,7 +139,7 @@ def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, monkeyp
     assert (got.double() - ref).abs().max().item() < 2e-5
     s = st.double().sum(1)
     np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
-    monkeypatch.delenv("VX_CONV_DMA")
+    vxcfg.delenv("VX_CONV_DMA")
     got2, _, _ = run_conv(x, wt, b, stats=True, xblk=xb)
     assert torch.equal(got, got2)   # same accumulation order in both schedules -> bit-identical
 
@@ -174,6 +175,7 @@ def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):
     slots = 2 * n
     feat = torch.empty((n, d, h, w, 8), dtype=torch.float32, device=dev())
     a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, 8)
     a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = feat.data_ptr()
     a.in_pitch, a.out_pitch, a.out_coff = cin, 8, 0
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, 8
@@ -208,7 +210,7 @@ def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):
     (16, 16, (2, 6, 35, 34), 0), (8, 16, (2, 8, 32, 32), 0),      # plain large-tile instances (EPI only)
 ])
 @pytest.mark.parametrize("mode", ["plain_stats", "lrelu_hash", "lrelu_hash_head"])
-def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mode, monkeypatch):
+def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mode, vxcfg):
     """The large-tile instances of conv3d_s16.hip with compile-time epilogues (EPI 0 / 1 / 2) and the double-buffered,
     staggered item loop (DB 2 / 3) must give the bits of the generic kernel (two barriers per item, run-time
     epilogue: VX_S16_NO_DB=1 VX_S16_NO_EPI=1) -- output, statistics partials and fused head, hash dropout included."""
@@ -234,6 +236,7 @@ def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mod
         st = torch.zeros((n, nt, cout, 2), dtype=torch.float32, device=dev())
         head = torch.full((n, ncls, d, h, w), -5.0, dtype=torch.float32, device=dev())
         a = _lib.ConvArgs()
+        a.w_family = lib.vx_conv3d_k3_family(cin, cout)
         a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
         a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
         a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
@@ -250,10 +253,10 @@ def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mod
         torch.cuda.synchronize()
         return out, st, head
 
-    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    vxcfg.delenv("VX_CONV_FP32", raising=False)
     got = run()
-    monkeypatch.setenv("VX_S16_NO_DB", "1")
-    monkeypatch.setenv("VX_S16_NO_EPI", "1")
+    vxcfg.setenv("VX_S16_NO_DB", "1")
+    vxcfg.setenv("VX_S16_NO_EPI", "1")
     ref = run()
     for g, r in zip(got, ref):
         assert torch.equal(g, r)

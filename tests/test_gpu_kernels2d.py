@@ -39,6 +39,7 @@ def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0):
     st = torch.zeros((n * nt, cout, 2), dtype=torch.float32, device=DEV)
     bd = b.float().to(DEV) if b is not None else None
     a = _lib.Conv2dArgs()
+    a.w_family = lib.vx_conv2d_family(cin, cout, ks)
     a.in_ = xd.data_ptr(); a.in_pitch = cin_pad; a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr() if bd is not None else None
     a.out = out.data_ptr(); a.out_pitch = out_pitch; a.out_coff = out_coff
     a.N, a.H, a.W, a.Cin, a.Cout, a.KS, a.S = n, h, wd, cin_pad, cout, ks, s
@@ -56,12 +57,12 @@ def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0):
     (240, 4, 1, 1, (1, 16, 24)), (64, 24, 1, 1, (1, 7, 9)), (16, 128, 3, 1, (1, 5, 7)),
 ])
 @pytest.mark.parametrize("mode", ["split16", "fp32"])
-def test_conv2d_matches_oracle(cin, cout, ks, s, shape, mode, monkeypatch):
+def test_conv2d_matches_oracle(cin, cout, ks, s, shape, mode, vxcfg):
     # default: split-fp16 schedule (conv2d_s16.hip); VX_CONV_FP32=1: native-fp32 kernels (conv2d_mfma.hip)
     if mode == "fp32":
-        monkeypatch.setenv("VX_CONV_FP32", "1")
+        vxcfg.setenv("VX_CONV_FP32", "1")
     else:
-        monkeypatch.delenv("VX_CONV_FP32", raising=False)
+        vxcfg.delenv("VX_CONV_FP32", raising=False)
     n, h, w = shape
     x = torch.from_numpy(formula_tensor((n, cin, h, w), 201))
     wt = torch.from_numpy(formula_tensor((cout, cin, ks, ks), 202, scale=(1.0 / (ks * ks * cin)) ** 0.5))

@@ -89,11 +89,11 @@ def test_golden_no_dropout_forward(size):
 
 
 @pytest.mark.parametrize("size", [16, 32])
-def test_native_fp32_mode_network_vs_golden(size, monkeypatch):
+def test_native_fp32_mode_network_vs_golden(size, vxcfg):
     """VX_CONV_FP32=1: the native-fp32 matrix kernels (16x16x4 / 4x4x1 with the final 1x1x1 conv fused into
     expand_1_2) give the same network within tolerance, with the reference's dropout masks and TTA flips"""
     from values_amd import predict_uncertainty
-    monkeypatch.setenv("VX_CONV_FP32", "1")
+    vxcfg.setenv("VX_CONV_FP32", "1")
     g = load_npz(f"unet3d_{size}.npz")
     T = g["logits"].shape[0]
     model = make_model(do_dropout=True)
@@ -274,16 +274,16 @@ def test_volume_chunks_on_two_streams_equal_one_stream():
     assert torch.equal(s0["pred_entropy"], s1["pred_entropy"])
 
 
-def test_mode_switch_repacks_the_weights(monkeypatch):
+def test_mode_switch_repacks_the_weights(vxcfg):
     """The packed weight layout belongs to the kernel family: switching VX_CONV_FP32 on a live model must re-pack
     (the cache is keyed on _lib.pack_mode()), not feed split-fp16 blocks to the native-fp32 kernels."""
     model = make_model(do_dropout=False)
     x = torch.from_numpy(formula_volume((2, 1, 16, 16, 16), tag=51)).float().cuda()
-    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    vxcfg.delenv("VX_CONV_FP32", raising=False)
     a = model(x)
-    monkeypatch.setenv("VX_CONV_FP32", "1")
+    vxcfg.setenv("VX_CONV_FP32", "1")
     b = model(x)
-    monkeypatch.delenv("VX_CONV_FP32", raising=False)
+    vxcfg.delenv("VX_CONV_FP32", raising=False)
     c = model(x)
     assert (a - b).abs().max().item() < LOGIT_TOL
     assert torch.equal(a, c)

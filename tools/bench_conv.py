@@ -45,6 +45,7 @@ def main():
         _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(w), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
         out = torch.empty((N, edge, edge, edge, cout), dtype=torch.float32, device=dev)
         a = _lib.ConvArgs()
+        a.w_family = lib.vx_conv3d_k3_family(cin, cout)
         a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
         a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
         a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout

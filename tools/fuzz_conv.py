@@ -31,17 +31,14 @@ for case in range(cases):
     nt = lib.vx_conv3d_k3_tiles(d, h, w)
 
     def run(env):
-        old = {k: os.environ.get(k) for k in ("VX_S16_NO_DB", "VX_S16_NO_EPI", "VX_CONV_FP32")}
-        for k in old:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        try:
+        with _lib.config(**{"s16_no_db": 0, "s16_no_epi": 0, "conv_fp32": 0, **env}):
             wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
             _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
             out = torch.full((n, d, h, w, cout), -3.0, device=dev)
             st = torch.zeros((n, nt, cout, 2), device=dev)
             head = torch.full((n, 2, d, h, w), -5.0, device=dev)
             a = _lib.ConvArgs()
+            a.w_family = lib.vx_conv3d_k3_family(cin, cout)
             a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
             a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
             a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
@@ -57,21 +54,16 @@ for case in range(cases):
             _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
             torch.cuda.synchronize()
             return out, st, head
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None)
-                if v is not None:
-                    os.environ[k] = v
 
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}", flush=True)
     got = run({})
     if os.environ.get("FUZZ_VERBOSE"):
         print("  default ok", flush=True)
-    gen = run({"VX_S16_NO_DB": "1", "VX_S16_NO_EPI": "1"})
+    gen = run({"s16_no_db": 1, "s16_no_epi": 1})
     if os.environ.get("FUZZ_VERBOSE"):
         print("  generic ok", flush=True)
-    f32 = run({"VX_CONV_FP32": "1"})
+    f32 = run({"conv_fp32": 1})
     ok = all(torch.equal(p, q) for p, q in zip(got, gen))
     tile_counts_differ = False
     err = max((got[0] - f32[0]).abs().max().item(), (got[2] - f32[2]).abs().max().item())

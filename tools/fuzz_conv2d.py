@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 torch.set_num_threads(16)
 from tests.test_gpu_kernels2d import run_conv2d
+from values_amd import _lib
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -26,16 +27,14 @@ for case in range(cases):
     tag = f"case {case}: {cin}->{cout} k{ks} s{s} n={n} {h}x{w} bias={b is not None}"
     if os.environ.get("FUZZ_VERBOSE"):
         print(tag, flush=True)
-    for mode in ("0", "1"):
-        os.environ["VX_CONV_FP32"] = mode
+    for mode in (0, 1):
         try:
-            got, st, _ = run_conv2d(x, wt, b, ks, s)
+            with _lib.config(conv_fp32=mode):
+                got, st, _ = run_conv2d(x, wt, b, ks, s)
         except Exception as e:
             print(f"ERROR {tag} mode={mode}: {e}")
             bad += 1
             continue
-        finally:
-            del os.environ["VX_CONV_FP32"]
         err = (got.double() - ref).abs().max().item()
         ssum = st.double().sum(0)
         e1 = (ssum[:, 0] - ref.sum((0, 2, 3))).abs().max().item()

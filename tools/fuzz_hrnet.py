@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from tests.test_gpu_hrnet import make
+from values_amd import _lib
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-os.environ.pop("VX_CONV_FP32", None)
 m16, _, _ = make(dropout_final=True)
 m32, _, _ = make(dropout_final=True)
 bad = 0
@@ -24,17 +24,15 @@ for case in range(cases):
     x = torch.randn((n, 3, h, w), generator=torch.Generator().manual_seed(case)).cuda()
     tag = f"case {case}: n={n} {h}x{w} T={T}"
     try:
-        os.environ.pop("VX_CONV_FP32", None)
-        a = m16.forward_samples(x, T, seeds=list(range(T)))
-        os.environ["VX_CONV_FP32"] = "1"
-        b = m32.forward_samples(x, T, seeds=list(range(T)))
+        with _lib.config(conv_fp32=0):
+            a = m16.forward_samples(x, T, seeds=list(range(T)))
+        with _lib.config(conv_fp32=1):
+            b = m32.forward_samples(x, T, seeds=list(range(T)))
         torch.cuda.synchronize()
     except Exception as e:
         print(f"ERROR {tag}: {type(e).__name__}: {e}")
         bad += 1
         continue
-    finally:
-        os.environ.pop("VX_CONV_FP32", None)
     err = (a - b).abs().max().item()
     scale = max(1.0, a.abs().max().item())
     if a.shape != b.shape or err > 5e-4 * scale or torch.isnan(a).any():

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from values_amd import UNet3D, predict_uncertainty
+from values_amd import _lib
 
 dev = torch.device("cuda", 0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -34,22 +35,13 @@ for case in range(cases):
     m32.load_state_dict(m.state_dict())                                               # one instance per mode
 
     def run(env, **kw):
-        old = {k: os.environ.get(k) for k in ("VX_CONV_FP32",)}
-        for k in old:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        try:
+        with _lib.config(**{"conv_fp32": 0, **env}):
             o = predict_uncertainty([m32 if env else m], x, n_pred=T, seeds=[7], **kw)
             torch.cuda.synchronize()
             return o
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None)
-                if v is not None:
-                    os.environ[k] = v
 
     a = run({}, n_streams=1)
-    b = run({"VX_CONV_FP32": "1"}, n_streams=1)
+    b = run({"conv_fp32": 1}, n_streams=1)
     c = run({}, n_streams=2)
     err = (a["logits"] - b["logits"]).abs().max().item()
     scale = max(1.0, a["logits"].abs().max().item())

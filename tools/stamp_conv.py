@@ -18,6 +18,7 @@ for spec in sys.argv[1:] or ["16:8:64", "16:16:32", "8:8:64", "64:32:16"]:
     dbg = torch.zeros((4096, 8, 8), dtype=torch.int64, device=dev)
     os.environ["VX_CONV_DBG_PTR"] = str(dbg.data_ptr())
     a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, cout)
     a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
     a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout

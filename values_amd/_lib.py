@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
                 ("in_pitch", _i32), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32),
-                ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32),
+                ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32), ("w_family", _i32),
                 ("head_out", _p), ("head_w", _p), ("head_b", _p), ("head_dst", _p), ("head_flip", _p),
                 ("head_C", _i32)]
 
@@ -53,7 +53,7 @@ class Conv2dArgs(C.Structure):
     _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32), ("KS", _i32), ("S", _i32),
-                ("stats_partial", _p)]
+                ("stats_partial", _p), ("w_family", _i32)]
 
 
 class AffineArgs(C.Structure):
@@ -63,9 +63,23 @@ class AffineArgs(C.Structure):
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
 
 
+class Config(C.Structure):
+    """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
+    _fields_ = [(n, _i32) for n in (
+        "conv_fp32", "conv_no_c8", "conv_dma", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
+        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm",
+        "c2s_no_nt5", "convt_no_mfma", "no_head_fusion", "s16_dbg", "c8_dbg", "dma_dbg", "dma_nw16", "c8_tile16",
+        "s16_range_check")]
+
+
+class UncOutputs(C.Structure):
+    _fields_ = [("mean_prob", _p), ("pred_entropy", _p), ("exp_entropy", _p), ("mutual_info", _p), ("variance", _p),
+                ("argmax", _p), ("sample_argmax", _p), ("in_count", _p), ("out_count", _p)]
+
+
 class UNet3DWeights(C.Structure):
     _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
-                ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32)]
+                ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32), ("conv_family", _i32 * 18)]
 
 
 class UNet3DRun(C.Structure):
@@ -78,7 +92,12 @@ class UNet3DRun(C.Structure):
 SIGNATURES = {
     "vx_version": (_i, []),
     "vx_last_error_string": (C.c_char_p, []),
+    "vx_get_config": (_i, [C.POINTER(Config)]),
+    "vx_set_config": (_i, [C.POINTER(Config)]),
+    "vx_conv3d_k3_family": (_i, [_i, _i]),
+    "vx_conv2d_family": (_i, [_i, _i, _i]),
     "vx_unc_reduce": (_i, [_p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "vx_unc_reduce_ex": (_i, [_p, _i, _i, _i, _i, _i, _i64, C.POINTER(UncOutputs), _p]),
     "vx_unc_stats_accumulate": (_i, [_p, _i, _i, _i, _i64, _p, _p]),
     "vx_unc_stats_finalize": (_i, [_p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p]),
     "vx_softmax_planar": (_i, [_p, _i64, _i, _i64, _p, _p]),
@@ -123,7 +142,7 @@ SIGNATURES = {
     "vx_affine_gather": (_i, [C.POINTER(AffineArgs), _p]),
     "vx_bilinear_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vx_box_max": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p]),
-    "vx_sum_thr": (_i, [_p, _i64, C.c_float, _p, _p]),
+    "vx_sum_thr": (_i, [_p, _i, _i64, C.c_double, _p, _p]),
 }
 
 _lib = None
@@ -153,11 +172,41 @@ def load():
     return lib
 
 
+def get_config() -> "Config":
+    c = Config()
+    check(load().vx_get_config(C.byref(c)), "vx_get_config")
+    return c
+
+
+class config:
+    """`with _lib.config(conv_fp32=1): ...` -- run a block under a changed vx_config (tests and A/B tools; the library
+    reads its VX_* environment variables only once, at first use).  Restores the previous configuration on exit."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.saved = get_config()
+        c = get_config()
+        for k, v in self.fields.items():
+            if not hasattr(c, k):
+                raise AttributeError(f"vx_config has no field {k!r}")
+            setattr(c, k, int(v))
+        check(load().vx_set_config(C.byref(c)), "vx_set_config")
+        return c
+
+    def __exit__(self, *exc):
+        check(load().vx_set_config(C.byref(self.saved)), "vx_set_config")
+        return False
+
+
 def pack_mode():
-    """The environment knobs that select the kernel family and with it the PACKED WEIGHT LAYOUT (conv_config() in
+    """The configuration fields that select the kernel family and with it the PACKED WEIGHT LAYOUT (conv_config() in
     conv3d_mfma.hip, s16_config() in conv3d_s16.hip, c2_split16() in conv2d_mfma.hip).  Models key their packed-weight
-    cache on it: weights packed for one family fed to another would be silently wrong."""
-    return tuple(os.environ.get(k, "") for k in ("VX_CONV_FP32", "VX_CONV_NO_C8", "VX_S16_NO_XP", "VX_C2S_NO_NT5"))
+    cache on it, and every launch carries the family its weights were packed for (w_family): the library refuses a
+    mismatch."""
+    c = get_config()
+    return (c.conv_fp32, c.conv_no_c8, c.s16_no_xp, c.c2s_no_nt5)
 
 
 def check(rc: int, what: str = ""):

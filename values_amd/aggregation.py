@@ -44,9 +44,17 @@ def patch_level_aggregation(image, patch_size, mean=False, **kwargs):
 
 
 def _sums(image, thr):
-    img, dev = _dev_map(image)
+    """(sum, sum of values >= thr, count of values >= thr) in float64; a float64 map (what medpy hands the reference
+    after a NIfTI round trip) stays float64, so `map >= threshold` is the reference's comparison bit for bit."""
+    _lib.require_gpu()
+    if isinstance(image, np.ndarray):
+        image = torch.from_numpy(np.ascontiguousarray(image))
+    dev = image.device if image.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    f64 = image.dtype == torch.float64
+    img = image.to(dev, torch.float64 if f64 else torch.float32).contiguous()
     sums = torch.empty(3, dtype=torch.float64, device=dev)
-    rc = _lib.load().vx_sum_thr(_lib.ptr(img), img.numel(), float(thr), _lib.ptr(sums), _lib.stream_ptr())
+    rc = _lib.load().vx_sum_thr(_lib.ptr(img), _lib.VX_F64 if f64 else _lib.VX_F32, img.numel(), float(thr),
+                                _lib.ptr(sums), _lib.stream_ptr())
     _lib.check(rc, "vx_sum_thr")
     return sums.tolist(), img.numel()
 

@@ -93,14 +93,18 @@ extern "C" int vx_box_max(const float* map, int D, int H, int W, int pd, int ph,
   return VX_OK;
 }
 
-__global__ __launch_bounds__(1024) void sum_thr_kernel(const float* __restrict__ v, int64_t n, float thr, double* sums) {
+// The comparison runs in float64 on both sides: the reference compares the stored map (float64 when it was read back
+// from NIfTI) with a float64 threshold (aggregate_uncertainties.py:61-66); a float32 threshold could move voxels within
+// one float32 ulp of it across the >= boundary.
+template <typename T>
+__global__ __launch_bounds__(1024) void sum_thr_kernel(const T* __restrict__ v, int64_t n, double thr, double* sums) {
   __shared__ double s_red[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s = 0.0, st = 0.0, ct = 0.0;
   for (int64_t i = tid; i < n; i += 1024) {
-    const float x = v[i];
-    s += (double)x;
-    if (x >= thr) { st += (double)x; ct += 1.0; }
+    const double x = (double)v[i];
+    s += x;
+    if (x >= thr) { st += x; ct += 1.0; }
   }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -117,10 +121,15 @@ __global__ __launch_bounds__(1024) void sum_thr_kernel(const float* __restrict__
   }
 }
 
-extern "C" int vx_sum_thr(const float* map, int64_t n, float thr, double* sums, vx_stream_t stream) {
+extern "C" int vx_sum_thr(const void* map, int dtype, int64_t n, double thr, double* sums, vx_stream_t stream) {
   if (!map || !sums) VX_FAIL(VX_E_NULL, "vx_sum_thr: null pointer");
   if (n < 0) VX_FAIL(VX_E_SHAPE, "vx_sum_thr: negative size");
-  hipLaunchKernelGGL(sum_thr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, map, n, thr, sums);
+  if (dtype == VX_F32)
+    hipLaunchKernelGGL(sum_thr_kernel<float>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)map, n, thr, sums);
+  else if (dtype == VX_F64)
+    hipLaunchKernelGGL(sum_thr_kernel<double>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double*)map, n, thr, sums);
+  else
+    VX_FAIL(VX_E_DTYPE, "vx_sum_thr: dtype %d", dtype);
   VX_CHECK_LAUNCH("vx_sum_thr");
   return VX_OK;
 }

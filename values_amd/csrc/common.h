@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 void vx_set_error(const char* fmt, ...);
+const vx_config& vx_cfg();   // lib.cpp: the environment is read once, never per launch
 
 #define VX_FAIL(code, ...)      \
   do {                          \

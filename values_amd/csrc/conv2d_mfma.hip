@@ -22,7 +22,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 int64_t vx_conv2d_s16_packed_floats(int Cin, int Cout, int KS);
 int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, hipStream_t s);
 int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s);
-static inline bool c2_split16() { const char* e = getenv("VX_CONV_FP32"); return !(e && atoi(e) != 0); }
+int vx_conv2d_s16_row_tiles(int KS, int Cout);
+static inline bool c2_split16() { return vx_cfg().conv_fp32 == 0; }
 
 struct Conv2dKArgs {
   vx_conv2d_args a;
@@ -318,6 +319,14 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restric
 
 static inline int c2_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
+// Kernel family = packed layout under the current configuration: 1 split-fp16, 2 split-fp16 with five row tiles
+// (wide 1x1 layers), 3 native fp32
+extern "C" int vx_conv2d_family(int Cin, int Cout, int KS) {
+  if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return 0;
+  if (!c2_split16()) return 3;
+  return vx_conv2d_s16_row_tiles(KS, Cout) == 5 ? 2 : 1;
+}
+
 extern "C" int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
   if (c2_split16()) return vx_conv2d_s16_packed_floats(Cin, Cout, KS);
@@ -391,6 +400,9 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: Cin=%d must be a positive multiple of 16 (pad the input), Cout=%d positive", a.Cin, a.Cout);
   if ((a.KS != 1 && a.KS != 3) || (a.S != 1 && a.S != 2) || (a.KS == 1 && a.S != 1))
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: kernel %d stride %d unsupported (3x3 s1/s2, 1x1 s1)", a.KS, a.S);
+  if (a.w_family != vx_conv2d_family(a.Cin, a.Cout, a.KS))
+    VX_FAIL(VX_E_DTYPE, "vx_conv2d: weights packed for kernel family %d, the library is configured for family %d: re-pack them",
+            a.w_family, vx_conv2d_family(a.Cin, a.Cout, a.KS));
   // outputs leave as 16-byte groups of 4 channels: a Cout that is not a multiple of 4 writes its last group up to
   // round4(Cout) (zeros beyond Cout), which the pitch must cover
   if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + (a.Cout + 3) / 4 * 4 || a.out_pitch % 4 || a.out_coff % 4)

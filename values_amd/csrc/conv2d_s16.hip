@@ -360,11 +360,12 @@ static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   c.NT = (Cout % 48 == 0) ? 3 : ((Cout % 32 == 0) ? 2 : 1);
   // wide 1x1 layers (the 720 -> 720 head conv): five row tiles per workgroup -- the input tile is re-staged once per
   // group of output channels, 9 times instead of 15
-  if (KS == 1 && Cout % 80 == 0 && Cout >= 240 && !getenv("VX_C2S_NO_NT5")) c.NT = 5;
+  if (KS == 1 && Cout % 80 == 0 && Cout >= 240 && !vx_cfg().c2s_no_nt5) c.NT = 5;
   c.NSUB = KS == 1 ? 4 : 1;
   c.TY = S == 2 ? 8 : 16;
   return c;
 }
+int vx_conv2d_s16_row_tiles(int KS, int Cout) { return c2s_config(KS, 1, Cout).NT; }
 static inline int c2s_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
 // torch (Cout, Cin, KS, KS) fp32 -> [row group][chunk][step][nt][hi | lo][lane][8 halves]

@@ -397,7 +397,7 @@ static int launch_c8(const ConvC8Args& ka, hipStream_t s) {
   constexpr int max_waves = NCH == 1 ? 16 : 24;   // 100 / 73 VGPRs per lane: 4 / 6 waves per SIMD
   if (per_cu * NW > max_waves) per_cu = max_waves / NW;
   if (per_cu < 1) per_cu = 1;
-  if (const char* e = getenv("VX_C8_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning knob
+  if (vx_cfg().c8_per_cu > 0) per_cu = vx_cfg().c8_per_cu;   // tuning knob
   int gx = 256 * per_cu;
   if (gx > total_tiles) gx = total_tiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTH), lds, s, ka);
@@ -409,8 +409,8 @@ static int launch_c8(const ConvC8Args& ka, hipStream_t s) {
 int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_t s) {
   ConvC8Args ka;
   ka.a = a;
-  ka.dbg = getenv("VX_C8_DBG") ? atoi(getenv("VX_C8_DBG")) : 0;
-  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
+  ka.dbg = vx_cfg().c8_dbg;
+  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -420,7 +420,7 @@ int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   const int nch = a.Cin / 8;
-  if (txv == 32 && getenv("VX_C8_TILE16")) {   // experiment: 4-wave workgroups, tile 16 x 4 x 4 (stats layout differs!)
+  if (txv == 32 && vx_cfg().c8_tile16) {   // experiment: 4-wave workgroups, tile 16 x 4 x 4 (stats layout differs!)
     txv = 16; ty = 4; tz = 4;
     ka.tiles_x = (a.W + txv - 1) / txv;
     ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;

@@ -362,12 +362,11 @@ int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s) {
   // Opt-in: measured at steady clocks (1000 launches) this schedule is 7-10 % SLOWER than the register-staged
   // kernel (104 vs 112 TFLOP/s on 16->16 @32^3, 78 vs 86 on 16->8 @64^3): its DMA reads are 16 B at voxel-pitch
   // stride (the LDS image is channel-group-major), where the register-staged loads are fully contiguous.
-  const char* on = getenv("VX_CONV_DMA");
-  if (!on || on[0] != '1') return 1;
+  if (vx_cfg().conv_dma != 1) return 1;
   const bool xp = a.Cout == 8;
   ConvDArgs ka;
   ka.a = a;
-  ka.dbg = getenv("VX_DMA_DBG") ? atoi(getenv("VX_DMA_DBG")) : 0;
+  ka.dbg = vx_cfg().dma_dbg;
   if (xp && a.W >= 32 && (a.Cin == 8 || a.Cin == 16)) {
     ka.tiles_x = (a.W + 31) / 32; ka.tiles_y = (a.H + 3) / 4; ka.tiles_z = (a.D + 3) / 4;
   } else if (!xp && a.Cout == 16 && a.W >= 16 && (a.Cin == 16 || a.Cin == 32 || a.Cin == 8)) {
@@ -381,13 +380,13 @@ int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s) {
   if (xp) {
     // weights were packed for CB = 16 when Cin == 16 (conv_config): this schedule needs the CB = 8 packing
     ka.nchunks = a.Cin / 8;
-    static const int nw16 = getenv("VX_DMA_NW16") ? 1 : 0;
+    const int nw16 = vx_cfg().dma_nw16 ? 1 : 0;
     if (nw16) return launch_dma<8, 16, 4, 4, 16, 1, 2>(ka, s);
     return launch_dma<8, 16, 4, 4, 8, 1, 2>(ka, s);
   }
   if (a.Cin == 8) { ka.nchunks = 1; return launch_dma<8, 16, 4, 4, 8, 0, 1>(ka, s); }
   ka.nchunks = a.Cin / 16;
-  static const int nw16b = getenv("VX_DMA_NW16") ? 1 : 0;
+  const int nw16b = vx_cfg().dma_nw16 ? 1 : 0;
   if (nw16b) return launch_dma<16, 16, 4, 4, 16, 0, 2>(ka, s);
   return launch_dma<16, 16, 4, 4, 8, 0, 2>(ka, s);
 }

@@ -463,10 +463,9 @@ static inline ConvCfg conv_config(int Cin, int Cout) {
   // Default: the split-fp16 schedule (conv3d_s16.hip) for every layer -- faster AND closer to float64 than the
   // native fp32 matrix instruction.  VX_CONV_FP32=1 selects the native-fp32 kernels of this
   // file / conv3d_c8.hip (an exact fmaf chain; the A/B baseline), VX_CONV_FP32=2 keeps fp32 only for Cout = 8.
-  // (read per call, not cached: packing and launch of a layer must simply see the same environment)
-  const char* ef = getenv("VX_CONV_FP32");
-  const int fp32 = ef ? atoi(ef) : 0;
-  const bool no_c8 = getenv("VX_CONV_NO_C8") != nullptr;   // fp32 mode: x-pair kernel instead of the 4x4x1 one
+  // (vx_config: read once; a launch checks its weights' w_family against what this returns NOW)
+  const int fp32 = vx_cfg().conv_fp32;
+  const bool no_c8 = vx_cfg().conv_no_c8 != 0;   // fp32 mode: x-pair kernel instead of the 4x4x1 one
   c.S16 = (fp32 == 0 || (fp32 == 2 && Cout != 8)) ? 1 : 0;
   c.C8 = (!c.S16 && !no_c8 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
@@ -503,6 +502,16 @@ __global__ void pack_conv3d_k3_kernel(const float* __restrict__ w, float* __rest
     }
     out[i] = v;
   }
+}
+
+// Kernel family = packed layout of a layer under the current configuration (values_amd.h, vx_config):
+//   1 split-fp16 fragments, 2 split-fp16 x-pair blocks, 3 fp32 fragments, 4 fp32 x-pair, 5 fp32 4x4x1 (Cout = 8)
+extern "C" int vx_conv3d_k3_family(int Cin, int Cout) {
+  if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return 0;
+  const ConvCfg c = conv_config(Cin, Cout);
+  if (c.S16) return vx_conv3d_s16_head_fusable(Cin, Cout) ? 2 : 1;   // head-fusable == x-pair packing
+  if (c.C8) return 5;
+  return c.XP ? 4 : 3;
 }
 
 extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
@@ -596,7 +605,7 @@ static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
   const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   if (per_cu * NW > 32) per_cu = 32 / NW;
-  if (const char* e = getenv("VX_CONV_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // tuning knob
+  if (vx_cfg().conv_per_cu > 0) per_cu = vx_cfg().conv_per_cu;  // tuning knob
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   dim3 grid((unsigned)gx, (unsigned)ygroups);
@@ -641,6 +650,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.Cin <= 0 || a.Cout <= 0 || a.Cin % 8 || a.Cout % 8)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", a.Cin, a.Cout);
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: empty tensor");
+  if (a.w_family != vx_conv3d_k3_family(a.Cin, a.Cout))
+    VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: weights packed for kernel family %d, the library is configured for family %d "
+            "(vx_conv3d_k3_family(%d, %d)): re-pack them", a.w_family, vx_conv3d_k3_family(a.Cin, a.Cout), a.Cin, a.Cout);
   if (a.out && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
   if (a.in_xblk) {
@@ -670,7 +682,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.dbg = nullptr;
-  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
+  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

@@ -703,7 +703,7 @@ struct S16Cfg { int CB, NT, XP; };
 static inline S16Cfg s16_config(int Cin, int Cout) {
   S16Cfg c;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
-  c.XP = (Cout == 8 && !getenv("VX_S16_NO_XP")) ? 1 : 0;
+  c.XP = (Cout == 8 && !vx_cfg().s16_no_xp) ? 1 : 0;
   c.CB = c.XP ? 8 : ((Cin % 16 == 0) ? 16 : 8);
   return c;
 }
@@ -738,7 +738,7 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   static_assert((DB ? 2 : 1) * img + (DB == 3 ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
   ka.w_all = DB ? (ka.nchunks > 1 ? 1 : 0)   // double-buffered variants: the dispatch made sure everything fits
-                : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !getenv("VX_S16_NO_WALL")) ? 1 : 0);
+                : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0);
   const size_t lds = (DB ? 2 : 1) * img + (ka.w_all ? ka.nchunks : 1) * wch + red;
   auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP, DB, EPI>;
   static size_t attr_lds = 0;
@@ -752,7 +752,7 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   if (per_cu * NW > 16) per_cu = 16 / NW > 0 ? 16 / NW : 1;
-  if (const char* e = getenv("VX_S16_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  if (vx_cfg().s16_per_cu > 0) per_cu = vx_cfg().s16_per_cu;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(64 * NW), lds, s, ka);
@@ -765,19 +765,19 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
   // epilogue specialisation of the large-tile instances (EPI in the kernel's header)
   const vx_conv3d_args& a = ka.a;
   int epi = 3;
-  if (!getenv("VX_S16_NO_EPI")) {
+  if (!vx_cfg().s16_no_epi) {
     if (a.act == VX_ACT_NONE && a.drop_mode == VX_DROP_NONE && !a.head_out && a.out) epi = 0;
     else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && !a.head_out && a.out) epi = 1;
     else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
   }
   if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
-    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !getenv("VX_S16_NO_DB")) {
+    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
       if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 2>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 3>(ka, s);
     }
-    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !getenv("VX_S16_NO_DB") && !getenv("VX_S16_NO_DB3")) {   // 16 -> 8 channels
+    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3) {   // 16 -> 8 channels
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 1>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 3>(ka, s);
     }
@@ -806,7 +806,7 @@ void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
   // two row tiles per wave (Cout % 32 == 0) on the large tile would need > 256 registers (75 spilled): small tile there
   // (measured 32->32 @64^3: 321 TFLOP/s on 16x4x4 tiles against 204 on the spilling 16x8x4 instance)
   const bool nt2 = !xp && Cout % 32 == 0;
-  const bool ty8 = tx == 16 && H >= 32 && !nt2 && !getenv("VX_S16_NO_TY8");
+  const bool ty8 = tx == 16 && H >= 32 && !nt2 && !vx_cfg().s16_no_ty8;
   *txv = xp ? 2 * tx : tx;
   *ty = (tx == 8 || ty8) ? 8 : 4;
   *tz = 4;
@@ -830,8 +830,8 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
-  ka.no_xcd = getenv("VX_CONV_NO_XCD") ? 1 : 0;
-  ka.dbg = getenv("VX_S16_DBG") ? atoi(getenv("VX_S16_DBG")) : 0;
+  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
+  ka.dbg = vx_cfg().s16_dbg;
   ka.ty8 = ty8;
   if (c.XP) return dispatch_s16<8, 1, 1>(ka, tx, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1, 0>(ka, tx, s);

@@ -240,7 +240,7 @@ static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   const int groups = (a.Cout / 2) / RT;          // 8 * Cout rows = Cout / 2 row tiles
   int bx = (ncoltiles + 3) / 4;
   int per = 32;   // workgroups per CU in the grid: more, shorter address streams write faster (fill: 5.1 TB/s at 2048 WGs, 6.5 at 32768)
-  if (const char* e = getenv("VX_CONVT_WGS")) per = atoi(e) > 0 ? atoi(e) : per;
+  if (vx_cfg().convt_wgs > 0) per = vx_cfg().convt_wgs;
   const int cap = (256 * per + groups - 1) / groups;
   if (bx > cap) bx = cap;
   auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
@@ -302,7 +302,7 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   // (flat voxel index * largest dimension < 2^32: the multiply-high divisions of the index decode are then exact)
   const int64_t dmax = a.W > a.H ? (a.W > a.D ? a.W : a.D) : (a.H > a.D ? a.H : a.D);
   if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && (int64_t)a.N * a.D * a.H * a.W * dmax < (1ll << 32) &&
-      !getenv("VX_CONVT_NO_MFMA")) {
+      !vx_cfg().convt_no_mfma) {
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.Cout / 2;
     if (a.Cin == 16 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<16, 4>(a, s) : launch_convT_mfma<16, 8>(a, s);

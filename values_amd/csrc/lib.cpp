@@ -13,5 +13,68 @@ void vx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int vx_version(void) { return 100; /* 0.1.0 */ }
+// ---- configuration: read from the environment exactly once, replaced only by vx_set_config ----
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+
+static vx_config g_cfg;
+static std::once_flag g_cfg_once;
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 0);
+  return end == e ? 1 : (int)v;   // VX_S16_NO_DB=yes style switches count as 1
+}
+
+static void cfg_from_env() {
+  memset(&g_cfg, 0, sizeof(g_cfg));
+  g_cfg.conv_fp32 = env_int("VX_CONV_FP32", 0);
+  g_cfg.conv_no_c8 = env_int("VX_CONV_NO_C8", 0);
+  g_cfg.conv_dma = env_int("VX_CONV_DMA", 0);
+  g_cfg.conv_no_xcd = env_int("VX_CONV_NO_XCD", 0);
+  g_cfg.conv_per_cu = env_int("VX_CONV_PER_CU", 0);
+  g_cfg.s16_per_cu = env_int("VX_S16_PER_CU", 0);
+  g_cfg.c8_per_cu = env_int("VX_C8_PER_CU", 0);
+  g_cfg.convt_wgs = env_int("VX_CONVT_WGS", 0);
+  g_cfg.s16_no_xp = env_int("VX_S16_NO_XP", 0);
+  g_cfg.s16_no_db = env_int("VX_S16_NO_DB", 0);
+  g_cfg.s16_no_db3 = env_int("VX_S16_NO_DB3", 0);
+  g_cfg.s16_no_epi = env_int("VX_S16_NO_EPI", 0);
+  g_cfg.s16_no_ty8 = env_int("VX_S16_NO_TY8", 0);
+  g_cfg.s16_no_wall = env_int("VX_S16_NO_WALL", 0);
+  g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
+  g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
+  g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);
+  g_cfg.no_head_fusion = env_int("VX_NO_HEAD_FUSION", 0);
+  g_cfg.s16_dbg = env_int("VX_S16_DBG", 0);
+  g_cfg.c8_dbg = env_int("VX_C8_DBG", 0);
+  g_cfg.dma_dbg = env_int("VX_DMA_DBG", 0);
+  g_cfg.dma_nw16 = env_int("VX_DMA_NW16", 0);
+  g_cfg.c8_tile16 = env_int("VX_C8_TILE16", 0);
+  g_cfg.s16_range_check = env_int("VX_S16_RANGE_CHECK", 1);
+}
+
+const vx_config& vx_cfg() {
+  std::call_once(g_cfg_once, cfg_from_env);
+  return g_cfg;
+}
+
+extern "C" int vx_get_config(vx_config* out) {
+  if (!out) { vx_set_error("vx_get_config: null"); return VX_E_NULL; }
+  *out = vx_cfg();
+  return VX_OK;
+}
+
+extern "C" int vx_set_config(const vx_config* cfg) {
+  if (!cfg) { vx_set_error("vx_set_config: null"); return VX_E_NULL; }
+  if (cfg->conv_fp32 < 0 || cfg->conv_fp32 > 2) { vx_set_error("vx_set_config: conv_fp32 %d", cfg->conv_fp32); return VX_E_DTYPE; }
+  (void)vx_cfg();
+  g_cfg = *cfg;
+  return VX_OK;
+}
+
+extern "C" int vx_version(void) { return 200; /* 0.2.0 */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

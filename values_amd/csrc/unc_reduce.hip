@@ -55,13 +55,34 @@ __device__ __forceinline__ void store_u8(uint8_t* p, const int (&v)[VEC]) {
 }
 
 // ---- probabilities in, any C: class-outer loop, only scalars live ----
-template <typename TIn, int VEC>
+// Optional extras of vx_unc_reduce_ex, all in the same pass:
+//   variance  : mean over classes of the population variance over the T samples (north_star's fourth map; the reference
+//               has none).  Accumulated as deviations from sample 0 (d = p_t - p_0): sum d and sum d^2 stay small
+//               where the samples agree, so var = sum d^2 / T - (sum d / T)^2 does not cancel like sum p^2 / T - mean^2.
+//   in_count  : inputs divided by max(count, 1) on load (the normalised sliding-window sums)
+//   out_count : maps divided by max(count, 1) on store (DataCarrier3D.save_data, data_carrier_3D.py:323-337, applied to
+//               maps of the UN-normalised sums: quirk D10); the variance by its square
+struct UncExtra {
+  float* variance;
+  const float* in_count;
+  const float* out_count;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_inv_count(const float* cnt, int64_t i, float (&inv)[VEC]) {
+  float c[VEC];
+  load_vec<float, VEC>(cnt + i, c);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) inv[k] = fmaxf(c[k], 1.f);   // np.clip(count, 1, None); callers DIVIDE by it
+}
+
+template <typename TIn, int VEC, bool EX>
 __global__ __launch_bounds__(256) void unc_reduce_prob_kernel(const TIn* __restrict__ x, int T, int C, int64_t nvox,
                                                               float* __restrict__ mean_prob,
                                                               float* __restrict__ pred_entropy,
                                                               float* __restrict__ exp_entropy,
                                                               float* __restrict__ mutual_info,
-                                                              uint8_t* __restrict__ argmax) {
+                                                              uint8_t* __restrict__ argmax, UncExtra ex) {
   const int b = blockIdx.y;
   const TIn* xb = x + (size_t)b * T * C * nvox;
   const int64_t ngroups = nvox / VEC;
@@ -71,30 +92,46 @@ __global__ __launch_bounds__(256) void unc_reduce_prob_kernel(const TIn* __restr
     TIn ee[VEC];     // sum over (t, c) of p*log(p)
     TIn best[VEC];
     int besti[VEC];
+    TIn var[VEC];
+    float iin[VEC], iout[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { pe[k] = 0.f; ee[k] = 0; best[k] = 0; besti[k] = 0; }
+    for (int k = 0; k < VEC; ++k) { pe[k] = 0.f; ee[k] = 0; best[k] = 0; besti[k] = 0; var[k] = 0; iin[k] = 1.f; iout[k] = 1.f; }
+    if (EX && ex.in_count) load_inv_count<VEC>(ex.in_count, (int64_t)b * nvox + v0, iin);
+    if (EX && ex.out_count) load_inv_count<VEC>(ex.out_count, (int64_t)b * nvox + v0, iout);
     for (int c = 0; c < C; ++c) {
-      TIn s[VEC];
+      TIn s[VEC], p0[VEC], d1[VEC], d2[VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) s[k] = 0;
+      for (int k = 0; k < VEC; ++k) { s[k] = 0; p0[k] = 0; d1[k] = 0; d2[k] = 0; }
       for (int t = 0; t < T; ++t) {
         TIn p[VEC];
         load_vec<TIn, VEC>(xb + ((size_t)t * C + c) * nvox + v0, p);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
+          if (EX && ex.in_count) p[k] /= (TIn)iin[k];
           s[k] += p[k];
           const TIn term = p[k] * vx_log<TIn>(p[k]);
           if (term == term) ee[k] += term;  // NaN-skip (test_3D.py:503-504)
+          if (EX) {
+            if (t == 0) p0[k] = p[k];
+            const TIn d = p[k] - p0[k];
+            d1[k] += d;
+            d2[k] += d * d;
+          }
         }
       }
       float mo[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const TIn mean = s[k] / (TIn)T;
-        mo[k] = (float)mean;
+        mo[k] = (float)mean / iout[k];
         const TIn term = mean * vx_log<TIn>(mean);
         if (term == term) pe[k] = (float)((TIn)pe[k] + term);  // f32 accumulator (test_3D.py:490-494)
         if (c == 0 || mean > best[k]) { best[k] = mean; besti[k] = c; }
+        if (EX) {
+          const TIn md = d1[k] / (TIn)T;
+          const TIn vv = d2[k] / (TIn)T - md * md;
+          var[k] += vv > (TIn)0 ? vv : (TIn)0;
+        }
       }
       if (mean_prob) store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
     }
@@ -104,23 +141,30 @@ __global__ __launch_bounds__(256) void unc_reduce_prob_kernel(const TIn* __restr
       o_pe[k] = -pe[k];
       o_ee[k] = (float)(-ee[k] / (TIn)T);
       o_mi[k] = o_pe[k] - o_ee[k];
+      if (EX && ex.out_count) { o_pe[k] /= iout[k]; o_ee[k] /= iout[k]; o_mi[k] /= iout[k]; }
     }
     store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
     store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
     store_f32<VEC>(mutual_info + (size_t)b * nvox + v0, o_mi);
     if (argmax) store_u8<VEC>(argmax + (size_t)b * nvox + v0, besti);
+    if (EX && ex.variance) {
+      float o_v[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o_v[k] = (float)(var[k] / (TIn)C) / (iout[k] * iout[k]);
+      store_f32<VEC>(ex.variance + (size_t)b * nvox + v0, o_v);
+    }
   }
 }
 
 // ---- logits in, C known at compile time (<= 8): sample-outer loop, softmax in registers ----
-template <typename TIn, int C, int VEC>
+template <typename TIn, int C, int VEC, bool EX>
 __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __restrict__ x, int T, int64_t nvox,
                                                                float* __restrict__ mean_prob,
                                                                float* __restrict__ pred_entropy,
                                                                float* __restrict__ exp_entropy,
                                                                float* __restrict__ mutual_info,
                                                                uint8_t* __restrict__ argmax,
-                                                               uint8_t* __restrict__ sample_argmax) {
+                                                               uint8_t* __restrict__ sample_argmax, UncExtra ex) {
   const int b = blockIdx.y;
   const TIn* xb = x + (size_t)b * T * C * nvox;
   const int64_t ngroups = nvox / VEC;
@@ -128,11 +172,15 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
     const int64_t v0 = gi * VEC;
     TIn sum[C][VEC];
     TIn ee[VEC];
+    // variance (EX): deviations from sample 0 per class, see UncExtra
+    TIn p0[EX ? C : 1][VEC], d1[EX ? C : 1][VEC], d2[EX ? C : 1][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       ee[k] = 0;
 #pragma unroll
       for (int c = 0; c < C; ++c) sum[c][k] = 0;
+#pragma unroll
+      for (int c = 0; c < (EX ? C : 1); ++c) { p0[c][k] = 0; d1[c][k] = 0; d2[c][k] = 0; }
     }
     for (int t = 0; t < T; ++t) {
       TIn z[C][VEC];
@@ -158,12 +206,22 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
           const TIn p = e[c] * inv;
           sum[c][k] += p;
           ee[k] += p * ((z[c][k] - m) - lden);  // p*log(p) via log-softmax
+          if (EX) {
+            if (t == 0) p0[c][k] = p;
+            const TIn d = p - p0[c][k];
+            d1[c][k] += d;
+            d2[c][k] += d * d;
+          }
         }
       }
       if (sample_argmax) store_u8<VEC>(sample_argmax + ((size_t)b * T + t) * nvox + v0, am);
     }
     float pe[VEC];
     int besti[VEC];
+    float iout[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) iout[k] = 1.f;
+    if (EX && ex.out_count) load_inv_count<VEC>(ex.out_count, (int64_t)b * nvox + v0, iout);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       pe[k] = 0.f;
@@ -182,7 +240,7 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
       for (int c = 0; c < C; ++c) {
         float mo[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) mo[k] = (float)(sum[c][k] / (TIn)T);
+        for (int k = 0; k < VEC; ++k) mo[k] = (float)(sum[c][k] / (TIn)T) / iout[k];
         store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
       }
     }
@@ -192,11 +250,27 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
       o_pe[k] = -pe[k];
       o_ee[k] = (float)(-ee[k] / (TIn)T);
       o_mi[k] = o_pe[k] - o_ee[k];
+      if (EX && ex.out_count) { o_pe[k] /= iout[k]; o_ee[k] /= iout[k]; o_mi[k] /= iout[k]; }
     }
     store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
     store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
     store_f32<VEC>(mutual_info + (size_t)b * nvox + v0, o_mi);
     if (argmax) store_u8<VEC>(argmax + (size_t)b * nvox + v0, besti);
+    if (EX && ex.variance) {
+      float o_v[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        TIn var = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const TIn md = d1[c][k] / (TIn)T;
+          const TIn vv = d2[c][k] / (TIn)T - md * md;
+          var += vv > (TIn)0 ? vv : (TIn)0;
+        }
+        o_v[k] = (float)(var / (TIn)C) / (iout[k] * iout[k]);
+      }
+      store_f32<VEC>(ex.variance + (size_t)b * nvox + v0, o_v);
+    }
   }
 }
 
@@ -413,15 +487,20 @@ __global__ __launch_bounds__(256) void one_minus_msr_kernel(const TIn* __restric
 template <typename TIn, int VEC>
 static int launch_unc(const TIn* x, int from_logits, int B, int T, int C, int64_t nvox, float* mean_prob,
                       float* pred_entropy, float* exp_entropy, float* mutual_info, uint8_t* argmax,
-                      uint8_t* sample_argmax, hipStream_t s) {
+                      uint8_t* sample_argmax, const UncExtra& ex, hipStream_t s) {
   const int64_t ngroups = nvox / VEC;
   int bx = (int)((ngroups + 255) / 256);
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   dim3 grid((unsigned)bx, (unsigned)B);
+  const bool extra = ex.variance || ex.in_count || ex.out_count;
   if (!from_logits) {
-    hipLaunchKernelGGL((unc_reduce_prob_kernel<TIn, VEC>), grid, dim3(256), 0, s, x, T, C, nvox, mean_prob, pred_entropy,
-                       exp_entropy, mutual_info, argmax);
+    if (extra)
+      hipLaunchKernelGGL((unc_reduce_prob_kernel<TIn, VEC, true>), grid, dim3(256), 0, s, x, T, C, nvox, mean_prob, pred_entropy,
+                         exp_entropy, mutual_info, argmax, ex);
+    else
+      hipLaunchKernelGGL((unc_reduce_prob_kernel<TIn, VEC, false>), grid, dim3(256), 0, s, x, T, C, nvox, mean_prob, pred_entropy,
+                         exp_entropy, mutual_info, argmax, ex);
     if (sample_argmax) {
       const int64_t total = (int64_t)B * T * nvox;
       int bb = (int)((total + 255) / 256);
@@ -430,10 +509,15 @@ static int launch_unc(const TIn* x, int from_logits, int B, int T, int C, int64_
     }
     return VX_OK;
   }
+  if (ex.in_count) VX_FAIL(VX_E_DTYPE, "vx_unc_reduce_ex: in_count applies to probability sums, not to logits");
 #define VX_LOGIT(CC)                                                                                                \
   case CC:                                                                                                          \
-    hipLaunchKernelGGL((unc_reduce_logit_kernel<TIn, CC, VEC>), grid, dim3(256), 0, s, x, T, nvox, mean_prob,        \
-                       pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax);                              \
+    if (extra)                                                                                                      \
+      hipLaunchKernelGGL((unc_reduce_logit_kernel<TIn, CC, VEC, true>), grid, dim3(256), 0, s, x, T, nvox, mean_prob, \
+                         pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex);                        \
+    else                                                                                                            \
+      hipLaunchKernelGGL((unc_reduce_logit_kernel<TIn, CC, VEC, false>), grid, dim3(256), 0, s, x, T, nvox, mean_prob, \
+                         pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex);                        \
     break;
   switch (C) {
     VX_LOGIT(2) VX_LOGIT(3) VX_LOGIT(4) VX_LOGIT(5) VX_LOGIT(6) VX_LOGIT(7) VX_LOGIT(8)
@@ -443,33 +527,47 @@ static int launch_unc(const TIn* x, int from_logits, int B, int T, int C, int64_
   return VX_OK;
 }
 
-extern "C" int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
-                             float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
-                             uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream) {
+extern "C" int vx_unc_reduce_ex(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
+                                const vx_unc_outputs* o, vx_stream_t stream) {
+  if (!o) VX_FAIL(VX_E_NULL, "vx_unc_reduce: null outputs");
   if (B <= 0 || T <= 0 || C <= 0 || nvox < 0) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: B=%d T=%d C=%d nvox=%lld", B, T, C, (long long)nvox);
   if (nvox == 0) return VX_OK;  // empty volume: nothing to do (the reference returns empty maps)
+  float *mean_prob = o->mean_prob, *pred_entropy = o->pred_entropy, *exp_entropy = o->exp_entropy, *mutual_info = o->mutual_info;
+  uint8_t *argmax = o->argmax, *sample_argmax = o->sample_argmax;
   if (!x || !pred_entropy || !exp_entropy || !mutual_info) VX_FAIL(VX_E_NULL, "vx_unc_reduce: null pointer");
   if (C > 255 && (argmax || sample_argmax)) VX_FAIL(VX_E_SHAPE, "vx_unc_reduce: uint8 argmax needs C <= 255");
   if (dtype != VX_F32 && dtype != VX_F64) VX_FAIL(VX_E_DTYPE, "vx_unc_reduce: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
+  UncExtra ex;
+  ex.variance = o->variance; ex.in_count = o->in_count; ex.out_count = o->out_count;
   const bool al = vx_aligned16(x) && vx_aligned16(pred_entropy) && vx_aligned16(exp_entropy) && vx_aligned16(mutual_info) &&
                   (!mean_prob || vx_aligned16(mean_prob)) && (!argmax || (((uintptr_t)argmax) & 3u) == 0) &&
-                  (!sample_argmax || (((uintptr_t)sample_argmax) & 3u) == 0);
+                  (!sample_argmax || (((uintptr_t)sample_argmax) & 3u) == 0) && (!ex.variance || vx_aligned16(ex.variance)) &&
+                  (!ex.in_count || vx_aligned16(ex.in_count)) && (!ex.out_count || vx_aligned16(ex.out_count));
   int rc;
   if (dtype == VX_F32) {
     if (al && nvox % 4 == 0)
-      rc = launch_unc<float, 4>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+      rc = launch_unc<float, 4>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex, s);
     else
-      rc = launch_unc<float, 1>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+      rc = launch_unc<float, 1>((const float*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex, s);
   } else {
     if (al && nvox % 4 == 0)
-      rc = launch_unc<double, 2>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+      rc = launch_unc<double, 2>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex, s);
     else
-      rc = launch_unc<double, 1>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, s);
+      rc = launch_unc<double, 1>((const double*)x, from_logits, B, T, C, nvox, mean_prob, pred_entropy, exp_entropy, mutual_info, argmax, sample_argmax, ex, s);
   }
   if (rc != VX_OK) return rc;
   VX_CHECK_LAUNCH("vx_unc_reduce");
   return VX_OK;
+}
+
+extern "C" int vx_unc_reduce(const void* x, int dtype, int from_logits, int B, int T, int C, int64_t nvox,
+                             float* mean_prob, float* pred_entropy, float* exp_entropy, float* mutual_info,
+                             uint8_t* argmax, uint8_t* sample_argmax, vx_stream_t stream) {
+  vx_unc_outputs o;
+  o.mean_prob = mean_prob; o.pred_entropy = pred_entropy; o.exp_entropy = exp_entropy; o.mutual_info = mutual_info;
+  o.variance = nullptr; o.argmax = argmax; o.sample_argmax = sample_argmax; o.in_count = nullptr; o.out_count = nullptr;
+  return vx_unc_reduce_ex(x, dtype, from_logits, B, T, C, nvox, &o, stream);
 }
 
 extern "C" int vx_one_minus_msr(const void* x, int dtype, int C, int64_t nvox, void* out, vx_stream_t stream) {

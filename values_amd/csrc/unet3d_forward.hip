@@ -136,7 +136,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
 
   auto xblk_of = [](int W) { return W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); };
   // head fusion: where the last 3x3x3 conv runs on the kernel that holds a voxel's channels in one lane
-  const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !getenv("VX_NO_HEAD_FUSION");
+  const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !vx_cfg().no_head_fusion;
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk) {
     vx_conv3d_args a;
@@ -147,6 +147,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       out = nullptr;
     }
     a.in_xblk = in_xblk;
+    a.w_family = w->conv_family[wi];
     a.in = in; a.w_packed = w->conv_w[wi]; a.bias = w->conv_b[wi]; a.out = out;
     a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.out_coff = out_coff;
     a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.Cin = Cin; a.Cout = Cout;

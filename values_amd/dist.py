@@ -21,15 +21,27 @@ def shard_range(n_items: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def float_keys(out: Dict[str, torch.Tensor]):
+    """the single-plane float maps of a result dict that travel: the reference's three + the variance map if present"""
+    return MAP_KEYS + (("softmax_variance",) if "softmax_variance" in out else ())
+
+
+def use_all_gather() -> bool:
+    """Chosen ONCE, up front, from the backend's capabilities (never by catching an error mid-collective: ranks that
+    disagree about which collective comes next hang).  gloo, nccl (= RCCL on ROCm) and mpi implement gather."""
+    import torch.distributed as dist
+    return str(dist.get_backend()).lower() not in ("gloo", "nccl", "mpi")
+
+
 def pack_maps(out: Dict[str, torch.Tensor]):
-    """(V, 3+C, *spatial) f32 [pred_entropy, aleatoric, epistemic, mean_softmax...] and (V, *spatial) u8."""
-    f = torch.cat([out[k].unsqueeze(1) for k in MAP_KEYS] + [out["mean_softmax"]], dim=1)
+    """(V, K+C, *spatial) f32 [pred_entropy, aleatoric, epistemic, (variance,) mean_softmax...] and (V, *spatial) u8."""
+    f = torch.cat([out[k].unsqueeze(1) for k in float_keys(out)] + [out["mean_softmax"]], dim=1)
     return f.contiguous(), out["pred_seg_mean"].contiguous()
 
 
-def unpack_maps(f: torch.Tensor, seg: torch.Tensor) -> Dict[str, torch.Tensor]:
-    out = {k: f[:, i] for i, k in enumerate(MAP_KEYS)}
-    out["mean_softmax"] = f[:, len(MAP_KEYS):]
+def unpack_maps(f: torch.Tensor, seg: torch.Tensor, keys=MAP_KEYS) -> Dict[str, torch.Tensor]:
+    out = {k: f[:, i] for i, k in enumerate(keys)}
+    out["mean_softmax"] = f[:, len(keys):]
     out["pred_seg_mean"] = seg
     return out
 
@@ -49,10 +61,10 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
             lists = ([torch.empty_like(f) for _ in range(world)], [torch.empty_like(seg) for _ in range(world)])
             _bufs.clear()
             _bufs[key] = lists
-    try:
+    if not use_all_gather():
         dist.gather(f, lists[0] if lists else None, dst=dst)
         dist.gather(seg, lists[1] if lists else None, dst=dst)
-    except RuntimeError:
+    else:
         # a backend without gather: all_gather is universally available (every rank then holds the maps)
         if lists is None:
             lists = ([torch.empty_like(f) for _ in range(world)], [torch.empty_like(seg) for _ in range(world)])
@@ -60,7 +72,7 @@ def gather_maps(out: Dict[str, torch.Tensor], world: int, rank: int, dst: int = 
         dist.all_gather(lists[1], seg)
     if rank != dst:
         return None
-    return unpack_maps(torch.cat(lists[0], 0), torch.cat(lists[1], 0))
+    return unpack_maps(torch.cat(lists[0], 0), torch.cat(lists[1], 0), float_keys(out))
 
 
 class MapGatherPipeline:
@@ -82,7 +94,8 @@ class MapGatherPipeline:
         self._inflight = []      # [(slot, works)] oldest first
         self._pending = None     # (slot, completion event or None) of the step packed last
         self._next = 0
-        self._use_all_gather = False
+        self._keys = MAP_KEYS
+        self._use_all_gather = use_all_gather() if world > 1 else False
 
     def _start(self):
         """start the gather of the pending step"""
@@ -97,17 +110,9 @@ class MapGatherPipeline:
                                 torch.empty((self.world,) + tuple(ss.shape), dtype=ss.dtype, device=ss.device))
         have_recv = self._recv[slot] is not None
         rl = (list(self._recv[slot][0].unbind(0)), list(self._recv[slot][1].unbind(0))) if have_recv else (None, None)
-        works = None
         if not self._use_all_gather:
-            try:
-                works = [dist.gather(sf, rl[0] if self.rank == self.dst else None, dst=self.dst, async_op=True),
-                         dist.gather(ss, rl[1] if self.rank == self.dst else None, dst=self.dst, async_op=True)]
-            except RuntimeError:
-                # a backend without gather: all_gather is universally available (every rank then holds the maps);
-                # the switch is collective-safe because every rank hits the same error on the same call
-                self._use_all_gather = True
-                self._pending = (slot, None)
-                return self._start()
+            works = [dist.gather(sf, rl[0] if self.rank == self.dst else None, dst=self.dst, async_op=True),
+                     dist.gather(ss, rl[1] if self.rank == self.dst else None, dst=self.dst, async_op=True)]
         else:
             works = [dist.all_gather(rl[0], sf, async_op=True), dist.all_gather(rl[1], ss, async_op=True)]
         self._inflight.append((slot, works))
@@ -125,7 +130,8 @@ class MapGatherPipeline:
             self._start()
         slot = self._next
         self._next = (self._next + 1) % self._slots
-        parts = [out[k].unsqueeze(1) for k in MAP_KEYS] + [out["mean_softmax"]]
+        self._keys = float_keys(out)
+        parts = [out[k].unsqueeze(1) for k in self._keys] + [out["mean_softmax"]]
         seg = out["pred_seg_mean"]
         fshape = (seg.shape[0], sum(p.shape[1] for p in parts)) + tuple(seg.shape[1:])
         if self._send[slot] is None or tuple(self._send[slot][0].shape) != fshape:
@@ -154,7 +160,7 @@ class MapGatherPipeline:
         if self.rank != self.dst:
             return None
         rf, rs = self._recv[slot]
-        return unpack_maps(rf.view((-1,) + tuple(rf.shape[2:])), rs.view((-1,) + tuple(rs.shape[2:])))
+        return unpack_maps(rf.view((-1,) + tuple(rf.shape[2:])), rs.view((-1,) + tuple(rs.shape[2:])), self._keys)
 
     def flush(self) -> List[Optional[Dict[str, torch.Tensor]]]:
         res = []
@@ -185,11 +191,23 @@ def ensemble_work_items(n_members: int, n_volumes: int, world: int):
     return [items[r::world] for r in range(world)]
 
 
+def passes_per_member(model, n_pred: int = 1, tta: bool = False, n_aleatoric_samples: int = 10) -> int:
+    """Passes predict_cases makes per member (test_3D.py:426-482): 16 TTA views, n_aleatoric_samples draws of an
+    aleatoric head (n_pred is ignored there, :458-469), else n_pred MC samples."""
+    if tta:
+        return 16
+    if bool(getattr(model, "aleatoric_loss", False)):
+        return int(n_aleatoric_samples)
+    return int(n_pred)
+
+
 def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int, n_pred: int = 1, dst: int = 0,
-                                 seeds=None, group=None) -> Optional[Dict[str, torch.Tensor]]:
+                                 seeds=None, group=None, tta: bool = False, x_noise=None,
+                                 n_aleatoric_samples: int = 10) -> Optional[Dict[str, torch.Tensor]]:
     """models: the FULL member list (every rank holds all checkpoints; only its items run).  x: (V,1,D,H,W), the
-    same on every rank.  Returns the maps on `dst` (None elsewhere)."""
-    import ctypes as C_
+    same on every rank.  Returns the maps on `dst` (None elsewhere).  The number of passes of a member is taken from the
+    logits it produced (and checked against passes_per_member); the total every rank finalises with is the sum over
+    ALL members, whichever rank ran them."""
     from . import _lib
     from .predict import predict_logits
     lib = _lib.load()
@@ -200,18 +218,26 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
     nvox = 1
     for s_ in spatial:
         nvox *= s_
+    per_member = [passes_per_member(m, n_pred, tta, n_aleatoric_samples) for m in models]
     stats = torch.zeros((V, Cc + 1) + spatial, dtype=torch.float32, device=dev)
     for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
         kw = {"seeds": [seeds[m]]} if seeds is not None else {}
-        logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, **kw)  # (hi-lo, n_pred, C, ...)
-        _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(logits), hi - lo, n_pred, Cc, nvox, _lib.ptr(stats[lo:hi]),
+        if tta:
+            kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
+        logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,
+                                **kw).contiguous()  # (hi-lo, T_m, C, ...)
+        T_m = int(logits.shape[1])
+        if T_m != per_member[m] or tuple(logits.shape[:3]) != (hi - lo, T_m, Cc):
+            raise _lib.VxError(f"ensemble_uncertainty_sharded: member {m} produced logits {tuple(logits.shape)}, "
+                               f"expected {per_member[m]} passes of {Cc} classes")
+        _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(logits), hi - lo, T_m, Cc, nvox, _lib.ptr(stats[lo:hi]),
                                                _lib.stream_ptr()), "vx_unc_stats_accumulate")
     if world > 1:
         import torch.distributed as dist
         dist.reduce(stats, dst=dst, op=dist.ReduceOp.SUM, group=group)
         if rank != dst:
             return None
-    return finalize_stats(stats, len(models) * n_pred)
+    return finalize_stats(stats, sum(per_member))
 
 
 def finalize_stats(stats: torch.Tensor, t_total: int) -> Dict[str, torch.Tensor]:

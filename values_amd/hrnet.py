@@ -306,7 +306,7 @@ class HighResolutionNet(nn.Module):
                 if mod.bias is not None:
                     b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=dev)  # readable per 16-row tile
                     b[:cout] = mod.bias.detach().to(dev, torch.float32)
-                packed[name] = (wp, b, cin, cout, ks, mod.stride[0], w)
+                packed[name] = (wp, b, cin, cout, ks, mod.stride[0], w, lib.vx_conv2d_family(cin, cout, ks))
             elif isinstance(mod, nn.BatchNorm2d):
                 packed[name] = (mod.weight.detach().to(dev, torch.float32).contiguous(),
                                 mod.bias.detach().to(dev, torch.float32).contiguous())
@@ -316,7 +316,7 @@ class HighResolutionNet(nn.Module):
     # ------------------------------------------------------------------ kernel wrappers
     def _conv(self, x: _Act, name, stats=True):
         lib = _lib.load()
-        wp, b, cin, cout, ks, stride, _w = self._pk[name]
+        wp, b, cin, cout, ks, stride, _w, fam = self._pk[name]
         cin_pad = (cin + 15) // 16 * 16
         assert x.C == cin_pad or x.C == cin, (name, x.C, cin)
         n, h, w = x.N, x.H, x.W
@@ -330,6 +330,7 @@ class HighResolutionNet(nn.Module):
             out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
         part = None
         a = _lib.Conv2dArgs()
+        a.w_family = fam
         a.in_ = x.t.data_ptr(); a.in_pitch = x.pitch; a.w_packed = wp.data_ptr()
         a.bias = b.data_ptr() if b is not None else None
         a.out = out.data_ptr(); a.out_pitch = pitch; a.out_coff = 0

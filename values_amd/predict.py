@@ -59,6 +59,32 @@ def predict_logits_ssn(model, x: torch.Tensor, n_pred: int = 1, eps_w=None, eps_
 
 
 _side_streams: Dict[int, list] = {}
+_index_cache: Dict[tuple, tuple] = {}
+
+
+def _slot_indices(dev, v0: int, v1: int, n_total: int, base: int, per_model: int, tta: bool):
+    """(src, flip, dst) int32 device tensors of a volume chunk's samples: sample (v, k) writes logits slot
+    v * n_total + base + k; TTA sample k reads the original (k < 8) or the noisy (k >= 8) copy of volume v with flip
+    code TTA_FLIP_CODES[k % 8].  Built on the host once per geometry and cached: no index arithmetic kernels per step."""
+    key = (str(dev), v0, v1, n_total, base, per_model, tta)
+    hit = _index_cache.get(key)
+    if hit is not None:
+        return hit
+    import numpy as np
+    Vc = v1 - v0
+    v = np.arange(v0, v1, dtype=np.int64)[:, None]
+    k = np.arange(per_model, dtype=np.int64)[None, :]
+    dst = torch.from_numpy((v * n_total + base + k).reshape(-1).astype(np.int32)).to(dev)
+    src = flip = None
+    if tta:
+        lidx = np.arange(Vc, dtype=np.int64)[:, None]
+        src = torch.from_numpy((lidx + (k // 8) * Vc).reshape(-1).astype(np.int32)).to(dev)   # orig / noisy copy of v
+        codes = np.asarray(TTA_FLIP_CODES * 2, dtype=np.int32)[None, :]
+        flip = torch.from_numpy(np.broadcast_to(codes, (Vc, 16)).reshape(-1).copy()).to(dev)
+    if len(_index_cache) > 256:
+        _index_cache.clear()
+    _index_cache[key] = (src, flip, dst)
+    return src, flip, dst
 
 
 def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, samples_per_volume: int = 1):
@@ -128,23 +154,14 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
             st.wait_stream(main)          # x, x_noise and the logits buffer were produced on the caller's stream
     for ci, (v0, v1) in enumerate(chunks):
         with torch.cuda.stream(side[ci % len(side)]):
-            Vc = v1 - v0
-            vidx = torch.arange(v0, v1, device=dev, dtype=torch.int32)
             xc = x[v0:v1]
+            xin = torch.cat([xc, x_noise[v0:v1]], 0) if tta else None   # volumes [0,Vc) orig, [Vc,2Vc) noisy
             for mi, model in enumerate(models):
                 base = mi * per_model
+                src, flip, dst = _slot_indices(dev, v0, v1, n_total, base, per_model, tta)
                 if tta:
-                    xin = torch.cat([xc, x_noise[v0:v1]], 0)  # volumes [0,Vc) orig, [Vc,2Vc) noisy
-                    k = torch.arange(16, device=dev, dtype=torch.int32)
-                    codes = torch.tensor(TTA_FLIP_CODES * 2, device=dev, dtype=torch.int32)
-                    lidx = torch.arange(Vc, device=dev, dtype=torch.int32)
-                    src = (lidx[:, None] + (k[None, :] // 8) * Vc).reshape(-1)      # sample (v,k) reads orig / noisy v
-                    flip = codes[None, :].expand(Vc, 16).reshape(-1)
-                    dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
                     model(xin, src=src, flip=flip, dst=dst, out=flat)
                 else:
-                    k = torch.arange(n_pred, device=dev, dtype=torch.int32)
-                    dst = (vidx[:, None] * n_total + base + k[None, :]).reshape(-1)
                     kw = {}
                     if dropout_masks is not None:
                         kw["dropout_masks"] = dropout_masks[mi]
@@ -166,7 +183,9 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
                         **kw) -> Dict[str, torch.Tensor]:
     """Forward passes + fused reduction.  Returns device tensors keyed like the reference's results:
     pred_entropy / aleatoric_uncertainty / epistemic_uncertainty (V,D,H,W) f32 (test_3D.py:509-516),
-    mean_softmax (V,C,D,H,W), pred_seg_mean (V,D,H,W) u8 (data_carrier_3D.py:254-255), logits."""
+    mean_softmax (V,C,D,H,W), pred_seg_mean (V,D,H,W) u8 (data_carrier_3D.py:254-255), logits; plus
+    softmax_variance (V,D,H,W) f32 -- the north star's fourth map, from the same pass over the logits (no reference
+    counterpart)."""
     m = None
     one_batch = (hasattr(models[0], "rank") and hasattr(models[0], "cov_factor_conv")) or \
         (bool(getattr(models[0], "aleatoric_loss", False)) and not tta)      # SSN / aleatoric head: no volume chunks
@@ -176,18 +195,18 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         n_total = (16 if tta else n_pred) * len(models)
         m = alloc_uncertainty_maps(x.shape[0], n_total, models[0].num_classes, tuple(x.shape[2:]), dev,
-                                   want_sample_argmax=want_sample_argmax)
+                                   want_sample_argmax=want_sample_argmax, want_variance=True)
 
     def reduce_chunk(lg, v0, v1):
-        uncertainty_maps(lg[v0:v1], from_logits=True, want_sample_argmax=want_sample_argmax,
+        uncertainty_maps(lg[v0:v1], from_logits=True, want_sample_argmax=want_sample_argmax, want_variance=True,
                          out={k: t[v0:v1] for k, t in m.items()})
 
     logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise,
                             _after_chunk=None if one_batch else reduce_chunk, **kw)
     if one_batch:
-        m = uncertainty_maps(logits, from_logits=True, want_sample_argmax=want_sample_argmax)
+        m = uncertainty_maps(logits, from_logits=True, want_sample_argmax=want_sample_argmax, want_variance=True)
     out = {"pred_entropy": m["pred_entropy"], "mean_softmax": m["mean_softmax"], "pred_seg_mean": m["argmax"],
-           "logits": logits}
+           "softmax_variance": m["softmax_variance"], "logits": logits}
     if not ssn:
         out["aleatoric_uncertainty"] = m["expected_entropy"]
         out["epistemic_uncertainty"] = m["mutual_information"]
@@ -214,7 +233,8 @@ class HostPipeline:
     Here step i's download is enqueued in submit(i + 2), after the HOST has seen step i's completion event; step
     i + 1 is queued on the GPU meanwhile, so the device never idles (tools/exp_hostpipe.py, exp_hostpipe2.py)."""
 
-    KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax", "pred_seg_mean")
+    KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "softmax_variance", "mean_softmax",
+            "pred_seg_mean")
 
     def __init__(self, models: Sequence, device=None, **predict_kw):
         _lib.require_gpu()

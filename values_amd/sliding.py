@@ -20,10 +20,15 @@ from .uncertainty import uncertainty_maps
 @torch.no_grad()
 def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int = 64, patch_overlap: float = 1,
                           n_pred: int = 1, tta: bool = False, patch_batch: int = 8, compat: bool = True,
-                          seeds=None, noise_fn=None) -> Dict[str, torch.Tensor]:
+                          seeds=None, noise_fn=None, n_aleatoric_samples: int = 10, ssn: bool = False,
+                          **predict_kw) -> Dict[str, torch.Tensor]:
     """image: (X, Y, Z) float tensor (the preprocessed .npy of load_image).  Returns device tensors:
     softmax_sum (T, C, X,Y,Z), num_predictions (X,Y,Z), pred_entropy / aleatoric_uncertainty / epistemic_uncertainty
-    (X,Y,Z) -- already divided by clip(count,1) like save_data --, mean_softmax (C, X,Y,Z), pred_seg_mean (X,Y,Z) u8."""
+    (X,Y,Z) -- already divided by clip(count,1) like save_data --, mean_softmax (C, X,Y,Z), pred_seg_mean (X,Y,Z) u8.
+    The number of passes T is whatever predict_logits produced for the model kind (n_pred, 16 TTA views, or
+    n_aleatoric_samples for an aleatoric head: test_3D.py:458-469 sets n_pred := n_aleatoric_samples there), times the
+    number of members.  ssn=True swaps the aleatoric / epistemic maps like calculate_uncertainty(ssn=True)
+    (test_3D.py:510-516)."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = image.device if image.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -31,9 +36,8 @@ def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int
     X, Y, Z = img.shape
     crops = crop_indices((X, Y, Z), patch_size, patch_overlap)
     P = patch_size
-    T = (16 if tta else n_pred) * len(models)
     C = models[0].num_classes
-    ssum = torch.zeros((T, C, X, Y, Z), dtype=torch.float32, device=dev)
+    T, ssum = None, None          # allocated once the first batch has shown how many passes a patch gets
     count = torch.zeros((X, Y, Z), dtype=torch.float32, device=dev)
     overlap = int(int(P * patch_overlap) < P)
     for b0 in range(0, len(crops), patch_batch):
@@ -43,20 +47,29 @@ def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int
         if seeds is not None:
             kw["seeds"] = [s + b0 for s in seeds]
         x_noise = noise_fn(x) if (tta and noise_fn is not None) else None
-        logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, **kw)  # (B, T, C, P,P,P)
+        logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise,
+                                n_aleatoric_samples=n_aleatoric_samples, **kw, **predict_kw)  # (B, T, C, P,P,P)
+        if ssum is None:
+            T = int(logits.shape[1])
+            ssum = torch.zeros((T, C, X, Y, Z), dtype=torch.float32, device=dev)
+        if tuple(logits.shape) != (len(batch), T, C, P, P, P):
+            raise _lib.VxError(f"predict_image_sliding: logits {tuple(logits.shape)} != {(len(batch), T, C, P, P, P)}")
+        logits = logits.contiguous()
         crop_t = torch.tensor([[c[0][0], c[1][0], c[2][0]] for c in batch], dtype=torch.int32, device=dev)
         rc = lib.vx_softmax_accumulate(_lib.ptr(logits), len(batch), T, C, P, P, P, _lib.ptr(crop_t), _lib.ptr(ssum),
                                        _lib.ptr(count), X, Y, Z, overlap, _lib.stream_ptr())
         _lib.check(rc, "vx_softmax_accumulate")
-    cl = count.clamp(min=1)
-    if compat:
-        m = uncertainty_maps(ssum.unsqueeze(0), from_logits=False)          # on the un-normalised sums (D10)
-        pe, ee, mi = (m[k][0] / cl for k in ("pred_entropy", "expected_entropy", "mutual_information"))
-    else:
-        m = uncertainty_maps((ssum / cl).unsqueeze(0), from_logits=False)
-        pe, ee, mi = (m[k][0] for k in ("pred_entropy", "expected_entropy", "mutual_information"))
-    # mean over T of softmax/clip(count,1) and its argmax (data_carrier_3D.py:215-217, 254-255); the per-voxel
+    # maps of the un-normalised sums divided by clip(count, 1) afterwards (compat: quirk D10), or of the normalised
+    # sums -- either division happens inside the reduction pass (vx_unc_reduce_ex), no separate tensor arithmetic
+    cnt = count.unsqueeze(0)
+    m = uncertainty_maps(ssum.unsqueeze(0), from_logits=False, want_variance=True,
+                         **({"out_count": cnt} if compat else {"in_count": cnt}))
+    pe, ee, mi = (m[k][0] for k in ("pred_entropy", "expected_entropy", "mutual_information"))
+    # mean over T of softmax / clip(count,1) and its argmax (data_carrier_3D.py:215-217, 254-255); the per-voxel
     # count does not change the argmax
-    mean = m["mean_softmax"][0] / cl if compat else m["mean_softmax"][0]
+    mean = m["mean_softmax"][0]
+    if ssn:
+        ee, mi = mi, ee
     return {"softmax_sum": ssum, "num_predictions": count, "pred_entropy": pe, "aleatoric_uncertainty": ee,
-            "epistemic_uncertainty": mi, "mean_softmax": mean, "pred_seg_mean": m["argmax"][0]}
+            "epistemic_uncertainty": mi, "mean_softmax": mean, "pred_seg_mean": m["argmax"][0],
+            "softmax_variance": m["softmax_variance"][0]}

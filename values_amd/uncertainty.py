@@ -22,7 +22,8 @@ def _dev_tensor(t: torch.Tensor):
     return t.detach().to(dev).contiguous(), dev
 
 
-def alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean=True, want_argmax=True, want_sample_argmax=False):
+def alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean=True, want_argmax=True, want_sample_argmax=False,
+                           want_variance=False):
     out = {
         "pred_entropy": torch.empty((B,) + spatial, dtype=torch.float32, device=dev),
         "expected_entropy": torch.empty((B,) + spatial, dtype=torch.float32, device=dev),
@@ -34,15 +35,20 @@ def alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean=True, want_argmax=T
         out["argmax"] = torch.empty((B,) + spatial, dtype=torch.uint8, device=dev)
     if want_sample_argmax:
         out["sample_argmax"] = torch.empty((B, T) + spatial, dtype=torch.uint8, device=dev)
+    if want_variance:
+        out["softmax_variance"] = torch.empty((B,) + spatial, dtype=torch.float32, device=dev)
     return out
 
 
 def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool = True, want_argmax: bool = True,
-                     want_sample_argmax: bool = False, out: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                     want_sample_argmax: bool = False, out: Dict[str, torch.Tensor] = None, want_variance: bool = False,
+                     in_count: Optional[torch.Tensor] = None, out_count: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """x: (B, T, C, *spatial) probabilities or logits (f32/f64) -> dict of device tensors:
     pred_entropy, expected_entropy, mutual_information (B,*spatial) f32, mean_softmax (B,C,*spatial) f32,
-    argmax (B,*spatial) u8, sample_argmax (B,T,*spatial) u8.  `out`: write into these (contiguous, e.g. the rows of a
-    larger batch's maps from alloc_uncertainty_maps) instead of allocating."""
+    argmax (B,*spatial) u8, sample_argmax (B,T,*spatial) u8, softmax_variance (B,*spatial) f32 (want_variance: the
+    north star's fourth map, same pass).  `out`: write into these (contiguous, e.g. the rows of a larger batch's maps
+    from alloc_uncertainty_maps) instead of allocating.  in_count / out_count (B,*spatial) f32: divide the inputs / the
+    maps by max(count, 1) inside the pass (sliding-window sums; vx_unc_reduce_ex)."""
     lib = _lib.load()
     xd, dev = _dev_tensor(x)
     B, T, Cc = xd.shape[:3]
@@ -59,16 +65,28 @@ def uncertainty_maps(x: torch.Tensor, from_logits: bool = False, want_mean: bool
         _lib.check(lib.vx_softmax_planar(_lib.ptr(xd), B * T, Cc, nvox, _lib.ptr(probs), _lib.stream_ptr()), "vx_softmax_planar")
         xd, from_logits = probs, False
     if out is None:
-        out = alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean, want_argmax, want_sample_argmax)
+        out = alloc_uncertainty_maps(B, T, Cc, spatial, dev, want_mean, want_argmax, want_sample_argmax, want_variance)
     else:
         for k, t in out.items():
             if not t.is_contiguous() or t.shape[0] != B or t.device != dev:
                 raise ValueError(f"uncertainty_maps: out[{k!r}] must be a contiguous device tensor with {B} rows")
-    rc = lib.vx_unc_reduce(_lib.ptr(xd), _lib.VX_F64 if xd.dtype == torch.float64 else _lib.VX_F32, int(from_logits),
-                           B, T, Cc, nvox, _lib.ptr(out.get("mean_softmax")), _lib.ptr(out["pred_entropy"]),
-                           _lib.ptr(out["expected_entropy"]), _lib.ptr(out["mutual_information"]),
-                           _lib.ptr(out.get("argmax")), _lib.ptr(out.get("sample_argmax")), _lib.stream_ptr())
-    _lib.check(rc, "vx_unc_reduce")
+    o = _lib.UncOutputs()
+    o.mean_prob, o.pred_entropy = _lib.ptr(out.get("mean_softmax")), _lib.ptr(out["pred_entropy"])
+    o.exp_entropy, o.mutual_info = _lib.ptr(out["expected_entropy"]), _lib.ptr(out["mutual_information"])
+    o.variance = _lib.ptr(out.get("softmax_variance"))
+    o.argmax, o.sample_argmax = _lib.ptr(out.get("argmax")), _lib.ptr(out.get("sample_argmax"))
+    counts = []
+    for cnt in (in_count, out_count):
+        if cnt is not None:
+            cnt = cnt.to(dev, torch.float32).contiguous()
+            if cnt.numel() != B * nvox:
+                raise ValueError("uncertainty_maps: a count map must have B * prod(spatial) elements")
+        counts.append(cnt)
+    o.in_count, o.out_count = _lib.ptr(counts[0]), _lib.ptr(counts[1])
+    import ctypes as C
+    rc = lib.vx_unc_reduce_ex(_lib.ptr(xd), _lib.VX_F64 if xd.dtype == torch.float64 else _lib.VX_F32, int(from_logits),
+                              B, T, Cc, nvox, C.byref(o), _lib.stream_ptr())
+    _lib.check(rc, "vx_unc_reduce_ex")
     return out
 
 

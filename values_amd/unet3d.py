@@ -115,6 +115,7 @@ class UNet3D(nn.Module):
             keep += [packed, b, wt]
             w.conv_w[i] = packed.data_ptr()
             w.conv_b[i] = b.data_ptr()
+            w.conv_family[i] = 0 if i == 0 else lib.vx_conv3d_k3_family(cin, cout)
         for i, name in enumerate(UP_ORDER):
             wt, b = sd[name + ".weight"], sd[name + ".bias"]
             cin, cout = wt.shape[0], wt.shape[1]

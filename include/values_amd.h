@@ -51,6 +51,13 @@ enum { VX_DROP_NONE = 0, VX_DROP_HASH = 1, VX_DROP_MASK = 2 };
 int vx_version(void);
 const char* vx_last_error_string(void);
 
+/* The keep-bits of VX_DROP_HASH as an explicit VX_DROP_MASK mask: mask[n][e] (uint8 0/1) for sample n, channels-last
+ * element e = voxel * C + c of dropout layer `layer` (index in DROPOUT order: contr_1_1 .. contr_4_2, center,
+ * expand_4_1 .. expand_1_2) under `seed`.  A hash-dropout run can be replayed with explicit masks -- the parity tests
+ * hand them to the float64 restatement of unet3D_module.py, so the production bit generator's kernels are what is
+ * compared. */
+int vx_drop_hash_mask(uint32_t seed, uint32_t layer, int N, int64_t elems_per_sample, uint8_t* mask, vx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Library configuration: which kernel family runs a layer (and with it the PACKED WEIGHT LAYOUT) plus tuning knobs.
  * Read ONCE from the environment on first use (variable VX_<FIELD NAME IN CAPITALS>, e.g. VX_CONV_FP32=1), never per

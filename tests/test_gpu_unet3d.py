@@ -461,3 +461,110 @@ def test_host_pipeline_returns_every_step_in_order():
         for k in HostPipeline.KEYS:
             assert np.array_equal(got[s][k], ref[k].cpu().numpy()), (s, k)
     assert hp.flush() == []
+
+
+def _oracle_maps(sd, x, masks_per_pass):
+    """float64 restatement of predict_cases + calculate_uncertainty for one volume: logits (T, C, ...) and the maps"""
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
+    logits = []
+    with torch.no_grad():
+        for mk in masks_per_pass:
+            logits.append(unet3d_forward(sd, x, masks=None if mk is None else dict(zip(DROPOUT_ORDER, mk)))[0].numpy())
+    logits = np.stack(logits)
+    return logits, uo.calculate_uncertainty(uo.softmax(logits, axis=1))
+
+
+def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
+    """BASELINE config C2's shape through the kernels the bench times: ONE 64^3 volume, T = 2 MC-dropout samples on
+    the production path (hash dropout -> the large-tile double-buffered instances with compile-time epilogues
+    <8,1,16,8,4,8,1,{2,3},{0,1,2}>, head fused into expand_1_2, shared first layer + fan-out).  The bit generator's
+    masks are exported (vx_drop_hash_mask) and handed to the float64 oracle, so logits and maps compare at the north
+    star's tolerance.  Then the same volume with dropout off."""
+    from values_amd import predict_uncertainty
+    S, T, seed = 64, 2, 4242
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(formula_volume((1, 1, S, S, S), tag=71))
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, T, S, S, S)]
+    keep = float(np.mean([m.float().mean().item() for m in masks]))
+    assert 0.49 < keep < 0.51, keep
+    sd = formula_sd_torch()
+    logits, ref = _oracle_maps(sd, x, [[m[t:t + 1] for m in masks] for t in range(T)])
+    got = out["logits"][0].cpu().numpy()
+    assert np.abs(got - logits).max() < LOGIT_TOL, np.abs(got - logits).max()
+    for k in KEYS:
+        err = np.abs(out[k][0].cpu().numpy() - ref[k]).max()
+        assert err < MAP_TOL, (k, err)
+    # replaying the exported masks through VX_DROP_MASK (run-time epilogue instances) gives the same logits
+    rep = predict_uncertainty([model], x.float().cuda(), n_pred=T, dropout_masks=[masks])
+    assert (rep["logits"] - out["logits"]).abs().max().item() < 2e-5
+    # dropout off: the plain-epilogue instances, EPI = 0 / run-time activation
+    det = make_model(do_dropout=False)
+    with torch.no_grad():
+        y = det(x.float().cuda())
+    l0, _ = _oracle_maps(sd, x, [None])
+    assert np.abs(y[0].cpu().numpy() - l0[0]).max() < LOGIT_TOL
+
+
+def test_config_C3_full_size_five_members_64_vs_oracle():
+    """BASELINE config C3 as worded: a 5-member deep ensemble on 64^3 volumes (n_pred = 1, no dropout).  One volume
+    against the float64 oracle (5 passes), a second one for the batch path; the member-sharded statistics path
+    (what 8 ranks run, here dealt over 8 emulated ranks and summed) against the one-pass reduction."""
+    from values_amd import _lib, predict_logits, predict_uncertainty
+    from values_amd.dist import ensemble_uncertainty_sharded, ensemble_work_items, finalize_stats
+    S, M = 64, 5
+    models = [make_model(seed_tag=s, do_dropout=False) for s in range(M)]
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1, S, S, S), tag=81 + i) for i in range(2)], 0))
+    out = predict_uncertainty(models, x.float().cuda(), n_pred=1)
+    assert out["logits"].shape == (2, M, 2, S, S, S)
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import unet3d_forward
+    with torch.no_grad():
+        lg = np.stack([unet3d_forward(formula_sd_torch(seed_tag=s), x[:1])[0].numpy() for s in range(M)])
+    assert np.abs(out["logits"][0].cpu().numpy() - lg).max() < LOGIT_TOL
+    ref = uo.calculate_uncertainty(uo.softmax(lg, axis=1))
+    for k in KEYS:
+        err = np.abs(out[k][0].cpu().numpy() - ref[k]).max()
+        assert err < MAP_TOL, (k, err)
+    sh = ensemble_uncertainty_sharded(models, x.float().cuda(), world=1, rank=0, n_pred=1)
+    for k in KEYS + ("mean_softmax",):
+        assert (sh[k] - out[k]).abs().max().item() < 2e-6, k
+    # 8 ranks: (member, volume block) items dealt round robin, each rank's statistics summed as dist.reduce does
+    lib = _lib.load()
+    xd = x.float().cuda()
+    total = torch.zeros((2, 3, S, S, S), device="cuda")
+    items = ensemble_work_items(M, 2, 8)
+    assert sum(len(it) for it in items) == 10 and all(len(it) >= 1 for it in items)
+    for rank in range(8):
+        st = torch.zeros_like(total)
+        for (m, lo, hi) in items[rank]:
+            l1 = predict_logits([models[m]], xd[lo:hi], n_pred=1).contiguous()
+            _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(l1), hi - lo, 1, 2, S ** 3, _lib.ptr(st[lo:hi]),
+                                                   _lib.stream_ptr()), "acc")
+        total += st
+    eight = finalize_stats(total, M)
+    for k in KEYS:
+        assert (eight[k] - out[k]).abs().max().item() < 2e-6, k
+        assert np.abs(eight[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
+
+
+def test_variance_rides_in_the_reduction_pass():
+    """north_star's fourth map: predict_uncertainty returns softmax_variance from the same pass over the logits
+    (vx_unc_reduce_ex).  No reference counterpart -> checked against numpy in float64 and against the
+    stand-alone kernel."""
+    from values_amd import predict_uncertainty, softmax_variance
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1, 16, 16, 16), tag=90 + i) for i in range(3)], 0)).float().cuda()
+    out = predict_uncertainty([model], x, n_pred=6, seeds=[3])
+    p = torch.softmax(out["logits"].double(), 2).cpu().numpy()          # (V, T, C, ...)
+    want = p.var(axis=1).mean(axis=1)
+    got = out["softmax_variance"].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-7, np.abs(got - want).max()
+    alone = softmax_variance(out["logits"], from_logits=True).cpu().numpy()
+    assert np.abs(alone - want).max() < 1e-6
+    assert got.min() >= 0
+    # where the samples agree to 1e-4 the shifted accumulation keeps the relative error small
+    small = want < 1e-8
+    if small.any():
+        assert np.abs(got[small] - want[small]).max() < 1e-10

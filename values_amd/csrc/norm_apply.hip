@@ -258,3 +258,33 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
   VX_CHECK_LAUNCH("vx_norm_act_drop_pool");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The keep-bits VX_DROP_HASH uses, written out as a VX_DROP_MASK-style mask: mask[n][e] = bit of element e of sample n
+// of dropout layer `layer` under `seed` (e = channels-last linear index, voxel * C + c -- what every kernel hashes).
+// Lets a caller replay a hash-dropout run with explicit masks (parity tests feed them to the float64 oracle).
+__global__ __launch_bounds__(256) void drop_hash_mask_kernel(uint32_t seed, uint32_t layer, int N, int64_t per,
+                                                             uint8_t* __restrict__ out) {
+  const int64_t groups = per / 4;
+  const int64_t total = (int64_t)N * groups;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / groups, g = i - n * groups;
+    const uint32_t bits = vx_drop_bits4(vx_drop_key(seed, layer, (uint32_t)n), (uint32_t)(4 * g));
+    const uint32_t v = (bits & 1u) | ((bits >> 1 & 1u) << 8) | ((bits >> 2 & 1u) << 16) | ((bits >> 3 & 1u) << 24);
+    *reinterpret_cast<uint32_t*>(out + n * per + 4 * g) = v;
+  }
+}
+
+extern "C" int vx_drop_hash_mask(uint32_t seed, uint32_t layer, int N, int64_t elems_per_sample, uint8_t* mask,
+                                 vx_stream_t stream) {
+  if (N <= 0 || elems_per_sample <= 0 || elems_per_sample % 4 || elems_per_sample >= (1ll << 32))
+    VX_FAIL(VX_E_SHAPE, "vx_drop_hash_mask: N=%d, %lld elements per sample (a positive multiple of 4 below 2^32)", N,
+            (long long)elems_per_sample);
+  if (!mask || (((uintptr_t)mask) & 3u)) VX_FAIL(VX_E_ALIGN, "vx_drop_hash_mask: mask must be a 4-byte aligned device pointer");
+  const int64_t total = (int64_t)N * (elems_per_sample / 4);
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  hipLaunchKernelGGL(drop_hash_mask_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, seed, layer, N, elems_per_sample, mask);
+  VX_CHECK_LAUNCH("vx_drop_hash_mask");
+  return VX_OK;
+}

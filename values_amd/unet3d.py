@@ -155,6 +155,28 @@ class UNet3D(nn.Module):
         off = (-ws.data_ptr()) % 256
         return ws, off, ws.numel() - 256
 
+    def dropout_layer_shapes(self, D, H, W):
+        """[(channels, (d, h, w))] of the 17 dropout layers in DROPOUT_ORDER for a (D, H, W) input."""
+        f = self.initial_filter_size
+        enc = [(f << l, (D >> l, H >> l, W >> l)) for l in range(4) for _ in range(2)]
+        dec = [(f << l, (D >> l, H >> l, W >> l)) for l in (3, 2, 1, 0) for _ in range(2)]
+        return enc + [(8 * f, (D >> 3, H >> 3, W >> 3))] + dec
+
+    def hash_dropout_masks(self, seed: int, N: int, D: int, H: int, W: int, device=None):
+        """The keep-masks the hash bit generator applies to an N-sample forward launched with `seed`
+        (vx_drop_hash_mask), as 17 bool tensors (N, C, d, h, w) in DROPOUT_ORDER: feeding them back through
+        `dropout_masks=` -- or to a float64 restatement of the network -- replays that forward's dropout exactly."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        out = []
+        for layer, (c, (d, h, w)) in enumerate(self.dropout_layer_shapes(D, H, W)):
+            m = torch.empty((N, d, h, w, c), dtype=torch.uint8, device=dev)
+            _lib.check(lib.vx_drop_hash_mask(int(seed) & 0xFFFFFFFF, layer, N, d * h * w * c, _lib.ptr(m),
+                                             _lib.stream_ptr()), "vx_drop_hash_mask")
+            out.append(m.permute(0, 4, 1, 2, 3).bool())
+        return out
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, enable_concat: bool = True, last_layer: bool = True, *,
                 n_samples: int = 1, src: Optional[torch.Tensor] = None, flip: Optional[torch.Tensor] = None,

@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: uncertainty-volumes/sec at 64^3, T=10 MC-dropout (BASELINE.json config C2).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 with WORLD_SIZE unset: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one batch of V synthetic 64^3 1-channel volumes per GPU through the whole hot path:
-T=10 MC-dropout forwards of UNet3D (batched on device as V*T samples, hash dropout, fp32 exact-MFMA
-convs) -> logits in their pred_idx slots -> fused softmax/entropy/MI/argmax reduction -> (N>1) RCCL gather
-of the per-volume maps to rank 0.  Inputs are resident in HBM before the timed region.  Volumes are
-sharded over ranks (weak scaling: V per GPU fixed), no collective on the data path except that gather.
+T=10 MC-dropout forwards of UNet3D (batched on device as V*T samples, hash dropout, float32 tensors, the 3x3x3
+products evaluated fp32-accurately on the f16 matrix cores by operand splitting) -> logits in their pred_idx slots ->
+fused softmax / entropy / MI / variance / argmax reduction -> (N>1) RCCL gather of the per-volume maps to rank 0.
+Inputs are resident in HBM before the timed region.  Volumes are sharded over ranks (weak scaling: V per GPU fixed),
+no collective on the data path except that gather.
 
-Rank 0 prints ONE JSON line; it carries `roofline` (dominant kernel, live HIP-event timing, algorithmic
-FLOPs) and, at N=1, `cpu_baseline` (the oracle = PyTorch-CPU restatement of test_3D.py's float64 loop, timed
-on this host on a bounded sample).
+--config C3: the 5-member deep ensemble of BASELINE config 3, (member, volume block) items dealt over the ranks, one
+RCCL sum-reduce of sufficient statistics per step (values_amd.dist.ensemble_uncertainty_sharded).
+--config C4: HRNet-W18 at 1024x512, 8 TTA views per image (BASELINE config 4), images sharded over the ranks.
+
+Rank 0 prints ONE JSON line; it carries `roofline` (dominant kernel, live HIP-event timing, algorithmic FLOPs and
+bytes, the binding roof named by max(flops / peak, bytes / bandwidth)) and, at N=1, `cpu_baseline` (the oracle =
+PyTorch-CPU restatement of test_3D.py's float64 loop, timed on this host on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak F
 # (same table: F16/BF16 ~2.5 PF dense = 16 x 157.3), so the matrix roof of fp32-EQUIVALENT work is 16/3 x 157.3
 PEAK_SPLIT16_TFLOPS = round(157.3 * 16 / 3, 1)
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
+
+
+def source_sha():
+    """sha256 over the kernel sources: ties a PMC traffic record (profiles/traffic.json) to the build it was taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "values_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def layer_table(F=8, S=64):
@@ -54,52 +73,6 @@ def layer_table(F=8, S=64):
     return t
 
 
-def kernel_name(kind, ci, co, edge, label=""):
-    if kind == "conv":
-        if ci == 1:
-            return f"conv3d_k3_c1_kernel<{co}>"
-        fp32 = int(os.environ.get("VX_CONV_FP32", "0") or 0)
-        if fp32 == 0 or (fp32 == 2 and co != 8):
-            # conv3d_s16.hip (default): <CB, NT, TX, TY, TZ, NW, XP, DB, EPI>, split-fp16 products on v_mfma_f32_16x16x32_f16;
-            # Cout = 8 layers: x-pair packing (XP = 1) in chunks of 8 channels, a column is a voxel pair
-            xp = 1 if co == 8 else 0
-            cb = 8 if xp else (16 if ci % 16 == 0 else 8)
-            nt = 2 if co % 32 == 0 else 1
-            ex = edge // 2 if xp else edge
-            if ex >= 16:   # vx_conv3d_s16_tile: large layers (H >= 32) take 16 x 8 x 4 tiles
-                tile, nw = ("16,8,4" if (edge >= 32 and nt == 1) else "16,4,4"), 8
-            else:
-                tile, nw = ("8,8,4", 8) if ex >= 8 else ("4,4,4", 4)
-            # DB = 2: x-pair layers on the large tile run the double-buffered, staggered variant
-            db = 0
-            if xp and tile == "16,8,4" and not os.environ.get("VX_S16_NO_DB"):
-                db = 2 if ci == cb else (3 if ci == 2 * cb else 0)   # 3: the same for two chunks per tile (16 -> 8)
-            # EPI: compile-time epilogue of the large-tile instances -- 0 plain (encoder: an InstanceNorm follows),
-            # 1 LeakyReLU + hash dropout (decoder), 2 = 1 + fused 1x1x1 head (expand_1_2), 3 run-time (all others)
-            epi = 3
-            if tile == "16,8,4" and nt == 1 and not os.environ.get("VX_S16_NO_EPI"):
-                epi = 0 if label.startswith("contr") else 1
-                if label == "expand_1_2" and not os.environ.get("VX_NO_HEAD_FUSION"):
-                    epi = 2
-            return f"conv3d_k3_s16_kernel<{cb},{nt},{tile},{nw},{xp},{db},{epi}>"
-        if co == 8 and ci in (8, 16):
-            # conv3d_c8.hip: <chunks of 8 input channels, tile x, y, z> (v_mfma_f32_4x4x1 kernel for Cout = 8)
-            tile = "32,4,4" if edge >= 32 else ("16,8,4" if edge >= 16 else "8,4,4")
-            return f"conv3d_k3_c8_kernel<{ci // 8},{tile}>"
-        # template instance = <CB, NT, TX, TY, TZ, NW, XP> as conv_config()/tile_config() choose it (conv3d_mfma.hip)
-        nt = 2 if co % 32 == 0 else 1
-        xp = 1 if co == 8 else 0
-        cb = 8 if xp else (16 if ci % 16 == 0 else 8)
-        ex = edge // 2 if xp else edge  # x-pair: a column is a voxel pair
-        tile, nw = ("16,4,4", 8) if ex >= 16 else (("8,8,4", 8) if ex >= 8 else ("4,4,4", 4))
-        return f"conv3d_k3_mfma_kernel<{cb},{nt},{tile},{nw},{xp}>"
-    if kind == "convT":
-        return "convT_k2s2_mfma_kernel" if ci in (16, 32, 64, 128) else "convT_k2s2_kernel"
-    if kind == "conv1x1":
-        return f"conv1x1_ncdhw_kernel<{ci}>"
-    return kind
-
-
 def launch_cost(kind, ci, co, edge, N):
     """(algorithmic FLOPs, algorithmic bytes) of one launch over N samples."""
     vox = edge ** 3
@@ -113,7 +86,8 @@ def launch_cost(kind, ci, co, edge, N):
 
 
 def profiled_forward(model, x, n_samples, seed):
-    """Per-launch milliseconds of one eager forward (HIP events on the launch stream, inside the library)."""
+    """Per-launch (label, kernel name, milliseconds) of one eager forward (HIP events on the launch stream, inside the
+    library; the kernel name is the template instance the launch dispatched to, as rocprofv3 prints it)."""
     import torch
     from values_amd import _lib
     lib = _lib.load()
@@ -135,15 +109,20 @@ def profiled_forward(model, x, n_samples, seed):
     n = C.c_int(0)
     _lib.check(lib.vx_unet3d_forward_profiled(C.byref(w), C.byref(run), _lib.stream_ptr(), 96, ms, labels, C.byref(n)),
                "vx_unet3d_forward_profiled")
-    return [(labels[i].decode(), float(ms[i])) for i in range(n.value)]
+    rows = []
+    for i in range(n.value):
+        lab = labels[i].decode()
+        name = lab.split("|", 1)[1] if "|" in lab else None
+        rows.append((lab.split("|", 1)[0], name, float(ms[i])))
+    return rows
 
 
 def roofline_leg(model, x, T, reps=3):
-    """Per-launch HIP-event times of the forwards one step launches: the SAME volume chunks the timed path runs
-    (values_amd.predict splits a batch into chunks on two streams), one after the other on this stream -- so the
-    average launch duration is the one a rocprofv3 trace of this command shows for the kernel."""
+    """Per-launch HIP-event times of the forwards one step launches: the SAME volume chunks the timed path runs, one
+    after the other on this stream -- so the average launch duration is the one a rocprofv3 trace of this command shows
+    for the kernel.  The binding roof of the dominant kernel is the larger of flops / matrix peak and bytes / HBM peak."""
     from values_amd.predict import _volume_chunks
-    tab = layer_table()
+    tab = layer_table(S=x.shape[-1])
     V = x.shape[0]
     N = V * T
     chunks, _ = _volume_chunks(V, None, False, T)
@@ -155,40 +134,56 @@ def roofline_leg(model, x, T, reps=3):
             if rep == 0:
                 continue  # warm-up
             Vc = v1 - v0
-            for label, ms in rows:
+            for label, kname, ms in rows:
                 per_label.setdefault(label, []).append(ms)
-                if label in tab:
-                    kind, ci, co, edge = tab[label]
-                    name = kernel_name(kind, ci, co, edge, label)
-                    # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
-                    fl, by = launch_cost(kind, ci, co, edge, Vc if label == "contr_1_1" else Vc * T)
-                else:
-                    name, fl, by = label.split(":")[0], 0.0, 0.0
+                fl, by = 0.0, 0.0
+                for part in label.split("+"):          # a fused launch carries every layer it computes
+                    if part in tab:
+                        kind, ci, co, edge = tab[part]
+                        # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
+                        f1, b1 = launch_cost(kind, ci, co, edge, Vc if part == "contr_1_1" else Vc * T)
+                        fl += f1
+                        by += b1
+                name = kname or label.split(":")[0]
                 a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
                 a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
     per_label = {k: [sum(v) / reps] for k, v in per_label.items()}     # per step: the chunks' launches summed
     total_ms = sum(a["ms"] for a in acc.values()) / reps
-    dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
-    name, a = dom
-    tflops = a["flops"] / (a["ms"] * 1e-3) / 1e12
-    split = name.startswith("conv3d_k3_s16")
-    peak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-    roof = {"bound": "mfma", "kernel": name, "achieved": round(tflops, 3), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+    name, a = max(acc.items(), key=lambda kv: kv[1]["ms"])
+    sec = a["ms"] * 1e-3
+    tflops = a["flops"] / sec / 1e12
+    gbs = a["bytes"] / sec / 1e9
+    split = "s16" in name
+    mpeak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    t_mfma = a["flops"] / (mpeak * 1e12)
+    t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    roof = {"bound": bound, "kernel": name,
+            "achieved": round(tflops if bound == "mfma" else gbs, 3), "peak": mpeak if bound == "mfma" else PEAK_HBM_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round((tflops / mpeak) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
+            "frac_mfma": round(tflops / mpeak, 4), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+            "achieved_tflops": round(tflops, 3), "achieved_GBps": round(gbs, 1),
+            "mfma_peak_tflops": mpeak, "hbm_peak_GBps": PEAK_HBM_GBS,
             "frac_of_fp32_matrix_peak": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-            "peak_note": ("fp32-equivalent matrix roof of the split-fp16 scheme: f16 dense peak (16 x 157.3 TF) / 3 "
-                          "products per fp32 product; the native-fp32 matrix peak is 157.3 TF") if split else
-                         "fp32 matrix peak, dense",
+            "peak_note": ("matrix roof = fp32-equivalent rate of the split-fp16 scheme: f16 dense peak (16 x 157.3 TF) / 3 "
+                          "products per fp32 product; HBM roof = 8 TB/s spec; bound = the roof that takes longer for this "
+                          "kernel's algorithmic flops and bytes") if split else "fp32 matrix peak, dense; HBM 8 TB/s spec",
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_step": a["launches"] // reps,
             "samples_per_launch": round(N / len(chunks), 1),
             "share_of_forward": round(a["ms"] / reps / total_ms, 3), "traffic": None}
+    # HBM-side bytes per launch from the PMC counters: only a record taken on THIS build counts (tools/pmc_traffic.py
+    # writes profiles/traffic.json with the source hash); otherwise null
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            roof["traffic"] = json.load(open(tpath)).get(name)
+            rec = json.load(open(tpath))
+            if rec.get("src_sha") == source_sha():
+                roof["traffic"] = rec.get("kernels", {}).get(name)
         except Exception:
             pass
     detail = {"forward_ms_sum_of_launches": round(total_ms, 3), "samples": N,
+              "launches_per_forward": sum(v["launches"] for v in acc.values()) // reps // len(chunks),
               "kernels": {k: {"ms_per_step": round(v["ms"] / reps, 4), "launches": v["launches"] // reps,
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["flops"] else None,
                               "alg_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
@@ -197,10 +192,11 @@ def roofline_leg(model, x, T, reps=3):
     return roof, detail
 
 
-def cpu_baseline_leg(T=10, passes=2):
-    """The oracle (kind 'port': PyTorch-CPU restatement of test_3D.py:417-482, float64, autograd on, as the
-    reference runs it) on a bounded sample: `passes` of the T forwards of one 64^3 volume + the full T-sample
-    calculate_uncertainty restatement; extrapolated to volumes/s."""
+def cpu_baseline_leg(T=10, budget_s=25.0):
+    """The oracle (kind 'port': PyTorch-CPU restatement of test_3D.py:417-482) on a bounded sample of the same
+    workload: the T float64 autograd-on forwards of one 64^3 volume as the reference runs them (fewer, stated, if they
+    would not fit the time budget) + the T-sample calculate_uncertainty restatement -> volumes/s; and the same loop in
+    float32 without autograd (the "fair" CPU number of SURVEY 8d) next to it."""
     import numpy as np
     import torch
     from oracle import uncertainty_oracle as uo
@@ -228,22 +224,81 @@ def cpu_baseline_leg(T=10, passes=2):
     x = torch.randn((1, 1, 64, 64, 64), generator=g, dtype=torch.float64)
     shapes = [(8, 64), (8, 64), (16, 32), (16, 32), (32, 16), (32, 16), (64, 8), (64, 8), (64, 8), (64, 8), (64, 8),
               (32, 16), (32, 16), (16, 32), (16, 32), (8, 64), (8, 64)]
-    t0 = time.perf_counter()
-    sm = None
-    for _ in range(passes):
-        masks = {n: torch.rand((1, c, s, s, s), generator=g) > 0.5 for n, (c, s) in zip(DROPOUT_ORDER, shapes)}
-        logits = unet3d_forward(sd, x, masks=masks)
-        sm = torch.softmax(logits, 1).detach().numpy()
-    t_pass = (time.perf_counter() - t0) / passes
-    stack = np.repeat(sm, T, axis=0)  # (T,2,64,64,64) float64 buffer like concat_data's
+
+    def passes(sdx, xx, n, grad):
+        t0 = time.perf_counter()
+        sms = []
+        done = 0
+        for _ in range(n):
+            masks = {nm: torch.rand((1, c, s, s, s), generator=g) > 0.5 for nm, (c, s) in zip(DROPOUT_ORDER, shapes)}
+            with torch.set_grad_enabled(grad):
+                logits = unet3d_forward(sdx, xx, masks=masks)
+            sms.append(torch.softmax(logits, 1).detach().numpy()[0])
+            done += 1
+            if time.perf_counter() - t0 > budget_s * 0.6 and done >= 2:
+                break
+        return (time.perf_counter() - t0) / done, done, sms
+
+    t_pass, n64, sms = passes(sd, x, T, True)
+    stack = np.stack((sms * T)[:T])                       # (T,2,64,64,64) float64 buffer like concat_data's
     t0 = time.perf_counter()
     uo.calculate_uncertainty(stack)
     t_red = time.perf_counter() - t0
     vps = 1.0 / (T * t_pass + t_red)
+    sd32 = {k: v.detach().float() for k, v in sd.items()}
+    t32, n32, sms32 = passes(sd32, x.float(), T, False)
+    t0 = time.perf_counter()
+    uo.calculate_uncertainty(np.stack((sms32 * T)[:T]))
+    t_red32 = time.perf_counter() - t0
     return {"value": round(vps, 5), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} of the {T} float64 MC-dropout forwards of one 64^3 volume ({t_pass:.2f} s/pass) + "
-                      f"one T={T} entropy/MI reduction ({t_red:.2f} s), extrapolated to a whole volume; "
-                      f"torch {torch.__version__} CPU, {cores} of {ncpu} host threads (fastest of {cand} on a 32^3 pass)"}
+            "sample": f"{n64} of the {T} float64 autograd-on MC-dropout forwards of one 64^3 volume ({t_pass:.2f} s/pass"
+                      f"{'' if n64 == T else ', extrapolated to ' + str(T)}) + one T={T} entropy/MI reduction ({t_red:.2f} s); "
+                      f"torch {torch.__version__} CPU, {cores} of {ncpu} host threads (fastest of {cand} on a 32^3 pass)",
+            "fair_float32_nograd": {"value": round(1.0 / (T * t32 + t_red32), 5), "unit": "volumes/s",
+                                    "sample": f"{n32} float32 no-grad passes ({t32:.3f} s/pass) + reduction ({t_red32:.2f} s)"}}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` BEFORE this
+    process touches a GPU (a parent that has initialised HIP must never re-exec, and need not: it only waits)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def timed_regions(step, flush, barrier, steps, warmup, repeats, reduce_max):
+    """W untimed steps, then `repeats` regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both
+    sides; per region the max over ranks.  Returns the list of region times (seconds)."""
+    k = 0
+    for _ in range(warmup):
+        step(k)
+        k += 1
+    flush()
+    barrier()
+    times = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(k)
+            k += 1
+        flush()
+        barrier()
+        times.append(reduce_max(time.perf_counter() - t0))
+    return times
 
 
 def main():
@@ -251,19 +306,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--volumes", type=int, default=32, help="64^3 volumes per GPU per step")
+    ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4"))
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
+    ap.add_argument("--volumes", type=int, default=None, help="units per GPU per step (C2: 32 volumes, C3: 16, C4: 2 images)")
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
     ap.add_argument("--detail", type=str, default=None, help="write the per-kernel breakdown JSON here")
     args = ap.parse_args()
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+              "(or without a launcher: bench.py starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -273,13 +339,54 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(3)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(dt):
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    if args.config == "C2":
+        line = run_c2(args, world, rank, dev, barrier, reduce_max)
+    elif args.config == "C3":
+        line = run_c3(args, world, rank, dev, barrier, reduce_max)
+    else:
+        line = run_c4(args, world, rank, dev, barrier, reduce_max)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        line["ranks_joined"] = dist.get_world_size() if world > 1 else 1
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def summarise(times, units_per_region, steps):
+    med = statistics.median(times)
+    return {"value": round(units_per_region / med, 3), "ms_per_step": round(med / steps * 1e3, 3),
+            "repeats": {"regions": len(times), "steps_per_region": steps,
+                        "value_median": round(units_per_region / med, 3),
+                        "value_min": round(units_per_region / max(times), 3),
+                        "value_max": round(units_per_region / min(times), 3),
+                        "value_first_region": round(units_per_region / times[0], 3)}}
+
+
+def run_c2(args, world, rank, dev, barrier, reduce_max):
+    import torch
     from values_amd import UNet3D, predict_uncertainty
     from values_amd.dist import MapGatherPipeline
 
     torch.manual_seed(123)  # reference seed (configs/dropout_config.yaml:8); default torch init = random weights
     model = UNet3D(num_classes=2, do_dropout=True).to(dev)
-    V, T, S = args.volumes, args.T, args.size
+    V, T, S = args.volumes or 32, args.T, args.size
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((V, 1, S, S, S), generator=g).to(dev)  # z-scored synthetic volumes, resident in HBM
 
@@ -291,29 +398,11 @@ def main():
         out = predict_uncertainty([model], x, n_pred=T, seeds=[i])
         return pipe.submit(out)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    pipe.flush()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    pipe.flush()
-    barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    times = timed_regions(step, pipe.flush, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
 
     pcie = None
     if args.pcie and world == 1:
-        # host-inclusive variant: volumes start in pinned host memory, the five maps end there; never reported as `value`.
+        # host-inclusive variant: volumes start in pinned host memory, the maps end there; never reported as `value`.
         # values_amd.HostPipeline: upload and download on their own streams, step i's maps travel while step i + 1 computes
         from values_amd import HostPipeline
         xh = x.cpu().pin_memory()
@@ -330,39 +419,138 @@ def main():
         torch.cuda.synchronize()
         dth = time.perf_counter() - t1
         pcie = {"volumes_per_s": round(V * hsteps / dth, 3), "steps": hsteps,
-                "note": "pinned host -> device input, 5 maps device -> pinned host, copies on their own streams "
+                "note": "pinned host -> device input, maps device -> pinned host, copies on their own streams "
                         "(values_amd.HostPipeline), fill and drain of the 3-step pipeline included"}
 
-    roof, detail, cpu = None, None, None
+    roof, detail, cpu, lat = None, None, None, None
     if rank == 0 and not args.no_roofline:
         roof, detail = roofline_leg(model, x, T)
         if args.detail:
             os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
             json.dump(detail, open(args.detail, "w"), indent=1)
+    if rank == 0 and not args.no_latency:
+        lat = latency_leg(model, x[:1], T)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(T)
-    if world > 1:
-        dist.barrier()
-
-    if rank == 0:
-        vols = V * world * args.steps
-        line = {
-            "metric": "uncertainty-volumes/sec (64^3, T=10 MC-dropout)", "value": round(vols / dt, 3),
-            "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+    line = {"metric": "uncertainty-volumes/sec (64^3, T=10 MC-dropout)", "unit": "volumes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2: {S}^3 1-channel volumes, UNet3D(initial_filter_size=8, 2 classes), T={T} "
-                                   "MC-dropout passes + fused softmax/entropy/MI/argmax reduction",
+                                   "MC-dropout passes + fused softmax/entropy/MI/variance/argmax reduction",
                        "volumes_per_gpu_per_step": V, "samples_per_gpu_per_step": V * T,
                        "sharding": f"volumes over {world} rank(s); gather of maps to rank 0" if world > 1 else "single GPU",
                        "dropout": "hash bit generator, new seed every step", "weights": "torch default init, seed 123"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        if pcie is not None:
-            line["pcie_inclusive"] = pcie
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            "roofline": roof, "cpu_baseline": cpu}
+    line.update(summarise(times, V * world * args.steps, args.steps))
+    if lat is not None:
+        line["latency_single_volume"] = lat
+    if detail is not None:
+        line["launches_per_forward"] = detail["launches_per_forward"]
+    if pcie is not None:
+        line["pcie_inclusive"] = pcie
+    return line
+
+
+def latency_leg(model, x1, T, reps=30):
+    """One 64^3 volume, T passes + reduction, alone on the GPU: eager launches vs one captured hipGraph replay."""
+    import torch
+    from values_amd import predict_uncertainty
+    try:
+        from values_amd.predict import GraphedPredictor
+    except ImportError:
+        GraphedPredictor = None
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"volumes": 1, "T": T, "eager_ms": round(timeit(lambda: predict_uncertainty([model], x1, n_pred=T, seeds=[1])), 3)}
+    if GraphedPredictor is not None:
+        gp = GraphedPredictor([model], x1.shape, n_pred=T)
+        k = [0]
+
+        def run():
+            k[0] += 1
+            gp(x1, seed=k[0])
+        out["graph_ms"] = round(timeit(run), 3)
+    return out
+
+
+def run_c3(args, world, rank, dev, barrier, reduce_max):
+    """BASELINE config 3: 64^3, 5-member deep ensemble, members sharded over the ranks (with volume blocks so that every
+    rank has work), one sum-reduce of sufficient statistics to rank 0 per step."""
+    import torch
+    from values_amd import UNet3D
+    from values_amd.dist import ensemble_uncertainty_sharded
+    M, S = 5, args.size
+    Vg = args.volumes or 16
+    V = Vg * world                                    # weak scaling: volumes per step grow with the ranks
+    members = []
+    for m in range(M):
+        torch.manual_seed(123 + m)                    # seeds 123..127 (SURVEY 8d)
+        members.append(UNet3D(num_classes=2, do_dropout=False).to(dev))
+    g = torch.Generator(device="cpu").manual_seed(123)
+    x = torch.randn((V, 1, S, S, S), generator=g).to(dev)      # the same volumes on every rank
+
+    def step(i):
+        return ensemble_uncertainty_sharded(members, x, world, rank, n_pred=1)
+
+    times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    line = {"metric": "uncertainty-volumes/sec (64^3, 5-member deep ensemble)", "unit": "volumes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: {S}^3 volumes, {M}-member deep ensemble (n_pred=1, no dropout), (member, volume "
+                                   "block) items dealt over the ranks, RCCL sum-reduce of sufficient statistics + finalize",
+                       "volumes_per_step": V, "forwards_per_step": V * M,
+                       "sharding": f"{M} members x volume blocks over {world} rank(s)"},
+            "roofline": None, "cpu_baseline": None}
+    line.update(summarise(times, V * args.steps, args.steps))
+    return line
+
+
+def run_c4(args, world, rank, dev, barrier, reduce_max):
+    """BASELINE config 4: HRNet-W18 at 1024x512, 8 TTA views per image ({id, H, V, HV} x {clean, noisy}), images
+    sharded over the ranks.  One step = B images per GPU = 8 B forwards (every view is its own batch, as test_2D.py:299-311
+    runs them: training-mode BatchNorm sees one view at a time)."""
+    import torch
+    from values_amd.formula import hrnet_w18_extra
+    from values_amd.hrnet import HighResolutionNet
+    from values_amd.predict2d import predict_logits_2d, process_output_2d, tta_views_8
+    B = args.volumes or 2
+    H, W, NC = 512, 1024, 19
+    cfg = {"MODEL": {"EXTRA": hrnet_w18_extra(False), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+           "DATASET": {"NUM_CLASSES": NC}}
+    torch.manual_seed(123)
+    model = HighResolutionNet(cfg).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(123 + rank)
+    x = torch.randn((B, 3, H, W), generator=g).to(dev)
+    noisy = (x + 0.05 * torch.randn((B, 3, H, W), generator=g).to(dev))
+    views, hf, vf = tta_views_8(x, noisy)
+
+    def step(i):
+        lg = predict_logits_2d([model], views, tta=True, hflip_views=hf, vflip_views=vf)
+        return process_output_2d(lg)
+
+    times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    roof = None
+    if rank == 0 and not args.no_roofline and hasattr(model, "profile_forward"):
+        roof = model.profile_forward(views[0], peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS)
+    line = {"metric": "uncertainty-images/sec (HRNet-W18, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: HRNet-W18 (training-mode BatchNorm as the reference runs it), {W}x{H}, {NC} classes, "
+                                   "8 TTA views per image + softmax / entropy / MI reduction",
+                       "images_per_gpu_per_step": B, "forwards_per_gpu_per_step": 8,
+                       "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": None}
+    line.update(summarise(times, B * world * args.steps, args.steps))
+    return line
 
 
 if __name__ == "__main__":

@@ -311,7 +311,8 @@ typedef struct vx_affine_args {
 int vx_affine_gather(const vx_affine_args* a, vx_stream_t stream);
 
 /* Final upsample of the class logits to the input size (hrnet_module.py:667-669) into the reference's NCHW layout:
- * image n -> slot dst[n] (nullable) of out [slots][C][OH][OW]; flip[n] & 1 un-flips a HorizontalFlip TTA view. */
+ * image n -> slot dst[n] (nullable) of out [slots][C][OH][OW]; flip[n] bit 0 un-flips a HorizontalFlip TTA view
+ * (test_2D.py:304-309), bit 1 a VerticalFlip one (8-view extension, BASELINE config 4). */
 int vx_bilinear_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
                      const int32_t* dst, const int32_t* flip, vx_stream_t stream);
 

@@ -1,9 +1,9 @@
 """GPU: values_amd.HighResolutionNet (HIP) vs the golden fixture produced by the imported reference class (float32,
 training-mode BatchNorm, DROPOUT_FINAL masks injected) and vs the float64 oracle.
 
-Tolerance: the reference's 2D path is float32 end to end; its own logits differ from a float64 evaluation of the same
-network by up to ~1e-3 (test_hrnet_oracle_matches_reference bounds it).  The HIP path is held to that float64 oracle
-at the same order, and the maps computed from equal logits stay within 1e-4."""
+Tolerance (BASELINE.json north_star): uncertainty maps within 1e-4 abs of the reference; logits within 1e-4 too, or --
+where the reference's own float32 evaluation sits further than that from a float64 evaluation of the same network
+(the deep W18 fixture: 1.3e-4, recorded in the fixture) -- within twice that gap."""
 import json
 
 import numpy as np
@@ -15,6 +15,8 @@ from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
 
 pytestmark = pytest.mark.gpu
 KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
+MAP_TOL = 1e-4
+LOGIT_TOL = 1e-4
 
 
 def small_cfg(dropout_final=True, ncls=4):
@@ -63,8 +65,8 @@ def test_hrnet_golden_no_dropout():
     err_o = np.abs(y.cpu().numpy() - y64).max()
     ref_o = np.abs(g["logits_nodrop"] - y64).max()
     print(f"max|d| hip-vs-reference(f32) {err_ref:.2e}, hip-vs-oracle(f64) {err_o:.2e}, reference(f32)-vs-oracle(f64) {ref_o:.2e}")
-    assert err_o < max(2 * ref_o, 5e-4)
-    assert err_ref < 2e-3
+    assert err_o < max(2 * ref_o, LOGIT_TOL)
+    assert err_ref < LOGIT_TOL
 
 
 def test_hrnet_golden_mc_dropout_final_and_maps():
@@ -75,7 +77,7 @@ def test_hrnet_golden_mc_dropout_final_and_maps():
     lg = m.forward_samples(x, T, dropout_masks=[masks_of(g, t) for t in range(T)])
     assert lg.shape == (T, 2, 4, 64, 96)
     err = np.abs(lg.cpu().numpy() - g["logits"]).max()
-    assert err < 2e-3, err
+    assert err < LOGIT_TOL, err
     # process_output (test_2D.py:205-248): per image, (T, C+1, H, W) softmax with a zero channel -> calculate_uncertainty
     sm = torch.softmax(lg, dim=2)
     sm1 = torch.cat([sm, torch.zeros(T, 2, 1, 64, 96, device="cuda")], dim=2)
@@ -83,7 +85,7 @@ def test_hrnet_golden_mc_dropout_final_and_maps():
         u = uncertainty_maps(sm1[:, b].unsqueeze(0).contiguous())
         for k, kk in zip(KEYS, ("pred_entropy", "expected_entropy", "mutual_information")):
             d = np.abs(u[kk][0].cpu().numpy() - g[f"{k}_{b}"]).max()
-            assert d < 1e-3, (k, d)
+            assert d < MAP_TOL, (k, d)
     # the same maps from the REFERENCE's logits: isolates the reduction (must hold the 1e-4 of the north star)
     smr = torch.softmax(torch.from_numpy(g["logits"]).cuda(), dim=2)
     smr1 = torch.cat([smr, torch.zeros(T, 2, 1, 64, 96, device="cuda")], dim=2)
@@ -127,13 +129,13 @@ def test_predict_2d_driver_mc_and_tta_vs_oracle():
     masks = [masks_of(g, t) for t in range(T)]
     lg = predict_logits_2d([m], x.cuda(), n_pred=T, dropout_masks=[masks])
     assert lg.shape == (2, T, 4, 64, 96)
-    np.testing.assert_allclose(lg.permute(1, 0, 2, 3, 4).cpu().numpy(), g["logits"], atol=2e-3)
+    np.testing.assert_allclose(lg.permute(1, 0, 2, 3, 4).cpu().numpy(), g["logits"], atol=LOGIT_TOL)
     out = process_output_2d(lg)
     for b in range(2):
         for k in KEYS:
-            assert np.abs(out[k][b].cpu().numpy() - g[f"{k}_{b}"]).max() < 1e-3
+            assert np.abs(out[k][b].cpu().numpy() - g[f"{k}_{b}"]).max() < MAP_TOL
     sm_ref = torch.softmax(torch.from_numpy(g["logits"]), 2).permute(1, 0, 2, 3, 4).numpy()
-    assert np.abs(out["softmax_pred"].cpu().numpy() - sm_ref).max() < 1e-3
+    assert np.abs(out["softmax_pred"].cpu().numpy() - sm_ref).max() < MAP_TOL
     # TTA: 4 views (identity, hflip, noisy, hflip+noisy): flip views are un-flipped; dropout off in this model
     m2, _, _ = make(dropout_final=False)
     noise = torch.from_numpy(formula_tensor((2, 3, 64, 96), tag=82, scale=0.1)).float()
@@ -146,7 +148,7 @@ def test_predict_2d_driver_mc_and_tta_vs_oracle():
             y = hrnet_forward(extra, sd64, v.double())
             if fl:
                 y = torch.flip(y, [-1])
-            assert np.abs(lg[:, vi].cpu().numpy() - y.numpy()).max() < 1e-3, vi
+            assert np.abs(lg[:, vi].cpu().numpy() - y.numpy()).max() < LOGIT_TOL, vi
     out = process_output_2d(lg)
     ref = uo.calculate_uncertainty(uo.softmax(lg[0].double().cpu().numpy(), axis=1))
     for k in KEYS:
@@ -219,3 +221,90 @@ def test_hrnet_w18_widths_match_reference_fixture():
         else:
             y = m(x).cpu().numpy()
             assert np.abs(y - g["logits_nodrop"]).max() < 5e-5
+
+
+def _w18_full(ncls=19):
+    from values_amd.formula import hrnet_w18_extra
+    from values_amd.hrnet import HighResolutionNet
+    g = load_npz("hrnet_w18_256x478.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    cfg = {"MODEL": {"EXTRA": hrnet_w18_extra(False), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+           "DATASET": {"NUM_CLASSES": ncls}}
+    m = HighResolutionNet(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    m.load_state_dict(sd, strict=False)
+    return m.cuda(), g
+
+
+def _check_view(y, g, tag, tol):
+    """y (C, H, W) against a fixture view: the stride-(4, 6) sub-grid and the row / column sums over the whole map"""
+    assert np.abs(y[:, ::4, ::6] - g[f"{tag}_sub"]).max() < tol, (tag, np.abs(y[:, ::4, ::6] - g[f"{tag}_sub"]).max())
+    assert np.abs(y.astype(np.float64).sum(2) - g[f"{tag}_rowsum"]).max() < tol * y.shape[2] ** 0.5 * 4, tag
+    assert np.abs(y.astype(np.float64).sum(1) - g[f"{tag}_colsum"]).max() < tol * y.shape[1] ** 0.5 * 4, tag
+
+
+def test_config_C4_w18_full_layout_at_256x478_matches_reference_fixture():
+    """BASELINE config 4's network as worded -- the full HRNet-W18 layout, 19 classes -- at the size of the reference's test
+    images (256 x 478), one image per batch (training-mode BatchNorm over that image, as a TTA forward
+    runs): logits against the imported reference class (float32) and its float64 run, the HorizontalFlip view
+    un-flipped as test_2D.py:304-309 does and the VerticalFlip view of the 8-view extension.  The reference's own
+    float32-vs-float64 gap on this 300-layer net is 1.3e-4 (in the fixture): logits are held to twice that."""
+    from values_amd.predict2d import predict_logits_2d, process_output_2d, tta_views_8
+    m, g = _w18_full()
+    x = torch.from_numpy(formula_tensor((1, 3, 256, 478), tag=int(g["input_tag"]), scale=float(g["input_scale"]))).float().cuda()
+    gap = float(g["ref_f32_f64_gap"])
+    tol = max(LOGIT_TOL, 2 * gap)
+    y = m(x)[0].cpu().numpy()
+    assert y.shape == (19, 256, 478)
+    _check_view(y, g, "logits", tol)
+    _check_view(y, g, "logits64", tol)
+    e32 = np.abs(y[:, ::4, ::6] - g["logits_sub"]).max()
+    e64 = np.abs(y[:, ::4, ::6] - g["logits64_sub"]).max()
+    print(f"W18 256x478: max|d| vs reference f32 {e32:.2e}, vs reference f64 {e64:.2e}; reference f32-vs-f64 {gap:.2e}")
+    assert e64 < 2 * gap                      # no further from float64 than the reference itself (x2)
+    views, hf, vf = tta_views_8(x, x)         # noise-free: the noisy half repeats the clean one
+    lg = predict_logits_2d([m], views, tta=True, hflip_views=hf, vflip_views=vf)
+    assert lg.shape == (1, 8, 19, 256, 478)
+    l8 = lg[0].cpu().numpy()
+    _check_view(l8[0], g, "logits", tol)
+    _check_view(l8[1], g, "logits_hflip", tol)
+    _check_view(l8[2], g, "logits_vflip", tol)
+    assert np.array_equal(l8[:4], l8[4:])
+    # maps of the 4 distinct views against the reduction of the REFERENCE's logits where the fixture has them (sub-grid)
+    from oracle import uncertainty_oracle as uo
+    out = process_output_2d(lg[:, :3].contiguous())
+    ref_l = np.stack([g["logits_sub"], g["logits_hflip_sub"], g["logits_vflip_sub"]]).astype(np.float64)
+    ref = uo.calculate_uncertainty(uo.softmax(ref_l, axis=1))
+    for k in KEYS:
+        d = np.abs(out[k][0].cpu().numpy()[::4, ::6] - ref[k]).max()
+        assert d < MAP_TOL, (k, d)
+
+
+def test_config_C4_w18_8_view_tta_at_1024x512_properties():
+    """Config 4 as worded, full size: HRNet-W18, one 1024 x 512 image, 8 TTA views ({id, H, V, HV} x {clean, noisy}).
+    No reference run exists at this size, so: every view equals its stand-alone forward un-flipped by
+    torch.flip, reruns are bit-identical, the maps obey their bounds and MI = PE - EE."""
+    from values_amd.predict2d import predict_logits_2d, process_output_2d, tta_views_8
+    m, _ = _w18_full()
+    x = torch.from_numpy(formula_tensor((1, 3, 512, 1024), tag=88, scale=1.5)).float().cuda()
+    noisy = x + torch.from_numpy(formula_tensor((1, 3, 512, 1024), tag=89, scale=0.1)).float().cuda()
+    views, hf, vf = tta_views_8(x, noisy)
+    lg = predict_logits_2d([m], views, tta=True, hflip_views=hf, vflip_views=vf)
+    lg2 = predict_logits_2d([m], views, tta=True, hflip_views=hf, vflip_views=vf)
+    assert lg.shape == (1, 8, 19, 512, 1024) and torch.equal(lg, lg2)
+    assert torch.isfinite(lg).all()
+    for vi in (0, 1, 2, 3, 6):
+        alone = m(views[vi])
+        dims = ([-1] if hf[vi] else []) + ([-2] if vf[vi] else [])
+        alone = torch.flip(alone, dims) if dims else alone
+        assert torch.equal(lg[:, vi], alone), vi
+    assert (lg[:, 0] - lg[:, 3]).abs().max().item() > 1e-3      # strided convs are not flip-equivariant: the views differ
+    out = process_output_2d(lg)
+    pe, ee, mi = out["pred_entropy"], out["aleatoric_uncertainty"], out["epistemic_uncertainty"]
+    assert pe.min().item() >= 0 and pe.max().item() <= float(np.log(19)) + 1e-5
+    assert ee.min().item() >= 0 and mi.min().item() > -1e-5
+    assert (mi - (pe - ee)).abs().max().item() < 1e-6
+    assert (out["mean_softmax"].sum(1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(out["pred_seg"], out["mean_softmax"].argmax(1).to(torch.uint8)) or \
+        (out["pred_seg"] != out["mean_softmax"].argmax(1).to(torch.uint8)).float().mean().item() < 1e-5

@@ -306,3 +306,21 @@ def test_hrnet_w18_widths_oracle_matches_reference():
             assert np.abs(y - g["logits"][t]).max() < 2e-5
         y = hrnet_forward(dict(HRNET_W18S_EXTRA, DROPOUT_FINAL=False), sd, x).numpy()
         assert np.abs(y - g["logits_nodrop"]).max() < 2e-5
+
+
+def test_hrnet_oracle_matches_reference_w18_full_layout_256x478():
+    """the float64 oracle against the imported reference class in the FULL HRNet-W18 layout at 256 x 478 (config C4's
+    network at the reference's image size): sub-grid and whole-map row / column sums of its float64 run"""
+    import json
+    from oracle.hrnet_oracle import hrnet_forward
+    from values_amd.formula import formula_state_dict_from_shapes, formula_tensor, hrnet_w18_extra
+    g = dict(np.load(os.path.join(GOLDEN, "hrnet_w18_256x478.npz")))
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).double() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    x = torch.from_numpy(formula_tensor((1, 3, 256, 478), tag=int(g["input_tag"]), scale=float(g["input_scale"]))).float().double()
+    with torch.no_grad():
+        y = hrnet_forward(hrnet_w18_extra(False), sd, x).numpy()[0]
+    assert np.abs(y[:, ::4, ::6] - g["logits64_sub"]).max() < 5e-7          # the sub-grid is stored as float32
+    assert np.abs(y.sum(2) - g["logits64_rowsum"]).max() < 1e-9
+    assert np.abs(y.sum(1) - g["logits64_colsum"]).max() < 1e-9
+    assert np.abs(y[:, ::4, ::6] - g["logits_sub"]).max() < 2 * float(g["ref_f32_f64_gap"])

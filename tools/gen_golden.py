@@ -429,6 +429,55 @@ def gen_hrnet_w18():
           float(out["logits"].min()), float(out["logits"].max()))
 
 
+def gen_hrnet_w18_full():
+    """G11 hrnet_w18_256x478.npz: the reference HighResolutionNet in the FULL HRNet-W18 layout (BASELINE config 4:
+    widths 18/36/72/144, 1/4/3 modules of 4 blocks, 19 classes, no DROPOUT_FINAL) on ONE 3 x 256 x 478 image -- the size
+    the reference's test images have -- in training-mode BatchNorm as the reference runs it.  Kept small:
+    the float32 logits on a stride-(4, 6) sub-grid, their float64 row and column sums over the WHOLE map (every pixel
+    is pinned through them), the same from a float64 run of the reference class (its own float32-vs-float64 gap), and
+    the VerticalFlip / HorizontalFlip views' logits on the sub-grid for the 8-view TTA of config 4."""
+    import copy
+    import uncertainty_modeling.models.hrnet_module as ref_hr
+    from values_amd.formula import formula_state_dict_from_shapes, hrnet_w18_extra
+    extra = copy.deepcopy(hrnet_w18_extra(False))
+    ncls = 19
+    cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
+                "DATASET": {"NUM_CLASSES": ncls}})
+    model = ref_hr.HighResolutionNet(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    for k, v in formula_state_dict_from_shapes(shapes).items():
+        full[k] = torch.from_numpy(v).float()
+    model.load_state_dict(full)
+    x = torch.from_numpy(formula_tensor((1, 3, 256, 478), tag=87, scale=1.5)).float()
+    torch.set_grad_enabled(False)
+    out = {"shapes_json": np.frombuffer(json.dumps({k: list(v) for k, v in shapes.items()}).encode(), dtype=np.uint8),
+           "input_tag": np.array(87), "input_scale": np.array(1.5)}
+    sy, sx = 4, 6
+
+    def put(tag, y):
+        y = y[0]
+        out[f"{tag}_sub"] = y[:, ::sy, ::sx].astype(np.float32)
+        out[f"{tag}_rowsum"] = y.astype(np.float64).sum(2)
+        out[f"{tag}_colsum"] = y.astype(np.float64).sum(1)
+        out[f"{tag}_absmax"] = np.array(np.abs(y).max())
+
+    y32 = model.forward(x).numpy()
+    put("logits", y32)
+    put("logits_hflip", torch.flip(model.forward(torch.flip(x, [-1])), [-1]).numpy())      # test_2D.py:304-309
+    put("logits_vflip", torch.flip(model.forward(torch.flip(x, [-2])), [-2]).numpy())      # the 8-view extension
+    m64 = ref_hr.HighResolutionNet(cfg).double()
+    m64.load_state_dict({k: v.double() for k, v in full.items()})
+    y64 = m64.forward(x.double()).numpy()
+    put("logits64", y64)
+    out["ref_f32_f64_gap"] = np.array(np.abs(y32 - y64).max())
+    torch.set_grad_enabled(True)
+    path = os.path.join(OUT, "hrnet_w18_256x478.npz")
+    np.savez_compressed(path, **out)
+    print("G11 hrnet_w18_256x478.npz", y32.shape, os.path.getsize(path) / 1e6, "MB; logit range", float(y32.min()), float(y32.max()),
+          "reference f32-vs-f64 gap", float(out["ref_f32_f64_gap"]))
+
+
 def gen_ssn():
     """G7 ssn_16.npz: the reference SsnUNet3D (ssn_unet3D_module.py) + distribution.sample as predict_cases_ssn
     calls it (test_3D.py:373-385), with the standard normals of LowRankMultivariateNormal.rsample replaced by
@@ -557,7 +606,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn", "hrnet_w18"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn", "hrnet_w18", "hrnet_w18_full"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -580,3 +629,5 @@ if __name__ == "__main__":
         gen_hrnet_ssn()
     if "hrnet_w18" in which:
         gen_hrnet_w18()
+    if "hrnet_w18_full" in which:
+        gen_hrnet_w18_full()

@@ -153,8 +153,12 @@ __global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* __restr
     const float* p10 = x + (((size_t)n * H + y1) * W + x0) * x_pitch;
     const float* p11 = x + (((size_t)n * H + y1) * W + x1) * x_pitch;
     const int slot = dst ? dst[n] : n;
-    const int wx = (flip && (flip[n] & 1)) ? OW - 1 - ox : ox;   // un-flip of a HorizontalFlip TTA view (test_2D.py:304-309)
-    float* o = out + (size_t)slot * C * OH * OW + (size_t)oy * OW + wx;
+    // un-flip of a TTA view: bit 0 HorizontalFlip (test_2D.py:304-309: torch.flip(output, [-1])), bit 1 VerticalFlip
+    // (the 8-view extension of BASELINE config 4; the reference ships 4 views)
+    const int fl = flip ? flip[n] : 0;
+    const int wx = (fl & 1) ? OW - 1 - ox : ox;
+    const int wy = (fl & 2) ? OH - 1 - oy : oy;
+    float* o = out + (size_t)slot * C * OH * OW + (size_t)wy * OW + wx;
     for (int c = 0; c < C; ++c)
       o[(size_t)c * OH * OW] = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
   }

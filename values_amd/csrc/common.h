@@ -10,7 +10,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 void vx_set_error(const char* fmt, ...);
-const vx_config& vx_cfg();   // lib.cpp: the environment is read once, never per launch
+const vx_config& vx_cfg();
+// name of the kernel instance a launcher dispatched to, as rocprofv3 prints it (vx_unet3d_forward_profiled reports it
+// next to each launch's time); vx_kname formats once and keeps the string for the life of the process
+void vx_note_kernel(const char* name);
+const char* vx_last_kernel();
+const char* vx_kname(const char* fmt, ...);   // lib.cpp: the environment is read once, never per launch
 
 #define VX_FAIL(code, ...)      \
   do {                          \

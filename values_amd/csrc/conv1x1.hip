@@ -50,7 +50,8 @@ extern "C" int vx_conv1x1_ncdhw(const float* in, int in_pitch, const float* w, c
   int blocks = (int)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   hipStream_t s = (hipStream_t)stream;
-#define VX_1X1(FF) \
+#define VX_1X1(FF)                                      \
+  vx_note_kernel("conv1x1_ncdhw_kernel<" #FF ">");        \
   hipLaunchKernelGGL(conv1x1_ncdhw_kernel<FF>, dim3(blocks), dim3(256), 0, s, in, in_pitch, w, bias, out, N, D, H, W, C, dst, flip)
   switch (F) {
     case 8: VX_1X1(8); break;

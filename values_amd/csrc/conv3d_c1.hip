@@ -114,6 +114,7 @@ extern "C" int vx_conv3d_k3_c1(const float* in, const float* w_torch, const floa
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z * N));
   hipStream_t s = (hipStream_t)stream;
 #define VX_C1(CO)                                                                                                  \
+  vx_note_kernel("conv3d_k3_c1_kernel<" #CO ">");                                                                  \
   hipLaunchKernelGGL(conv3d_k3_c1_kernel<CO>, grid, dim3(256), 0, s, in, w_torch, bias, out, out_pitch, N, D, H, W, \
                      repeat, src, flip, stats_partial, tiles_x, tiles_y, tiles_z)
   switch (Cout) {

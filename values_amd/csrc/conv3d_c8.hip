@@ -400,6 +400,8 @@ static int launch_c8(const ConvC8Args& ka, hipStream_t s) {
   if (vx_cfg().c8_per_cu > 0) per_cu = vx_cfg().c8_per_cu;   // tuning knob
   int gx = 256 * per_cu;
   if (gx > total_tiles) gx = total_tiles;
+  static const char* kname = vx_kname("conv3d_k3_c8_kernel<%d,%d,%d,%d>", NCH, TXV, TY, TZ);
+  vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTH), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(c8)");
   return VX_OK;

@@ -352,6 +352,7 @@ static int launch_dma(const ConvDArgs& ka, hipStream_t s) {
   if (per_cu * NW > 32) per_cu = 32 / NW;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
+  vx_note_kernel("conv3d_k3_dma_kernel");
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(64 * NW), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(dma)");
   return VX_OK;

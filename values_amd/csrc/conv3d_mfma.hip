@@ -609,6 +609,8 @@ static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   dim3 grid((unsigned)gx, (unsigned)ygroups);
+  static const char* kname = vx_kname("conv3d_k3_mfma_kernel<%d,%d,%d,%d,%d,%d,%d>", CB, NT, TX, TY, TZ, NW, XP);
+  vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3");
   return VX_OK;

@@ -755,6 +755,8 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   if (vx_cfg().s16_per_cu > 0) per_cu = vx_cfg().s16_per_cu;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
+  static const char* kname = vx_kname("conv3d_k3_s16_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", CB, NT, TX, TY, TZ, NW, XP, DB, EPI);
+  vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(64 * NW), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(s16)");
   return VX_OK;

@@ -246,6 +246,8 @@ static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
   ConvTDecode dc;
   dc.mW = magic(a.W); dc.mH = magic(a.H); dc.mD = magic(a.D);
+  static const char* kname = vx_kname("convT_k2s2_mfma_kernel<%d,%d>", CIN, RT);
+  vx_note_kernel(kname);
   hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
                      ncoltiles, (int)nvox, dc);
   VX_CHECK_LAUNCH("vx_convT_k2s2(mfma)");
@@ -316,6 +318,7 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
     int bx = (int)((total + 255) / 256);
     if (bx > 4096) bx = 4096;
     dim3 grid((unsigned)bx, 4);
+    vx_note_kernel("convT_k2s2_rows_kernel");
     if (a.Cin == 16)
       hipLaunchKernelGGL(convT_k2s2_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a, total);
     else
@@ -327,6 +330,7 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   int bx = (int)((nvox + 255) / 256);
   if (bx > 8192) bx = 8192;
   dim3 grid((unsigned)bx, (unsigned)(4 * (a.Cout / CT_CO)));
+  vx_note_kernel("convT_k2s2_kernel");
   hipLaunchKernelGGL(convT_k2s2_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, nvox);
   VX_CHECK_LAUNCH("vx_convT_k2s2");
   return VX_OK;

@@ -1,6 +1,8 @@
 // libvalues_amd.so: version + thread-local error string.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/values_amd.h"
 
@@ -11,6 +13,20 @@ void vx_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+static thread_local const char* g_last_kernel = nullptr;
+void vx_note_kernel(const char* name) { g_last_kernel = name; }
+const char* vx_last_kernel() { return g_last_kernel; }
+const char* vx_kname(const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  char* p = (char*)malloc(strlen(buf) + 1);   // one per launcher instantiation, never freed
+  strcpy(p, buf);
+  return p;
 }
 
 // ---- configuration: read from the environment exactly once, replaced only by vx_set_config ----

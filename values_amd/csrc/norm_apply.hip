@@ -34,6 +34,7 @@ extern "C" int vx_instnorm_finalize(const float* stats_partial, int N, int ntile
                                     float* mean, float* rstd, vx_stream_t stream) {
   if (!stats_partial || !mean || !rstd) VX_FAIL(VX_E_NULL, "vx_instnorm_finalize: null pointer");
   if (N <= 0 || ntiles <= 0 || C <= 0 || nvox <= 0) VX_FAIL(VX_E_SHAPE, "vx_instnorm_finalize: empty");
+  vx_note_kernel("instnorm_finalize_kernel");
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)(N * C)), dim3(64), 0, (hipStream_t)stream,
                      stats_partial, ntiles, C, 1.0 / (double)nvox, eps, mean, rstd);
   VX_CHECK_LAUNCH("vx_instnorm_finalize");
@@ -247,13 +248,18 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
       int fx = (int)((per + 255) / 256);
       const int fcap = (32768 + ns - 1) / ns;
       if (fx > fcap) fx = fcap;
+      vx_note_kernel("norm_act_drop_fanout_kernel");
       hipLaunchKernelGGL(norm_act_drop_fanout_kernel, dim3(fx, ns), dim3(256), 0, s, a, x_repeat, dc);
-    } else if (wide)
+    } else if (wide) {
+      vx_note_kernel("norm_act_drop_pool_kernel<true,true>");
       hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
-    else if (pool)
+    } else if (pool) {
+      vx_note_kernel("norm_act_drop_pool_kernel<true,false>");
       hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
-    else
+    } else {
+      vx_note_kernel("norm_act_drop_pool_kernel<false,false>");
       hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
+    }
   }
   VX_CHECK_LAUNCH("vx_norm_act_drop_pool");
   return VX_OK;

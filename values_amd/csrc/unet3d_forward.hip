@@ -81,10 +81,12 @@ struct Prof {
   static constexpr int MAXL = 96;
   hipEvent_t ev[2 * MAXL];
   const char* name[MAXL];
+  const char* kernel[MAXL];
   int n = 0;
   hipStream_t s;
 };
 thread_local Prof* g_prof = nullptr;
+thread_local char g_prof_labels[Prof::MAXL][192];   // "label|kernel instance", valid until the thread's next profiled forward
 }  // namespace
 
 #define VX_TRY(expr)            \
@@ -96,11 +98,12 @@ thread_local Prof* g_prof = nullptr;
 #define VX_STEP(label, expr)                                                       \
   do {                                                                             \
     Prof* pf_ = g_prof;                                                            \
-    if (pf_ && pf_->n < Prof::MAXL) (void)hipEventRecord(pf_->ev[2 * pf_->n], pf_->s);    \
+    if (pf_ && pf_->n < Prof::MAXL) { vx_note_kernel(nullptr); (void)hipEventRecord(pf_->ev[2 * pf_->n], pf_->s); }  \
     int rc_ = (expr);                                                              \
     if (rc_ != VX_OK) return rc_;                                                  \
     if (pf_ && pf_->n < Prof::MAXL) {                                              \
       (void)hipEventRecord(pf_->ev[2 * pf_->n + 1], pf_->s);                             \
+      pf_->kernel[pf_->n] = vx_last_kernel();                                      \
       pf_->name[pf_->n++] = (label);                                               \
     }                                                                              \
   } while (0)
@@ -187,6 +190,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   static const char* kConv[18] = {"contr_1_1", "contr_1_2", "contr_2_1", "contr_2_2", "contr_3_1", "contr_3_2",
                                   "contr_4_1", "contr_4_2", "center.0", "center.2", "expand_4_1", "expand_4_2",
                                   "expand_3_1", "expand_3_2", "expand_2_1", "expand_2_2", "expand_1_1", "expand_1_2"};
+  const char* kLast = fuse_head ? "expand_1_2+final" : kConv[17];   // a fused launch is labelled with every layer it computes
   static const char* kNorm[8] = {"norm:contr_1_1", "norm:contr_1_2", "norm:contr_2_1", "norm:contr_2_2",
                                  "norm:contr_3_1", "norm:contr_3_2", "norm:contr_4_1", "norm:contr_4_2"};
   static const char* kFin[8] = {"finalize:contr_1_1", "finalize:contr_1_2", "finalize:contr_2_1", "finalize:contr_2_2",
@@ -240,7 +244,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
     VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
-    VX_STEP(kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
+    VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------
@@ -273,7 +277,8 @@ extern "C" int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_u
       float t = 0.f;
       (void)hipEventElapsedTime(&t, pf.ev[2 * n], pf.ev[2 * n + 1]);
       ms[n] = t;
-      labels[n] = pf.name[n];
+      snprintf(g_prof_labels[n], sizeof(g_prof_labels[n]), "%s|%s", pf.name[n], pf.kernel[n] ? pf.kernel[n] : "?");
+      labels[n] = g_prof_labels[n];
     }
   }
   *n_launches = n;

@@ -542,10 +542,11 @@ class HighResolutionNet(nn.Module):
     @torch.no_grad()
     def forward_samples(self, x: torch.Tensor, n_samples: int = 1, dropout_masks: Optional[Sequence] = None,
                         seeds: Optional[Sequence[int]] = None, hflip_back: bool = False,
-                        out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0) -> torch.Tensor:
+                        out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0,
+                        vflip_back: bool = False) -> torch.Tensor:
         """(n_samples, B, C, H, W) logits: backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
         [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
-        (a HorizontalFlip TTA view, test_2D.py:304-309)."""
+        (a HorizontalFlip TTA view, test_2D.py:304-309); vflip_back: along H (VerticalFlip, the 8-view extension)."""
         _lib.require_gpu()
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         x = x.detach().to(dev, torch.float32)
@@ -557,7 +558,8 @@ class HighResolutionNet(nn.Module):
         user_out = out is not None
         if out is None:
             out = torch.empty((n_samples * n, self.num_classes, h, w), dtype=torch.float32, device=dev)
-        flip = torch.full((n,), 1, dtype=torch.int32, device=dev) if hflip_back else None
+        code = (1 if hflip_back else 0) | (2 if vflip_back else 0)
+        flip = torch.full((n,), code, dtype=torch.int32, device=dev) if code else None
         for t in range(n_samples):
             mode = _lib.VX_DROP_NONE
             masks = None

@@ -1,7 +1,7 @@
 """2D multi-pass inference: Tester.predict_cases + process_output (uncertainty_modeling/test_2D.py:205-319) on the device.
 
 pred order (test_2D.py:283-317): for model in models: [TTA: one forward per view, HorizontalFlip views un-flipped] or
-[n_pred forwards]; SSN is not built.  Every forward is its own batch, so training-mode BatchNorm sees the same batch
+[n_pred forwards]; an SSN model (hrnet_module.py:559-595) makes ONE forward and n_pred draws.  Every forward is its own batch, so training-mode BatchNorm sees the same batch
 statistics as in the reference; for DROPOUT_FINAL models the n_pred forwards share the backbone (exact).
 Logits land directly in per-image stacks (B, Npred, C, H, W); the per-image reduction is calculate_uncertainty
 (Npred > 1) or calculate_one_minus_msr (Npred == 1), test_2D.py:245-248.  The reference appends an all-zero class
@@ -18,10 +18,27 @@ from .uncertainty import uncertainty_maps
 
 
 @torch.no_grad()
+def tta_views_8(x: torch.Tensor, x_noisy: torch.Tensor):
+    """The 8 views BASELINE config 4 words: {identity, HorizontalFlip, VerticalFlip, both} of the clean and of the
+    noisy image (the reference's dataset builds 4: identity / HorizontalFlip x clean / GaussNoise,
+    cityscapes_dataset.py:76-99; the noise is an input here as there).  Returns (views, hflip flags, vflip flags) in
+    pred order: clean views first."""
+    views, hf, vf = [], [], []
+    for base in (x, x_noisy):
+        for h, v in ((False, False), (True, False), (False, True), (True, True)):
+            dims = ([-1] if h else []) + ([-2] if v else [])
+            views.append(torch.flip(base, dims) if dims else base)
+            hf.append(h)
+            vf.append(v)
+    return views, hf, vf
+
+
+@torch.no_grad()
 def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False, hflip_views: Optional[Sequence[bool]] = None,
-                      dropout_masks=None, seeds=None) -> torch.Tensor:
-    """data: (B,3,H,W) tensor, or with tta a list of view tensors (the dataset's 4 views, cityscapes_dataset.py:76-99)
-    and hflip_views[i] = "HorizontalFlip" in transforms of view i.  Returns logits (B, Npred_total, C, H, W)."""
+                      dropout_masks=None, seeds=None, vflip_views: Optional[Sequence[bool]] = None) -> torch.Tensor:
+    """data: (B,3,H,W) tensor, or with tta a list of view tensors (the dataset's 4 views, cityscapes_dataset.py:76-99,
+    or the 8 of tta_views_8) and hflip_views[i] = "HorizontalFlip" in transforms of view i (vflip_views likewise).
+    Returns logits (B, Npred_total, C, H, W)."""
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     views = list(data) if tta else [data]
@@ -38,6 +55,7 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
         if tta:
             for vi, view in enumerate(views):
                 model.forward_samples(view, 1, hflip_back=bool(hflip_views[vi]) if hflip_views else False,
+                                      vflip_back=bool(vflip_views[vi]) if vflip_views else False,
                                       seeds=None if seeds is None else [seeds[mi] * 131 + vi],
                                       out=out, slot_stride=total, slot_offset=base + vi)
         else:

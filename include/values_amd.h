@@ -380,6 +380,28 @@ int vx_ssn2d_add_diag(float* out, const float* diag, const float* eps_d, uint32_
                       float epsilon, vx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
+ * Downstream scalars of the evaluation stage (evaluation/metrics/{ncc,ace}.py): the per-voxel float64 reductions, all
+ * deterministic (fixed grid of partial rows added in index order).  workspace: vx_evalmetrics_workspace_bytes().
+ *   vx_ncc_sums  (ncc.py:9-25)  pass 0: sums[0..1] = sum gt, sum pred;  pass 1 (means given): sums[0..2] =
+ *                sum (gt-mg)^2, sum (pred-mp)^2, sum (gt-mg)(pred-mp)  -- numpy's two-pass mean / std(ddof=1) / product.
+ *   vx_platt_sums (ace.py:13-41, sklearn.calibration._sigmoid_calibration on (-unc, reference == prediction)):
+ *                ref [R][nvox] int32 reference segmentations, pred [nvox] int32 mean prediction, unc [nvox] f32/f64;
+ *                voxels with ref == ignore_value dropped (ignore_value < 0: none).  For the sigmoid parameters (A, B)
+ *                and Platt's targets t_pos / t_neg: sums[0] = valid count, [1] = correct count, [2] = loss,
+ *                [3..4] = gradient (dA, dB), [5..7] = Hessian (AA, AB, BB).  The host iterates (Newton).
+ *   vx_calib_bins (ace.py:44-90) platt_scale_confid + calib_stats' 20-bin statistics: bins63 = bin_sums[21],
+ *                bin_true[21], bin_total[21] for the bin edges edges21 (a HOST array: np.linspace(0, 1 + 1e-8, 21)). */
+int64_t vx_evalmetrics_workspace_bytes(void);
+int vx_ncc_sums(const void* gt, int gt_dtype, const void* pred, int pred_dtype, int64_t n, int pass, double mean_gt,
+                double mean_pred, double* sums, void* workspace, vx_stream_t stream);
+int vx_platt_sums(const void* unc, int dtype, const int32_t* ref, const int32_t* pred, int R, int64_t nvox,
+                  int ignore_value, double A, double B, double t_pos, double t_neg, double* sums, void* workspace,
+                  vx_stream_t stream);
+int vx_calib_bins(const void* unc, int dtype, const int32_t* ref, const int32_t* pred, int R, int64_t nvox,
+                  int ignore_value, double A, double B, const double* edges21, double* bins63, void* workspace,
+                  vx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * K19/K20: map -> scalar aggregations (evaluation/uncertainty_aggregation/aggregate_uncertainties.py).
  *   vx_box_max : patch_level_aggregation (:13-31): box-sum 'valid' (pd,ph,pw) in float64, max and
  *                first (C-order) index with isclose(value, max); result[0]=max, idx[0..2]

@@ -263,6 +263,12 @@ def test_metrics_oracle_loss_matches_reference_and_dice_by_definition():
     assert mo.calculate_ged(sm1, np.repeat(a, 2, 0))["ged"] == pytest.approx(0.0)
     anti = np.stack([a, 1 - a], 1).astype(np.float64) * 0.8 + 0.1
     assert mo.calculate_ged(np.repeat(anti, 2, 0), np.repeat(a, 2, 0))["ged"] == pytest.approx(2.0)
+    # cross-check (not a pin: torchmetrics is absent) with scikit-learn's micro-averaged F1 over the kept labels, an
+    # independent implementation of the same published quantity, on random label volumes of 2 / 3 / 5 classes
+    for C in (2, 3, 5):
+        p_, t_ = g[f"xc_pred_{C}"].astype(np.int64), g[f"xc_gt_{C}"].astype(np.int64)
+        assert mo.tm_dice(p_, t_) == pytest.approx(float(g[f"xc_f1_all_{C}"]), abs=1e-15)
+        assert mo.tm_dice(p_, t_, ignore_index=0) == pytest.approx(float(g[f"xc_f1_ign0_{C}"]), abs=1e-15)
 
 
 def test_hrnet_ssn_oracle_matches_reference():
@@ -324,3 +330,46 @@ def test_hrnet_oracle_matches_reference_w18_full_layout_256x478():
     assert np.abs(y.sum(2) - g["logits64_rowsum"]).max() < 1e-9
     assert np.abs(y.sum(1) - g["logits64_colsum"]).max() < 1e-9
     assert np.abs(y[:, ::4, ::6] - g["logits_sub"]).max() < 2 * float(g["ref_f32_f64_gap"])
+
+
+def test_evalmetrics_oracle_matches_reference_fixture():
+    """AURC / E-AURC, NCC, ACE (+ the Platt fit), AUROC: the numpy restatement against values produced by the
+    reference's evaluation/metrics modules (tests/golden/evalmetrics_kat.npz, tools/gen_golden.py)"""
+    from oracle import evalmetrics_oracle as em
+    g = dict(np.load(os.path.join(GOLDEN, "evalmetrics_kat.npz")))
+    cov, sel, wts = em.rc_curve_stats(g["aurc_risks"], g["aurc_confids"])
+    np.testing.assert_allclose(cov, g["rc_coverages"], rtol=0, atol=0)
+    np.testing.assert_allclose(sel, g["rc_risks"], rtol=1e-14)
+    np.testing.assert_allclose(wts, g["rc_weights"], rtol=0, atol=0)
+    assert abs(em.aurc(g["aurc_risks"], g["aurc_confids"]) - float(g["aurc"])) < 1e-14
+    assert abs(em.eaurc(g["aurc_risks"], g["aurc_confids"]) - float(g["eaurc"])) < 1e-14
+    assert abs(em.compute_ncc(g["ncc_gt"], g["ncc_pred"]) - float(g["ncc"])) < 1e-14
+    assert abs(em.roc_auc(g["auroc_y"], g["auroc_score"]) - float(g["auroc"])) < 1e-14
+    for tag, ign in (("all", None), ("ign2", 2)):
+        F, y = em.rater_correct(g["ace_ref"], g["ace_pred"], g["ace_unc"], ign)
+        a, b = em.sigmoid_calibration(F, y)
+        # the fit: same optimum as the installed scikit-learn to ITS optimiser tolerance (gtol 1e-6, ftol 64 eps)
+        assert abs(a - float(g[f"ace_{tag}_a"])) < 2e-3 * abs(a) and abs(b - float(g[f"ace_{tag}_b"])) < 2e-3 * abs(b), (a, b)
+        # everything after the fit, with the reference's own (a, b): exact
+        conf = em.platt_scale_confid(F, float(g[f"ace_{tag}_a"]), float(g[f"ace_{tag}_b"]))
+        d, w, k = em.calib_stats(y, conf)
+        np.testing.assert_allclose(d, g[f"ace_{tag}_disc"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(w, g[f"ace_{tag}_w"], rtol=1e-14)
+        assert k == int(g[f"ace_{tag}_k"])
+        assert abs(em.calc_ace(y, conf) - float(g[f"ace_{tag}"])) < 1e-14
+    conf1 = 1 / (1 + np.exp(-g["ace_unc"].flatten() * 2.0 - 1.0))
+    assert abs(em.calc_ace(np.ones(conf1.size, dtype=int), conf1) - float(g["ace_onelabel"])) < 1e-14
+
+
+def test_evalmetrics_host_functions_match_reference_fixture():
+    """the host halves of values_amd.evalmetrics (one scalar per image: AURC / E-AURC / AUROC) against the same fixture"""
+    from values_amd import evalmetrics as vm
+    g = dict(np.load(os.path.join(GOLDEN, "evalmetrics_kat.npz")))
+    cov, sel, wts = vm.rc_curve_stats(g["aurc_risks"], g["aurc_confids"])
+    np.testing.assert_allclose(cov, g["rc_coverages"], rtol=0, atol=0)
+    np.testing.assert_allclose(sel, g["rc_risks"], rtol=1e-14)
+    np.testing.assert_allclose(wts, g["rc_weights"], rtol=0, atol=0)
+    assert abs(vm.aurc(g["aurc_risks"], g["aurc_confids"]) - float(g["aurc"])) < 1e-14
+    assert abs(vm.eaurc(g["aurc_risks"], g["aurc_confids"]) - float(g["eaurc"])) < 1e-14
+    assert abs(vm.roc_auc(g["auroc_y"], g["auroc_score"]) - float(g["auroc"])) < 1e-14
+    assert vm.get_auroc_input({"3.nii.gz": {"a": {"max_score": 1.5}}, "25.nii.gz": {"a": {"max_score": 0.5}}}, "a") == ([1, 0], [1.5, 0.5])

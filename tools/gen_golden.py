@@ -478,6 +478,69 @@ def gen_hrnet_w18_full():
           "reference f32-vs-f64 gap", float(out["ref_f32_f64_gap"]))
 
 
+def gen_evalmetrics():
+    """G12 evalmetrics_kat.npz: the evaluation stage's downstream scalars from the reference's own modules --
+    evaluation/metrics/aurc.py (rc_curve_stats, aurc, eaurc), ncc.py (compute_ncc), ace.py (platt_scale_confid,
+    calib_stats, calc_ace, and the Platt fit it imports from the INSTALLED scikit-learn: the reference pins 1.2.2, this
+    container has another version -- same objective, other optimiser), auroc.py's roc_curve + auc call."""
+    import sklearn
+    import evaluation.metrics.aurc as ref_aurc
+    import evaluation.metrics.ncc as ref_ncc
+    import evaluation.metrics.ace as ref_ace
+    from sklearn.metrics import auc, roc_curve
+    rng = np.random.default_rng(7)
+    out = {"sklearn_version": np.frombuffer(sklearn.__version__.encode(), dtype=np.uint8)}
+    # --- AURC / E-AURC: 40 images, ties in the confidences
+    risks = rng.random(40)
+    confids = -np.round(rng.random(40) * 12) / 12 - 0.3 * (1 - risks)
+    confids[5] = confids[9] = confids[17]
+    out.update(aurc_risks=risks, aurc_confids=confids, aurc=np.array(ref_aurc.aurc(risks, confids)),
+               eaurc=np.array(ref_aurc.eaurc(risks, confids)))
+    cov, sel, wts = ref_aurc.rc_curve_stats(risks, confids)
+    out.update(rc_coverages=np.array(cov), rc_risks=np.array(sel), rc_weights=np.array(wts))
+    # --- NCC: rater variance (float64) against a float32 uncertainty map
+    segs = (rng.random((4, 12, 14, 10)) < 0.35).astype(np.int64)
+    gt_unc = np.var(segs, axis=0)
+    pred_unc = (0.6 * gt_unc + 0.1 * rng.random(gt_unc.shape)).astype(np.float32)
+    out.update(ncc_gt=gt_unc, ncc_pred=pred_unc, ncc=np.array(ref_ncc.compute_ncc(gt_unc, pred_unc)))
+    # --- ACE: 3 raters, labels {0, 1, 2}; with and without ignore_value = 2
+    ref = rng.integers(0, 3, size=(3, 12, 14, 10))
+    pred = np.where(rng.random((12, 14, 10)) < 0.7, ref[0], rng.integers(0, 3, size=(12, 14, 10)))
+    agree = (ref == pred[None]).mean(0)
+    unc = (0.7 * (1 - agree) + 0.3 * rng.random(pred.shape)).astype(np.float32) * 0.69
+    out.update(ace_ref=ref.astype(np.int32), ace_pred=pred.astype(np.int32), ace_unc=unc)
+    for tag, ign in (("all", None), ("ign2", 2)):
+        p3 = np.repeat(pred[np.newaxis, :], 3, 0)
+        u3 = np.repeat(unc[np.newaxis, :], 3, 0)
+        correct = (ref == p3).astype(int)
+        if ign is not None:
+            keep = ref != ign
+            a, b = ref_ace.calib(-u3[keep], correct[keep])
+            conf = 1 / (1 + np.exp(-u3[keep] * a + b))           # platt_scale_confid's formula (it reads a JSON file)
+            d, w, k = ref_ace.calib_stats(correct[keep], conf)
+            ace = ref_ace.calc_ace(correct[keep], conf)
+        else:
+            a, b = ref_ace.calib(-u3.flatten(), correct.flatten())
+            conf = 1 / (1 + np.exp(-u3.flatten() * a + b))
+            d, w, k = ref_ace.calib_stats(correct.flatten(), conf)
+            ace = ref_ace.calc_ace(correct.flatten(), conf)
+        out.update({f"ace_{tag}_a": np.array(a), f"ace_{tag}_b": np.array(b), f"ace_{tag}_disc": d, f"ace_{tag}_w": w,
+                    f"ace_{tag}_k": np.array(k), f"ace_{tag}": np.array(ace)})
+    # the one-label case (every voxel correct): label_binarize gives zeros
+    conf1 = 1 / (1 + np.exp(-unc.flatten() * 2.0 - 1.0))
+    out.update(ace_onelabel=np.array(ref_ace.calc_ace(np.ones(unc.size, dtype=int), conf1)))
+    # --- AUROC as auroc.py:126-127 computes it
+    y = (rng.random(60) < 0.35).astype(int)
+    sc = np.round(rng.random(60) * 20) / 20 + 0.4 * y
+    fpr, tpr, _ = roc_curve(y, sc)
+    out.update(auroc_y=y, auroc_score=sc, auroc=np.array(auc(fpr, tpr)))
+    path = os.path.join(OUT, "evalmetrics_kat.npz")
+    np.savez_compressed(path, **out)
+    print("G12 evalmetrics_kat.npz", os.path.getsize(path) / 1e3, "KB; aurc", float(out["aurc"]), "eaurc", float(out["eaurc"]),
+          "ncc", float(out["ncc"]), "ace", float(out["ace_all"]), float(out["ace_ign2"]), "a,b", float(out["ace_all_a"]),
+          float(out["ace_all_b"]), "auroc", float(out["auroc"]), "sklearn", sklearn.__version__)
+
+
 def gen_ssn():
     """G7 ssn_16.npz: the reference SsnUNet3D (ssn_unet3D_module.py) + distribution.sample as predict_cases_ssn
     calls it (test_3D.py:373-385), with the standard normals of LowRankMultivariateNormal.rsample replaced by
@@ -539,6 +602,18 @@ def gen_metrics():
         out[f"gt_{C}"] = gt.numpy().astype(np.uint8)
         out[f"loss_per_rater_{C}"] = np.array(losses)
         out[f"loss_{C}"] = np.mean(np.array(losses))
+    # Cross-check material for the hard Dice (NOT a pin: torchmetrics 0.11.4, the reference's dependency, is absent).
+    # scikit-learn's micro-averaged F1 over the labels that are not ignored is an independent implementation of the
+    # same published quantity 2 TP / (2 TP + FP + FN) -- and of the same treatment of an ignored class (its column
+    # dropped, mistakes INTO it still counted): tests compare oracle/metrics_oracle.tm_dice with it.
+    from sklearn.metrics import f1_score
+    rng = np.random.default_rng(11)
+    for C in (2, 3, 5):
+        a = rng.integers(0, C, size=(4, 6, 5, 4))
+        b = np.where(rng.random(a.shape) < 0.6, a, rng.integers(0, C, size=a.shape))
+        out[f"xc_pred_{C}"], out[f"xc_gt_{C}"] = a.astype(np.uint8), b.astype(np.uint8)
+        out[f"xc_f1_all_{C}"] = np.array(f1_score(b.ravel(), a.ravel(), labels=list(range(C)), average="micro", zero_division=0))
+        out[f"xc_f1_ign0_{C}"] = np.array(f1_score(b.ravel(), a.ravel(), labels=list(range(1, C)), average="micro", zero_division=0))
     np.savez_compressed(os.path.join(OUT, "metrics_kat.npz"), **out)
     print("G8 metrics_kat.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("loss")})
 
@@ -606,7 +681,7 @@ def gen_hrnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn", "hrnet_w18", "hrnet_w18_full"]
+    which = sys.argv[1:] or ["unc", "unet16", "unet32", "tta", "patch", "agg", "hrnet", "ssn", "metrics", "hrnet_ssn", "hrnet_w18", "hrnet_w18_full", "evalmetrics"]
     if "unc" in which:
         gen_unc_kat()
     if "unet16" in which:
@@ -631,3 +706,5 @@ if __name__ == "__main__":
         gen_hrnet_w18()
     if "hrnet_w18_full" in which:
         gen_hrnet_w18_full()
+    if "evalmetrics" in which:
+        gen_evalmetrics()

@@ -142,6 +142,10 @@ SIGNATURES = {
     "vx_bn_finalize": (_i, [_p, _i, _i, _i64, C.c_float, _p, _p, _p, _p, _p]),
     "vx_affine_gather": (_i, [C.POINTER(AffineArgs), _p]),
     "vx_bilinear_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "vx_evalmetrics_workspace_bytes": (_i64, []),
+    "vx_ncc_sums": (_i, [_p, _i, _p, _i, _i64, _i, C.c_double, C.c_double, _p, _p, _p]),
+    "vx_platt_sums": (_i, [_p, _i, _p, _p, _i, _i64, _i, C.c_double, C.c_double, C.c_double, C.c_double, _p, _p, _p]),
+    "vx_calib_bins": (_i, [_p, _i, _p, _p, _i, _i64, _i, C.c_double, C.c_double, C.POINTER(C.c_double), _p, _p, _p]),
     "vx_box_max": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p]),
     "vx_sum_thr": (_i, [_p, _i, _i64, C.c_double, _p, _p]),
 }

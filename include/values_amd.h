@@ -71,7 +71,7 @@ typedef struct vx_config {
   int32_t conv_dma;       /* fp32 mode: LDS-DMA double-buffered schedule (conv3d_dma.hip) */
   int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
   int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
-  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm;
+  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_no_ping, s16_no_xp8;
   int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
   int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
@@ -172,7 +172,19 @@ typedef struct vx_conv3d_args {
   const int32_t* head_dst;  /* nullable: slot of sample n (default n) */
   const int32_t* head_flip; /* nullable: un-flip code of sample n (bit 0 z, 1 y, 2 x) */
   int32_t head_C;       /* 1 .. 8 */
+  /* Optional PROLOGUE (only where vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout)): the input -- or, for a concat input,
+   * its skip half -- is the RAW output of a contract block's conv (unet3D_module.py:231-237); InstanceNorm with the
+   * given statistics, LeakyReLU and the block's dropout are applied while the tile is staged, so the normalised tensor
+   * is never written.  in_repeat > 1: sample n reads input sample / statistics row n / in_repeat (the T MC-dropout
+   * samples of a volume share the first block's conv output; the dropout bits are those of sample n). */
+  const float* in_mean; const float* in_rstd;   /* nullable together: [N / in_repeat][8] */
+  int32_t in_drop_mode; uint32_t in_drop_seed, in_drop_layer;   /* VX_DROP_NONE | VX_DROP_HASH of the producing block */
+  int32_t in_repeat;    /* 0 or 1: sample n reads input sample n */
+  int32_t out_xblk, out_half; /* out_xblk > 0: `out` is a concat buffer, this conv writes its half out_half (as vx_norm_args) */
+  uint32_t* range_flag; /* nullable device word: atomic max of the bit patterns of |stored values| (fp16 range guard of
+                           the split-fp16 consumers: anything >= 65504 must not reach them) */
 } vx_conv3d_args;
+int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
  * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
  * skip half (s = 1, written by vx_norm_act_drop_pool) as alternating DENSE blocks of xb voxels, so both producers
@@ -263,6 +275,10 @@ typedef struct vx_unet3d_run {
   const uint8_t* masks[17]; /* channels-last keep-masks in DROPOUT order (oracle/unet3d_oracle.py) */
   float* logits;         /* [slots][C][D][H][W] */
   void* workspace; size_t workspace_bytes;
+  uint32_t* range_flag;  /* nullable device word (zero it before the launch): ends as the bit pattern of the largest
+                            |activation| an un-normalised layer handed to a split-fp16 convolution; >= 65504.0f means
+                            the fp16 split overflowed somewhere and the logits must not be used (re-run with
+                            vx_config.conv_fp32 = 1, the native-fp32 kernels have no such limit) */
 } vx_unet3d_run;
 
 size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F);

@@ -623,3 +623,188 @@ def test_softmax_variance_matches_numpy():
     assert np.abs(got - want).max() < 1e-6
     got = softmax_variance(torch.from_numpy(p.astype(np.float32)).cuda(), from_logits=False).cpu().numpy()
     assert np.abs(got - want).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv3d_xp8.hip: the z-column kernel of the full-resolution Cout = 8 layers (rolling LDS window, per-column statistics,
+# optional normalise-on-load prologue).  The dispatch takes it when W % 32 == 0, H % 8 == 0, D % 4 == 0, D >= 8.
+def _hash_mask(seed, layer, n, c, d, h, w):
+    """keep-mask of the hash bit generator in the reference's (N, C, D, H, W) layout"""
+    lib = _lib.load()
+    m = torch.empty((n, d, h, w, c), dtype=torch.uint8, device=dev())
+    _lib.check(lib.vx_drop_hash_mask(seed, layer, n, d * h * w * c, _lib.ptr(m), _lib.stream_ptr()), "mask")
+    return ncdhw(m).cpu().double()
+
+
+def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, stats=False, xblk=0, head=None,
+              pre=None, out_xblk=0):
+    """one vx_conv3d_k3 launch on a channels-last (or x-blocked) device input; returns (out NCDHW cpu, stats, head)"""
+    lib = _lib.load()
+    assert lib.vx_conv3d_k3_prologue_ok(d, h, wd, cin, 8) == 1
+    wdv, bd = w.float().contiguous().to(dev()), b.float().contiguous().to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, 8), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wdv), _lib.ptr(wp), cin, 8, _lib.stream_ptr()), "pack")
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, 8)
+    out = torch.full((n, d, h, wd, 16 if out_xblk else 8), -77.0, dtype=torch.float32, device=dev())
+    a.in_ = x_cl.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, 8, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, wd, cin, 8
+    a.act, a.drop_mode, a.drop_seed, a.drop_layer, a.in_xblk = act, drop, seed, layer, xblk
+    a.out_xblk, a.out_half = out_xblk, 1
+    keep = [wdv, bd, wp, out]
+    st = None
+    if stats:
+        nt = lib.vx_conv3d_k3_tiles_for(d, h, wd, 8)
+        st = torch.full((n, nt, 8, 2), 5.0, dtype=torch.float32, device=dev())     # the kernel must overwrite every entry
+        a.stats_partial = st.data_ptr()
+    ho = None
+    if head is not None:
+        hw, hb, dst, flip, slots = head
+        ho = torch.full((slots, hw.shape[0], d, h, wd), -5.0, dtype=torch.float32, device=dev())
+        a.out = None
+        a.head_out, a.head_w, a.head_b, a.head_C = ho.data_ptr(), hw.data_ptr(), hb.data_ptr(), hw.shape[0]
+        a.head_dst, a.head_flip = dst.data_ptr(), flip.data_ptr()
+    if pre is not None:
+        mean, rstd, rep, pmode, pseed, player = pre
+        a.in_mean, a.in_rstd, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), rep
+        a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = pmode, pseed, player
+        keep += [mean, rstd]
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    a.range_flag = flag.data_ptr()
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    if out_xblk:
+        res = from_xblk(out, 1, n, 8, d, h, wd, out_xblk).cpu()
+        assert (from_xblk(out, 0, n, 8, d, h, wd, out_xblk) == -77.0).all()      # the other half is not touched
+    else:
+        res = ncdhw(out).cpu()
+    return res, (st.cpu() if st is not None else None), (ho.cpu() if ho is not None else None), flag.view(torch.float32).item()
+
+
+@pytest.mark.parametrize("cin,shape,xblk", [(8, (3, 8, 16, 64), 0), (8, (2, 16, 8, 32), 0), (8, (5, 12, 24, 96), 0),
+                                            (16, (3, 8, 16, 64), 0), (16, (2, 12, 8, 32), 4), (16, (5, 16, 24, 64), 4)])
+def test_conv3d_xp8_epilogues_match_oracle(cin, shape, xblk):
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 301))
+    wt = torch.from_numpy(formula_tensor((8, cin, 3, 3, 3), 302, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((8,), 303, scale=0.2))
+    xd = (to_xblk(x[:, :8].float(), x[:, 8:].float(), xblk) if xblk else cl(x.float())).to(dev())
+    ref = F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1)
+    # plain + statistics (an InstanceNorm follows): every column's partials, the padding entries zero
+    got, st, _, mx = _xp8_conv(xd, cin, wt, b, n, d, h, w, stats=True, xblk=xblk)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    s = st.double().sum(1)
+    np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+    assert abs(mx - got.abs().max().item()) < 1e-6            # the range guard saw the largest stored magnitude
+    # LeakyReLU + hash dropout: the bit generator's mask exported and applied to the oracle
+    got, _, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=91, layer=6, xblk=xblk)
+    keep = _hash_mask(91, 6, n, 8, d, h, w)
+    assert 0.45 < keep.mean().item() < 0.55
+    assert (got.double() - F.leaky_relu(ref, 0.01) * keep * 2).abs().max().item() < 4e-5
+    # ReLU, no dropout; and the concat-buffer output form (skip half written as dense blocks)
+    got, _, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, act=_lib.VX_ACT_RELU, xblk=xblk)
+    assert (got.double() - F.relu(ref)).abs().max().item() < 2e-5
+    got, _, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, xblk=xblk, out_xblk=4)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    if cin == 8:   # fused 1x1x1 head with scattered slots and un-flips (expand_1_2)
+        hw = torch.from_numpy(formula_tensor((3, 8), 304, scale=0.3)).float().contiguous().to(dev())
+        hb = torch.from_numpy(formula_tensor((3,), 305, scale=0.2)).float().to(dev())
+        dst = torch.tensor([(n - 1 - i) * 2 for i in range(n)], dtype=torch.int32, device=dev())
+        flip = torch.tensor([(3 * i + 5) % 8 for i in range(n)], dtype=torch.int32, device=dev())
+        _, _, ho, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=92, layer=16,
+                                head=(hw, hb, dst, flip, 2 * n))
+        feat = F.leaky_relu(ref, 0.01) * _hash_mask(92, 16, n, 8, d, h, w) * 2
+        logits = torch.einsum("kc,ncdhw->nkdhw", hw.cpu().double(), feat) + hb.cpu().double().view(1, 3, 1, 1, 1)
+        for i in range(n):
+            dims = [ax + 1 for ax in range(3) if (int(flip[i]) >> ax) & 1]
+            want = torch.flip(logits[i], dims) if dims else logits[i]
+            assert (ho[int(dst[i])].double() - want).abs().max().item() < 4e-5, i
+        assert (ho[1::2] == -5.0).all()                       # unused slots untouched
+
+
+@pytest.mark.parametrize("cin,shape,rep,xblk,pmode", [(8, (2, 8, 16, 64), 3, 0, 1), (8, (3, 12, 8, 32), 1, 0, 1),
+                                                      (8, (2, 8, 8, 32), 2, 0, 0), (16, (2, 8, 16, 32), 1, 4, 1),
+                                                      (16, (1, 12, 8, 64), 1, 0, 1)])
+def test_conv3d_xp8_prologue_matches_oracle(cin, shape, rep, xblk, pmode):
+    """the normalise-on-load prologue (unet3D_module.py:231-237 applied to the conv's input while it is staged): n_in raw
+    tensors, each read by `rep` output samples with their own dropout pattern; for a concat input only the skip half"""
+    n_in, d, h, w = shape
+    n = n_in * rep
+    raw = torch.from_numpy(formula_tensor((n_in, 8, d, h, w), 311, scale=2.0)) + 0.7           # the raw contract-block conv output
+    up = torch.from_numpy(formula_tensor((n, 8, d, h, w), 312)) if cin == 16 else None           # up half of a concat (no prologue)
+    wt = torch.from_numpy(formula_tensor((8, cin, 3, 3, 3), 313, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((8,), 314, scale=0.2))
+    rf = raw.float()
+    mean = rf.double().mean((2, 3, 4))
+    rstd = 1.0 / torch.sqrt(rf.double().var((2, 3, 4), unbiased=False) + 1e-5)
+    meand, rstdd = mean.float().contiguous().to(dev()), rstd.float().contiguous().to(dev())
+    keep = _hash_mask(55, 1, n, 8, d, h, w) if pmode else torch.ones((n, 8, d, h, w), dtype=torch.float64)
+    norm = F.leaky_relu((rf.double() - meand.cpu().double().view(n_in, 8, 1, 1, 1)) * rstdd.cpu().double().view(n_in, 8, 1, 1, 1), 0.01)
+    skip = norm.repeat_interleave(rep, 0) * keep * (2.0 if pmode else 1.0)
+    xin = torch.cat([up.float().double(), skip], 1) if cin == 16 else skip
+    ref = F.conv3d(xin, wt.float().double(), b.float().double(), padding=1)
+    if cin == 16:
+        assert rep == 1
+        xd = (to_xblk(up.float(), rf, xblk) if xblk else cl(torch.cat([up.float(), rf], 1))).to(dev())
+    else:
+        xd = cl(rf).to(dev())
+    got, st, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, stats=(cin == 8), xblk=xblk,
+                              act=_lib.VX_ACT_NONE if cin == 8 else _lib.VX_ACT_LRELU,
+                              pre=(meand, rstdd, rep, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 55, 1))
+    want = ref if cin == 8 else F.leaky_relu(ref, 0.01)
+    err = (got.double() - want).abs().max().item()
+    assert err < 4e-5, err
+    if st is not None:
+        s = st.double().sum(1)
+        np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_conv3d_xp8_agrees_with_general_kernel_and_refuses_what_it_cannot_do(vxcfg):
+    lib = _lib.load()
+    n, d, h, w = 2, 8, 8, 64
+    x = torch.from_numpy(formula_tensor((n, 8, d, h, w), 321))
+    wt = torch.from_numpy(formula_tensor((8, 8, 3, 3, 3), 322, scale=0.07))
+    b = torch.from_numpy(formula_tensor((8,), 323, scale=0.2))
+    a1, s1, _ = run_conv(x, wt, b, stats=True)
+    vxcfg.set(s16_no_xp8=1)
+    assert lib.vx_conv3d_k3_prologue_ok(d, h, w, 8, 8) == 0
+    a0, s0, _ = run_conv(x, wt, b, stats=True)
+    assert (a1 - a0).abs().max().item() < 2e-6                 # same products, the bias enters at another point of the sum
+    assert (s1.double().sum(1) - s0.double().sum(1)).abs().max().item() < 1e-2
+    # a prologue on a layer the column kernel does not take is an error, not a silently un-normalised input
+    mean = torch.zeros((n, 8), device=dev()); rstd = torch.ones((n, 8), device=dev())
+    with pytest.raises(_lib.VxError):
+        _xp8_conv.__wrapped__ if hasattr(_xp8_conv, "__wrapped__") else None
+        a = _lib.ConvArgs()
+        xd = cl(x.float()).to(dev())
+        wp = torch.empty(lib.vx_conv3d_k3_packed_floats(8, 8), dtype=torch.float32, device=dev())
+        out = torch.empty((n, d, h, w, 8), device=dev())
+        a.w_family = lib.vx_conv3d_k3_family(8, 8)
+        a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = mean.data_ptr(); a.out = out.data_ptr()
+        a.in_pitch, a.out_pitch = 8, 8
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, 8, 8
+        a.in_mean, a.in_rstd = mean.data_ptr(), rstd.data_ptr()
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+
+
+def test_weights_packed_under_another_configuration_are_refused(vxcfg):
+    """every launch carries the kernel family its weights were packed for (w_family): a raw C-ABI caller that packs
+    under one vx_config and runs under another gets VX_E_DTYPE, not numbers from the wrong layout"""
+    lib = _lib.load()
+    x = torch.zeros((1, 8, 8, 16, 8), device=dev())
+    wt = torch.zeros((8, 8, 3, 3, 3), device=dev())
+    b = torch.zeros(8, device=dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(8, 8), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), 8, 8, _lib.stream_ptr()), "pack")
+    out = torch.empty_like(x)
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(8, 8)
+    a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch = 8, 8
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = 1, 8, 8, 16, 8, 8
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "same configuration")
+    vxcfg.set(conv_fp32=1)
+    assert lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()) == -3      # VX_E_DTYPE
+    assert b"family" in lib.vx_last_error_string()

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a wave of the split-fp16 x-pair conv kernel spends its cycles, per item, for the early (0..3) and
+late (4..7) waves (s_memtime stamps, VX_CONV_STAMPS build; nothing of this is in the product library).
+Build:  mkdir -p /tmp/stamps && cp values_amd/csrc/*.hip values_amd/csrc/*.h values_amd/csrc/*.cpp values_amd/csrc/Makefile /tmp/stamps ...
+        (tools/build_stamps.sh does it)
+Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head ...]   with VX_S16_NO_PING=1 etc. to pick the variant"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from values_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "values_amd", "libvalues_amd_stamps.so")
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+N = int(os.environ.get("STAMP_N", "160"))
+for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
+    cin, cout, edge, act, drop, head = map(int, spec.split(":"))
+    x = torch.randn((N, edge, edge, edge, cin), device=dev)
+    w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05; b = torch.zeros(cout, device=dev)
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(w), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+    out = torch.empty((N, edge, edge, edge, cout), device=dev)
+    dbg = torch.zeros((4096, 8, 8), dtype=torch.int64, device=dev)
+    os.environ["VX_CONV_DBG_PTR"] = str(dbg.data_ptr())
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+    a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout
+    a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, 1, 2
+    st = None
+    if not act:
+        st = torch.zeros((N, lib.vx_conv3d_k3_tiles(edge, edge, edge), cout, 2), device=dev)
+        a.stats_partial = st.data_ptr()
+    if head:
+        hw = torch.randn((2, cout), device=dev); hb = torch.zeros(2, device=dev)
+        ho = torch.empty((N, 2, edge, edge, edge), device=dev)
+        a.out = None
+        a.head_out, a.head_w, a.head_b, a.head_C = ho.data_ptr(), hw.data_ptr(), hb.data_ptr(), 2
+    reps = int(os.environ.get("STAMP_REPS", "200"))
+    for _ in range(reps // 2):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    d = dbg.cpu().double()
+    names = ["barrier wait", "multiply", "epilogue", "load wait", "convert+lds", "issue loads"]
+    print(f"{spec}: {ms:.4f} ms/launch at {N} samples (stamped build)")
+    for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        dd = d[:, sl]
+        used = dd[:, :, 6] > 0
+        it = dd[:, :, 6][used].mean().item()
+        tot = sum(dd[:, :, i][used].mean().item() for i in range(6))
+        print(f"  {half}: {it:.1f} items/wave, {tot/it:.0f} ticks/item (s_memtime = 100 MHz: x ~21 for shader cycles)")
+        for i, n in enumerate(names):
+            v = dd[:, :, i][used].mean().item()
+            print(f"     {n:12s} {v/it:8.1f} ticks/item  {100*v/tot:5.1f} %")

@@ -29,7 +29,9 @@ class ConvArgs(C.Structure):
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32),
                 ("drop_mask", _p), ("stats_partial", _p), ("in_xblk", _i32), ("w_family", _i32),
                 ("head_out", _p), ("head_w", _p), ("head_b", _p), ("head_dst", _p), ("head_flip", _p),
-                ("head_C", _i32)]
+                ("head_C", _i32),
+                ("in_mean", _p), ("in_rstd", _p), ("in_drop_mode", _i32), ("in_drop_seed", _u32), ("in_drop_layer", _u32),
+                ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p)]
 
 
 class NormArgs(C.Structure):
@@ -67,7 +69,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "conv_no_c8", "conv_dma", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
-        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm",
+        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_ping", "s16_no_xp8",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion", "s16_dbg", "c8_dbg", "dma_dbg", "dma_nw16", "c8_tile16",
         "s16_range_check")]
 
@@ -85,7 +87,8 @@ class UNet3DWeights(C.Structure):
 class UNet3DRun(C.Structure):
     _fields_ = [("x", _p), ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("repeat", _i32),
                 ("src", _p), ("flip", _p), ("dst", _p), ("drop_mode", _i32), ("seed", _u32),
-                ("masks", _p * 17), ("logits", _p), ("workspace", _p), ("workspace_bytes", C.c_size_t)]
+                ("masks", _p * 17), ("logits", _p), ("workspace", _p), ("workspace_bytes", C.c_size_t),
+                ("range_flag", _p)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -110,6 +113,7 @@ SIGNATURES = {
     "vx_conv3d_k3_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_tiles_for": (_i, [_i, _i, _i, _i]),
     "vx_conv3d_k3_head_fusable": (_i, [_i, _i]),
+    "vx_conv3d_k3_prologue_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -47,6 +47,8 @@ int64_t vx_conv3d_s16_packed_floats(int Cin, int Cout);
 int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s);
 bool vx_conv3d_s16_head_fusable(int Cin, int Cout);
+bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout);
+int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s);   // 1 = not taken
 void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz);
 
 struct ConvKArgs {
@@ -629,6 +631,10 @@ static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s
   return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);
 }
 
+extern "C" int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout) {
+  return vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
   const ConvCfg c = conv_config(Cin, Cout);
@@ -655,7 +661,11 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.w_family != vx_conv3d_k3_family(a.Cin, a.Cout))
     VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: weights packed for kernel family %d, the library is configured for family %d "
             "(vx_conv3d_k3_family(%d, %d)): re-pack them", a.w_family, vx_conv3d_k3_family(a.Cin, a.Cout), a.Cin, a.Cout);
-  if (a.out && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
+  if (a.out_xblk && ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || a.W % a.out_xblk || (a.out_half != 0 && a.out_half != 1)))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: bad concat output (xblk=%d, half=%d, W=%d)", a.out_xblk, a.out_half, a.W);
+  if ((a.in_mean == nullptr) != (a.in_rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: in_mean / in_rstd must come together");
+  if (a.in_drop_mode != VX_DROP_NONE && a.in_drop_mode != VX_DROP_HASH) VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: in_drop_mode %d", a.in_drop_mode);
+  if (a.out && !a.out_xblk && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
   if (a.in_xblk) {
     if (a.in_xblk != 1 && a.in_xblk != 2 && a.in_xblk != 4) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: in_xblk must be 0, 1, 2 or 4");
@@ -689,7 +699,16 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   hipStream_t s = (hipStream_t)stream;
-  if (c.C8) return vx_conv3d_k3_c8(a, t.TXV, t.TY, t.TZ, s);
+  if (c.C8 && !a.in_mean && !a.out_xblk) return vx_conv3d_k3_c8(a, t.TXV, t.TY, t.TZ, s);
+  if (c.S16 && vx_conv3d_xp8_applies(a.D, a.H, a.W, a.Cin, a.Cout) && a.drop_mode != VX_DROP_MASK &&
+      a.in_drop_mode != VX_DROP_MASK) {
+    // the full-resolution layers: z-column walk with a rolling LDS window (conv3d_xp8.hip)
+    const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
+    if (rc != 1) return rc;
+  }
+  if (a.in_mean || a.out_xblk)
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output are only available where "
+            "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);
   {
     const int rc = vx_conv3d_k3_try_dma(a, s);   // opt-in (VX_CONV_DMA=1) LDS-DMA schedule; 1 = not taken

@@ -26,12 +26,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-#define VX_NUMREC 0xFFFFF000u
-#define VX_OOB 0xFFFFF800u
+#include "s16_common.h"
 
 struct ConvSArgs {
   vx_conv3d_args a;
@@ -41,59 +36,26 @@ struct ConvSArgs {
   int ty8;   // 16 x 8 x 4 tiles (vx_conv3d_s16_tile)
   int w_all; // every chunk's weights fit in LDS next to the image: staged once, never re-staged per item
   int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
+  unsigned long long* stamps;   // VX_CONV_STAMPS diagnostic builds only: per wave, cycles spent per phase
 };
 
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// x -> (hi, lo) with x = hi + lo * 2^-11 (see the header).  Two elements at a time: one v_cvt_pk_f16_f32, one
-// v_pk_mul_f32 and a mixed-precision fma per element -- 8 VALU instructions per 16-byte piece.  No clamping: |x| >= 65520 turns into inf and the output into NaN -- loud, and
-// out of reach for activations that went through InstanceNorm / a dropout-scaled LeakyReLU.
-__device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
-#pragma unroll
-  for (int j = 0; j < 4; j += 2) {
-    const f32x2 x = {v[j], v[j + 1]};
-    const f16x2 h = __builtin_convertvector(x, f16x2);
-#ifdef VX_SPLIT_PLAIN
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
+// Phase stamps of the item loop (diagnostic build -DVX_CONV_STAMPS, tools/stamp_s16.py): s_memtime deltas summed per
+// wave into st_sum[phase]; the values go to a buffer of their own, never into an output.
+#ifdef VX_CONV_STAMPS
+#define VX_STAMP(i)                                                                      \
+  do {                                                                                   \
+    unsigned long long t_;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    st_sum[i] += t_ - st_last;                                                           \
+    st_last = t_;                                                                        \
+  } while (0)
+#define VX_STAMP_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
-    // lo = fp16(2048 x - 2048 hi) as one mixed-precision fma per element, reading hi as the fp16 it is and writing
-    // the fp16 half directly: 8 instead of 14 VALU instructions per 16-byte piece, the same bits (2048 x, 2048 hi
-    // and their difference are all exact in fp32; tools/micro/split_mix.hip compares the two forms)
-    const f32x2 xs = x * 2048.f;
-    const float m2048 = -2048.f;
-    const uint32_t hv = __builtin_bit_cast(uint32_t, h);
-    uint32_t lv = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[1]));
-    const f16x2 l = __builtin_bit_cast(f16x2, lv);
+#define VX_STAMP(i) do {} while (0)
+#define VX_STAMP_WAIT_LOADS() do {} while (0)
 #endif
-    hi[j] = h[0]; hi[j + 1] = h[1];
-    lo[j] = l[0]; lo[j + 1] = l[1];
-  }
-}
-
-// x + (x of lane ^ 16): two copies, v_permlane16_swap_b32 exchanges row 1 of the first with row 0 of the second (and
-// row 3 with row 2), so a = [r0, r0, r2, r2], b = [r1, r1, r3, r3] -- no LDS-queue ds_bpermute as __shfl_xor(x, 16) takes
-// (tools/micro/permlane_swap.hip); the same bits as x + __shfl_xor(x, 16)
-__device__ __forceinline__ float vx_add_xor16(float x) {
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-
-// lane i of every 16-lane row <- lane (i + rot) % 16 of the same row
-__device__ __forceinline__ float vx_row_ror(float x, int rot) {
-  const int v = __builtin_bit_cast(int, x);
-  int r;
-  switch (rot) {
-    case 8: r = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); break;
-    case 4: r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); break;
-    case 2: r = __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, true); break;
-    default: r = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, true); break;
-  }
-  return __builtin_bit_cast(float, r);
-}
 
 // XP (Cout == 8, CB == 8): x-pair packing as in conv3d_mfma.hip -- rows = (dx, cout), columns = voxel pairs
 // (x = 2p, 2p + 1), a K = 32 step = one (kz, ky) row with the four x-offsets ix = 0..3 as the four k-groups
@@ -113,8 +75,9 @@ __device__ __forceinline__ float vx_row_ror(float x, int rot) {
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
-  constexpr bool SINGLE = DB == 1 || DB == 2;      // double-buffered, every item a whole tile (one chunk)
-  constexpr bool STAG = DB >= 2;                   // staggered waves (DB = 3: also for several chunks per tile)
+  constexpr bool SINGLE = DB == 1 || DB == 2 || DB == 4;   // double-buffered, every item a whole tile (one chunk)
+  constexpr bool STAG = DB == 2 || DB == 3;        // staggered waves (DB = 3: also for several chunks per tile)
+  constexpr bool PING = DB >= 4;                   // ping-pong halves (DB = 5: several chunks per tile), see below
   constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
   constexpr int NVT = TX * TY * TZ / 16;
   constexpr int R = NVT / NW;
@@ -520,56 +483,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     }
   };
 
-  // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
-  // one): waves 4..7 run the epilogue of item k after the barrier of item k + 1, so their stores and statistics
-  // overlap the MFMA loop of waves 0..3 and vice versa instead of every wave hitting the same phase together.
-  const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
-  int red_cur = 0, red_prev = 0, prev_tile = 0;
-  bool have_prev = false;
-  // DB: item 0 goes into image 0 before the loop, item 1's loads are in flight
-  int db_cur = 0, db_ntile = 0, db_nchunk = 0;   // the item whose loads are in flight
-  bool db_nhave = false;
-  if constexpr (DB != 0) {
-    commit(w_fresh, 0);
-    w_fresh = false;
-    db_ntile = tile_lin; db_nchunk = 1;
-    if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = tile_lin + (int)gridDim.x; }
-    db_nhave = db_ntile < total;
-    prefetch(db_ntile, db_nchunk, db_nhave, false);
-  }
-
-  while (have) {
-    int ntile, nchunk;
-    bool nhave;
-    int cofs = 0;    // halves offset of the image this item reads
-    if constexpr (DB != 0) {
-      __syncthreads();       // image db_cur is complete; everyone is done reading image db_cur ^ 1
-      flush_stats();
-      if constexpr (STAG) {
-        if (late && have_prev) { epilogue(prev_tile, red_prev); have_prev = false; }
-      }
-      ntile = db_ntile; nchunk = db_nchunk; nhave = db_nhave;   // the next item: its loads are in flight
-      db_nchunk = nchunk + 1; db_ntile = ntile;                  // and the one after it
-      if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = ntile + (int)gridDim.x; }
-      db_nhave = db_ntile < total;
-      cofs = db_cur * BUF_H;
-      db_cur ^= 1;
-      if (!late) {
-        if (nhave) commit(false, db_cur * BUF_H);                // next item -> the other image (waits for its loads)
-        prefetch(db_ntile, db_nchunk, db_nhave, false);          // the item after next -> registers
-      }
-    } else {
-      if (ka.dbg < 3) __syncthreads();
-      flush_stats();
-      if (ka.dbg < 2) commit(w_fresh);
-      if (ka.dbg < 3) __syncthreads();
-      w_fresh = !w_resident;
-      ntile = tile_lin; nchunk = chunk + 1;
-      if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
-      nhave = ntile < total;
-      if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
-    }
-    const _Float16* s_wc = s_w + (ka.w_all ? chunk * W_H : 0);   // this item's weights
+  // ---- the multiply phase of one item: image at halves offset cofs, weights of chunk ck ----
+  auto multiply = [&](int cofs, int ck) {
+    const _Float16* s_wc = s_w + (ka.w_all ? ck * W_H : 0);   // this item's weights
 
     if constexpr (XP == 1 && TX == 16 && TY % R == 0) {
       // ---- x-pair, a wave's R column tiles are R consecutive y-rows of one z: the input row (z + kz, y) is the
@@ -635,10 +551,163 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       }
     }
 
+  };
+
+  // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
+  // one): waves 4..7 run the epilogue of item k after the barrier of item k + 1, so their stores and statistics
+  // overlap the MFMA loop of waves 0..3 and vice versa instead of every wave hitting the same phase together.
+  const bool late = (STAG || PING) && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+  int red_cur = 0, red_prev = 0, prev_tile = 0;
+  bool have_prev = false;
+  // DB: item 0 goes into image 0 before the loop, item 1's loads are in flight
+  int db_cur = 0, db_ntile = 0, db_nchunk = 0;   // the item whose loads are in flight
+  bool db_nhave = false;
+  if constexpr (DB != 0) {
+    commit(w_fresh, 0);
+    w_fresh = false;
+    db_ntile = tile_lin; db_nchunk = 1;
+    if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = tile_lin + (int)gridDim.x; }
+    db_nhave = db_ntile < total;
+    prefetch(db_ntile, db_nchunk, db_nhave, false);
+  }
+
+  // PING (DB = 4 / 5): the two waves of a SIMD (w and w + 4) ALTERNATE between the matrix phase and everything else.
+  // Two phases per item, one barrier each:
+  //      phase A                                   | phase B
+  //   waves 0..3:  multiply(k)                     | epilogue(k), stage(k + 1) -> other image, loads(k + 2)
+  //   waves 4..7:  epilogue(k - 1), stage(k + 1),  | multiply(k)
+  //                loads(k + 2)                    |
+  // so on every SIMD one wave feeds the matrix pipe while its partner converts / stores / loads (the pairing of
+  // MI355X_MICROARCH.md "Two waves per SIMD": matrix beside memory, never matrix beside matrix).  In the staggered
+  // variant (DB = 2 / 3) both waves still ran their multiply phases at the same time -- the pipe was shared for the
+  // 108 MFMAs of an item and idle while both converted.  Image k + 1 is written by waves 4..7 in phase A and by waves
+  // 0..3 in phase B of item k, complete at the end of item k; image k is read in both phases.
+#ifdef VX_CONV_STAMPS
+  // phases: 0 barrier wait, 1 multiply, 2 epilogue, 3 wait for the prefetched loads, 4 convert + LDS write, 5 issue loads
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_iters = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  auto st_flush = [&]() {
+    if (ka.stamps && lane == 0) {
+      unsigned long long* d = ka.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+      for (int i = 0; i < 6; ++i) d[i] = st_sum[i];
+      d[6] = st_iters;
+    }
+  };
+#endif
+  if constexpr (PING) {
+    __syncthreads();           // image 0 (and resident weights) visible
+    int fl_n = -1, fl_tile = 0, fl_red = 0;   // tile whose statistics slots are complete after the next phase A
+    VX_STAMP(0);
+    while (have) {
+      const int ntile = db_ntile, nchunk = db_nchunk;
+      const bool nhave = db_nhave;
+      db_nchunk = nchunk + 1; db_ntile = ntile;
+      if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = ntile + (int)gridDim.x; }
+      db_nhave = db_ntile < total;
+      const int cofs = db_cur * BUF_H;
+      db_cur ^= 1;
+      const bool last = chunk == ka.nchunks - 1;
+      // ---------------- phase A ----------------
+      if (!late) {
+        multiply(cofs, chunk);
+        VX_STAMP(1);
+      } else {
+        if (have_prev) { epilogue(prev_tile, red_prev); have_prev = false; }
+        VX_STAMP(2);
+        VX_STAMP_WAIT_LOADS();
+        VX_STAMP(3);
+        if (nhave) commit(false, db_cur * BUF_H);
+        VX_STAMP(4);
+        prefetch(db_ntile, db_nchunk, db_nhave, false);
+        VX_STAMP(5);
+      }
+      __syncthreads();
+      VX_STAMP(0);
+      // ---------------- phase B ----------------
+      if (!late) {
+        flush_one(fl_n, fl_tile, fl_red);     // waves 4..7 left their part of that tile in phase A
+        fl_n = -1;
+        if (last) {
+          pendB_n = -1;
+          epilogue(tile_lin, red_cur);
+          fl_n = pendB_n; fl_tile = pendB_tile; fl_red = red_cur;
+        }
+        VX_STAMP(2);
+        VX_STAMP_WAIT_LOADS();
+        VX_STAMP(3);
+        if (nhave) commit(false, db_cur * BUF_H);
+        VX_STAMP(4);
+        prefetch(db_ntile, db_nchunk, db_nhave, false);
+        VX_STAMP(5);
+      } else {
+        multiply(cofs, chunk);
+        VX_STAMP(1);
+        if (last) { prev_tile = tile_lin; have_prev = true; red_prev = red_cur; }
+      }
+      if (last) red_cur = red_cur == 2 * RED_F ? 0 : red_cur + RED_F;
+      __syncthreads();
+      VX_STAMP(0);
+#ifdef VX_CONV_STAMPS
+      ++st_iters;
+#endif
+      tile_lin = ntile; chunk = nchunk; have = nhave;
+    }
+    if (late && have_prev) epilogue(prev_tile, red_prev);
+    __syncthreads();
+    flush_one(fl_n, fl_tile, fl_red);
+#ifdef VX_CONV_STAMPS
+    st_flush();
+#endif
+    return;
+  }
+
+  while (have) {
+    int ntile, nchunk;
+    bool nhave;
+    int cofs = 0;    // halves offset of the image this item reads
+    if constexpr (DB != 0) {
+      __syncthreads();       // image db_cur is complete; everyone is done reading image db_cur ^ 1
+      VX_STAMP(0);
+      flush_stats();
+      if constexpr (STAG) {
+        if (late && have_prev) { epilogue(prev_tile, red_prev); have_prev = false; }
+        VX_STAMP(2);
+      }
+      ntile = db_ntile; nchunk = db_nchunk; nhave = db_nhave;   // the next item: its loads are in flight
+      db_nchunk = nchunk + 1; db_ntile = ntile;                  // and the one after it
+      if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = ntile + (int)gridDim.x; }
+      db_nhave = db_ntile < total;
+      cofs = db_cur * BUF_H;
+      db_cur ^= 1;
+      if (!late) {
+        VX_STAMP_WAIT_LOADS();
+        VX_STAMP(3);
+        if (nhave) commit(false, db_cur * BUF_H);                // next item -> the other image (waits for its loads)
+        VX_STAMP(4);
+        prefetch(db_ntile, db_nchunk, db_nhave, false);          // the item after next -> registers
+        VX_STAMP(5);
+      }
+    } else {
+      if (ka.dbg < 3) __syncthreads();
+      flush_stats();
+      if (ka.dbg < 2) commit(w_fresh);
+      if (ka.dbg < 3) __syncthreads();
+      w_fresh = !w_resident;
+      ntile = tile_lin; nchunk = chunk + 1;
+      if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
+      nhave = ntile < total;
+      if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+    }
+    multiply(cofs, chunk);
+    VX_STAMP(1);
     if constexpr (STAG) {   // waves 4..7 stage the next item after their MFMA loop: E M C against C M E of waves 0..3
       if (late) {
+        VX_STAMP_WAIT_LOADS();
+        VX_STAMP(3);
         if (nhave) commit(false, db_cur * BUF_H);
+        VX_STAMP(4);
         prefetch(db_ntile, db_nchunk, db_nhave, false);
+        VX_STAMP(5);
       }
     }
     if (ka.dbg >= 1) {
@@ -657,6 +726,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         if constexpr (DB == 1) red_cur ^= RED_F;
       }
     }
+    VX_STAMP(2);
+#ifdef VX_CONV_STAMPS
+    ++st_iters;
+#endif
     tile_lin = ntile; chunk = nchunk; have = nhave;
   }
   if constexpr (STAG) {
@@ -665,6 +738,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   __syncthreads();
   flush_stats();
   if constexpr (STAG) flush_stats();
+#ifdef VX_CONV_STAMPS
+  st_flush();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,7 +811,7 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
   constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * (XP ? 32 : 64) * 8 * 2;
   constexpr size_t red = (size_t)(DB >= 2 ? 3 : DB + 1) * NW * NT * 16 * 2 * 4;
-  static_assert((DB ? 2 : 1) * img + (DB == 3 ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
+  static_assert((DB ? 2 : 1) * img + ((DB == 3 || DB == 5) ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
   ka.w_all = DB ? (ka.nchunks > 1 ? 1 : 0)   // double-buffered variants: the dispatch made sure everything fits
                 : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0);
@@ -773,6 +849,16 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
     else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
   }
   if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
+    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_ping) {
+      if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 0>(ka, s);
+      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 1>(ka, s);
+      if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 2>(ka, s);
+      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 3>(ka, s);
+    }
+    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3 && !vx_cfg().s16_no_ping) {
+      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 1>(ka, s);
+      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 3>(ka, s);
+    }
     if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
@@ -834,6 +920,10 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.dbg = vx_cfg().s16_dbg;
+  ka.stamps = nullptr;
+#ifdef VX_CONV_STAMPS
+  if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
   ka.ty8 = ty8;
   if (c.XP) return dispatch_s16<8, 1, 1>(ka, tx, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1, 0>(ka, tx, s);

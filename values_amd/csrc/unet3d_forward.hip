@@ -140,9 +140,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   auto xblk_of = [](int W) { return W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1); };
   // head fusion: where the last 3x3x3 conv runs on the kernel that holds a voxel's channels in one lane
   const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !vx_cfg().no_head_fusion;
+  // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
+  // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
-                  int Cout, int act, int drop_layer, float* stats, int in_xblk) {
-    vx_conv3d_args a;
+                  int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1) {
+    vx_conv3d_args a = {};
     a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
     if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
       a.head_out = r->logits; a.head_w = w->final_w; a.head_b = w->final_b; a.head_C = NC;
@@ -159,6 +161,12 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
     a.drop_mask = drop_layer >= 0 ? mask(drop_layer) : nullptr;
     a.stats_partial = stats;
+    if (pre_layer >= 0) {
+      a.in_mean = p.mean; a.in_rstd = p.rstd;
+      a.in_drop_mode = dm; a.in_drop_seed = r->seed; a.in_drop_layer = (uint32_t)pre_layer;
+      a.in_repeat = pre_rep;
+    }
+    a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     return vx_conv3d_k3(&a, stream);
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
@@ -201,22 +209,28 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const Level& L = p.lv[l];
     const int C = L.C;
     int ntiles;
+    int pre_layer = -1, pre_rep = 1;       // contr_l_2 normalises its own input (no separate pass over A_l)
+    const float* in2 = p.A[l];
     if (l == 0) {
       ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
       const int rep = r->repeat > 0 ? r->repeat : 1;
+      const bool fuse_norm = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && vx_conv3d_k3_prologue_ok(L.D, L.H, L.W, C, C);
       if (!r->src && !r->flip && rep > 1 && N % rep == 0) {
         // MC-dropout: the T samples of a volume share this conv and its statistics -> once per volume into a
-        // scratch (CAT_0 is free until contr_1_2's norm), fanned out by the norm kernel
+        // scratch (CAT_0 is free until contr_1_2's norm); contr_1_2 reads that scratch with T dropout patterns, or
+        // (general kernels) the norm kernel fans it out
         const int V = N / rep;
         VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.CAT[0], C, V, L.D, L.H, L.W, C, 1, nullptr,
                                           nullptr, p.stats, stream));
         VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0));
+        if (fuse_norm) { in2 = p.CAT[0]; pre_layer = 0; pre_rep = rep; }
+        else VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0));
       } else {
         VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, rep, r->src,
                                           r->flip, p.stats, stream));
         VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1, 0));
+        if (fuse_norm) pre_layer = 0;
+        else VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1, 0));
       }
     } else {
       ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
@@ -225,7 +239,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
     }
     ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
-    VX_STEP(kConv[2 * l + 1], conv(p.A[l], C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0));
+    VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep));
     VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
     VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1, xblk_of(L.W)));
   }

@@ -138,7 +138,8 @@ def failure_detection(exp_dataloader):
 
 # ------------------------------------------------------------------------------------------------ ambiguity modelling
 def compute_ncc(gt_unc_map, pred_unc_map):
-    """ncc.py:9-25 on the device: float64, numpy's two-pass moments."""
+    """ncc.py:9-25 on the device: numpy's two-pass moments, in float64 whatever the maps' dtype (numpy works in the
+    dtype of the map: a float32 map read back from NIfTI gives the reference a float32-rounded value, ~1e-7 away)."""
     lib, dev = _lib.load(), _dev()
     g, gd = _float_map(gt_unc_map, dev)
     p, pd = _float_map(pred_unc_map, dev)

@@ -71,7 +71,7 @@ typedef struct vx_config {
   int32_t conv_dma;       /* fp32 mode: LDS-DMA double-buffered schedule (conv3d_dma.hip) */
   int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
   int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
-  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_no_ping, s16_no_xp8;
+  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_ping, s16_no_xp8;
   int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
   int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
@@ -235,6 +235,7 @@ typedef struct vx_convT_args {
   int32_t N, D, H, W, Cin, Cout; /* input dims; output is 2D x 2H x 2W */
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* mask [N][2D][2H][2W][Cout] */
   int32_t out_xblk, out_half; /* as in vx_norm_args: write half out_half of a concat buffer */
+  uint32_t* range_flag;       /* nullable: as in vx_conv3d_args (matrix-core kernels only: Cin in {16,32,64,128}) */
 } vx_convT_args;
 int vx_convT_k2s2(const vx_convT_args* a, vx_stream_t stream);
 

@@ -568,3 +568,37 @@ def test_variance_rides_in_the_reduction_pass():
     small = want < 1e-8
     if small.any():
         assert np.abs(got[small] - want[small]).max() < 1e-10
+
+
+def test_fp16_range_guard_never_returns_nan_maps():
+    """Decoder blocks have no norm (unet3D_module.py:263-267), so a checkpoint can drive their activations past what the
+    split-fp16 convolutions represent (65504).  Here the center's transposed conv is scaled up until that happens: the
+    kernels' range word reports it, "raise" raises, the default re-runs the batch on the native-fp32 kernels -- finite
+    maps equal to the float64 oracle's either way."""
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import unet3d_forward
+    from values_amd import UNet3D, _lib, predict_uncertainty
+    sd = formula_unet3d_state_dict(seed_tag=2)
+    sd["center.4.weight"] = sd["center.4.weight"] * 3e6
+    model = UNet3D(num_classes=2, do_dropout=False)
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    model = model.cuda()
+    x = torch.from_numpy(formula_volume((2, 1, 16, 16, 16), tag=95))
+    with torch.no_grad():
+        taps = {}
+        ref = unet3d_forward({k: torch.from_numpy(v).float().double() for k, v in sd.items()}, x, taps=taps)
+    assert taps["center"].abs().max().item() > 65504          # the oracle's own activations are past the limit
+    with pytest.raises(_lib.VxError):
+        predict_uncertainty([model], x.float().cuda(), n_pred=1, range_check="raise")
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=1)           # default: fallback to the fp32 kernels
+    assert torch.isfinite(out["logits"]).all()
+    lg = out["logits"][:, 0].cpu().double()
+    assert ((lg - ref).abs() / (1.0 + ref.abs())).max().item() < 1e-4
+    sm = uo.softmax(ref.numpy()[:, None], axis=2)
+    for v in range(2):
+        r = uo.calculate_uncertainty(sm[v])
+        assert np.abs(out["pred_entropy"][v].cpu().numpy() - r["pred_entropy"]).max() < MAP_TOL
+    # an ordinary checkpoint stays far below the limit and takes no second pass
+    ok = make_model(do_dropout=True)
+    predict_uncertainty([ok], x.float().cuda(), n_pred=3, seeds=[1])
+    assert 0 < ok.range_max() < 1e3

@@ -343,6 +343,15 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     pendB_n = -1;
   };
 
+  float rmax = 0.f;   // largest |value| this lane stored (range guard of the split-fp16 consumers, vx_conv3d_args.range_flag)
+  auto range_out = [&]() {
+    if (a.range_flag) {
+      float mx = rmax;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      if (lane == 0 && mx > 0.f) atomicMax(a.range_flag, __float_as_uint(mx));
+    }
+  };
   // ---- epilogue of item tl (conv3d_mfma.hip); its statistics go to the s_red slots at redo ----
   auto epilogue = [&](int tl, int redo) {
     // ---- epilogue (conv3d_mfma.hip) ----
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
+    const bool f_range = a.range_flag != nullptr;
 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
           }
         }
         if (f_store) {
+          if (f_range && !bad) rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
           // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     if (late && have_prev) epilogue(prev_tile, red_prev);
     __syncthreads();
     flush_one(fl_n, fl_tile, fl_red);
+    range_out();
 #ifdef VX_CONV_STAMPS
     st_flush();
 #endif
@@ -738,6 +750,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   __syncthreads();
   flush_stats();
   if constexpr (STAG) flush_stats();
+  range_out();
 #ifdef VX_CONV_STAMPS
   st_flush();
 #endif
@@ -849,13 +862,13 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
     else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
   }
   if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
-    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_ping) {
+    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db && vx_cfg().s16_ping) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 1>(ka, s);
       if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 2>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 3>(ka, s);
     }
-    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3 && !vx_cfg().s16_no_ping) {
+    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3 && vx_cfg().s16_ping) {
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 1>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 3>(ka, s);
     }

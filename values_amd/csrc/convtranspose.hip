@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
   }
   const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;   // x-block size is 1, 2 or 4
   const int wstride = (int)gridDim.x * 4;
+  float rmax = 0.f;   // range guard of the split-fp16 consumer (vx_convT_args.range_flag)
   for (int ct = blockIdx.x * 4 + wave; ct < ncoltiles; ct += wstride) {
     const int v = ct * 16 + m;                 // flattened input voxel of this lane's column
     const bool ok = v < nvox_in;
@@ -228,8 +229,16 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
              ((((ox >> xs) * 2 + a.out_half) << xs) + (ox & (a.out_xblk - 1))) * a.Cout + oco[rt];
       else
         op = a.out + (orow * OW + ox) * a.out_pitch + a.out_coff + oco[rt];
-      if (ok) *reinterpret_cast<f32x4*>(op) = acc;
+      if (ok) {
+        *reinterpret_cast<f32x4*>(op) = acc;
+        rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+      }
     }
+  }
+  if (a.range_flag) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+    if (lane == 0 && rmax > 0.f) atomicMax(a.range_flag, __float_as_uint(rmax));
   }
 }
 

@@ -62,7 +62,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_ty8 = env_int("VX_S16_NO_TY8", 0);
   g_cfg.s16_no_wall = env_int("VX_S16_NO_WALL", 0);
   g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
-  g_cfg.s16_no_ping = env_int("VX_S16_NO_PING", 0);
+  g_cfg.s16_ping = env_int("VX_S16_PING", 0);
   g_cfg.s16_no_xp8 = env_int("VX_S16_NO_XP8", 0);
   g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
   g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);

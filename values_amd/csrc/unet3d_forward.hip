@@ -183,7 +183,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   };
   auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
                    int drop_layer) {
-    vx_convT_args a;
+    vx_convT_args a = {};
+    a.range_flag = r->range_flag;
     a.out_xblk = xblk_of(2 * Lin.W); a.out_half = 0;
     a.in = in; a.in_pitch = Cin; a.w_packed = w->up_w[ui]; a.bias = w->up_b[ui];
     a.out = out; a.out_pitch = out_pitch; a.out_coff = 0;

@@ -180,12 +180,23 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
 @torch.no_grad()
 def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
                         x_noise: Optional[torch.Tensor] = None, ssn: bool = False, want_sample_argmax: bool = False,
-                        **kw) -> Dict[str, torch.Tensor]:
+                        range_check: str = "fallback", **kw) -> Dict[str, torch.Tensor]:
     """Forward passes + fused reduction.  Returns device tensors keyed like the reference's results:
     pred_entropy / aleatoric_uncertainty / epistemic_uncertainty (V,D,H,W) f32 (test_3D.py:509-516),
     mean_softmax (V,C,D,H,W), pred_seg_mean (V,D,H,W) u8 (data_carrier_3D.py:254-255), logits; plus
     softmax_variance (V,D,H,W) f32 -- the north star's fourth map, from the same pass over the logits (no reference
-    counterpart)."""
+    counterpart).
+    range_check: the split-fp16 convolutions represent activations below 65504; every kernel that feeds them an
+    un-normalised tensor records the largest magnitude it stored (UNet3D.range_max).  "fallback" (default): read that
+    word after the batch (one synchronisation) and, if the limit was reached, compute the batch again on the native-fp32
+    kernels -- NaN maps never leave this function; "raise": VxError instead; "off": no read (pipelined callers check
+    model.check_range() themselves, the word keeps the running maximum)."""
+    if range_check not in ("fallback", "raise", "off"):
+        raise ValueError("range_check must be 'fallback', 'raise' or 'off'")
+    if range_check != "off":
+        for mdl in models:
+            if hasattr(mdl, "range_max"):
+                mdl.range_max(reset=True)
     m = None
     one_batch = (hasattr(models[0], "rank") and hasattr(models[0], "cov_factor_conv")) or \
         (bool(getattr(models[0], "aleatoric_loss", False)) and not tta)      # SSN / aleatoric head: no volume chunks
@@ -215,6 +226,15 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
         out["epistemic_uncertainty"] = m["expected_entropy"]
     if want_sample_argmax:
         out["pred_seg"] = m["sample_argmax"]
+    if range_check != "off" and _lib.get_config().conv_fp32 == 0:
+        worst = max([mdl.range_max(reset=True) for mdl in models if hasattr(mdl, "range_max")] or [0.0])
+        if not worst < 65504.0:
+            if range_check == "raise":
+                raise _lib.VxError(f"predict_uncertainty: an activation of magnitude {worst:.4g} reached a split-fp16 "
+                                   "convolution (limit 65504)")
+            with _lib.config(conv_fp32=1):     # the native-fp32 matrix kernels: no range limit (weights re-pack per family)
+                return predict_uncertainty(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, ssn=ssn,
+                                           want_sample_argmax=want_sample_argmax, range_check="off", **kw)
     return out
 
 

@@ -84,6 +84,7 @@ class UNet3D(nn.Module):
         self.output_reconstruction_map = nn.Conv3d(f, out_channels=1, kernel_size=1)
         self._packed = None
         self._packed_key = None
+        self._range = {}      # device -> int32 word: running maximum |activation| handed to a split-fp16 conv (bit pattern)
         self._ws = {}
         self._calls = 0
         self.seed = 123  # reference default seed (configs/dropout_config.yaml:8); set_seed analogue
@@ -154,6 +155,26 @@ class UNet3D(nn.Module):
         ws = ent[1]
         off = (-ws.data_ptr()) % 256
         return ws, off, ws.numel() - 256
+
+    FP16_MAX = 65504.0
+
+    def range_max(self, reset: bool = False) -> float:
+        """Largest |activation| an un-normalised layer (center, decoder, transposed convs) has handed to a split-fp16
+        convolution since the last reset, over all forwards of this model (a device word the kernels raise with an atomic
+        max; reading it synchronises).  At or beyond 65504 the fp16 split of that value overflowed: the logits of that
+        forward are invalid.  The native-fp32 kernels (vx_config.conv_fp32 = 1) have no such limit."""
+        worst = 0.0
+        for flag in self._range.values():
+            worst = max(worst, float(flag.view(torch.float32).item()))
+            if reset:
+                flag.zero_()
+        return worst
+
+    def check_range(self, reset: bool = True):
+        m = self.range_max(reset=reset)
+        if not m < self.FP16_MAX:        # also catches NaN
+            raise _lib.VxError(f"values_amd.UNet3D: an activation of magnitude {m:.4g} reached a split-fp16 convolution "
+                               f"(limit {self.FP16_MAX}); re-run under _lib.config(conv_fp32=1)")
 
     def dropout_layer_shapes(self, D, H, W):
         """[(channels, (d, h, w))] of the 17 dropout layers in DROPOUT_ORDER for a (D, H, W) input."""
@@ -236,6 +257,10 @@ class UNet3D(nn.Module):
             run.seed = int(seed) & 0xFFFFFFFF
         else:
             run.drop_mode = _lib.VX_DROP_NONE
+        flag = self._range.get(str(dev))
+        if flag is None:
+            flag = self._range[str(dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
+        run.range_flag = flag.data_ptr()
         run.logits = out.data_ptr()
         run.workspace = ws.data_ptr() + off
         run.workspace_bytes = ws_bytes

@@ -153,7 +153,7 @@ def roofline_leg(model, x, T, reps=3):
     sec = a["ms"] * 1e-3
     tflops = a["flops"] / sec / 1e12
     gbs = a["bytes"] / sec / 1e9
-    split = "s16" in name
+    split = "s16" in name or "xp8" in name
     mpeak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     t_mfma = a["flops"] / (mpeak * 1e12)
     t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)

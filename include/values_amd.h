@@ -71,7 +71,7 @@ typedef struct vx_config {
   int32_t conv_dma;       /* fp32 mode: LDS-DMA double-buffered schedule (conv3d_dma.hip) */
   int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
   int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
-  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_ping, s16_no_xp8;
+  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_ping, s16_no_xp8, s16_skip_raw;
   int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
   int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
@@ -183,6 +183,9 @@ typedef struct vx_conv3d_args {
   int32_t out_xblk, out_half; /* out_xblk > 0: `out` is a concat buffer, this conv writes its half out_half (as vx_norm_args) */
   uint32_t* range_flag; /* nullable device word: atomic max of the bit patterns of |stored values| (fp16 range guard of
                            the split-fp16 consumers: anything >= 65504 must not reach them) */
+  const uint32_t* seed_dev; /* nullable device word ADDED to drop_seed / in_drop_seed at run time (a captured hipGraph
+                               replays with the arguments it was captured with; fresh dropout bits per replay = update
+                               this word).  Same field in vx_norm_args / vx_convT_args / vx_unet3d_run. */
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
@@ -219,6 +222,11 @@ typedef struct vx_norm_args {
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask;
   int32_t out_xblk, out_half; /* out_xblk > 0: `out` is a concat buffer (xb = out_xblk), this kernel writes half
                                  out_half (0 = up, 1 = skip); out_pitch / out_coff are then ignored */
+  int32_t x_xblk, x_half;     /* x_xblk > 0: `x` is half x_half of a concat buffer (a conv that wrote its raw output
+                                 straight into the skip half); x_pitch is then ignored.  With pool_out set, `out` may be
+                                 NULL: only the pooled tensor is produced (the consumer conv normalises the skip half
+                                 itself, vx_conv3d_args.in_mean) */
+  const uint32_t* seed_dev;   /* as in vx_conv3d_args */
 } vx_norm_args;
 int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
 /* Same, but sample n of the OUTPUT reads sample n / x_repeat of x / mean / rstd: the T MC-dropout samples of a
@@ -236,6 +244,7 @@ typedef struct vx_convT_args {
   int32_t act, drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* mask [N][2D][2H][2W][Cout] */
   int32_t out_xblk, out_half; /* as in vx_norm_args: write half out_half of a concat buffer */
   uint32_t* range_flag;       /* nullable: as in vx_conv3d_args (matrix-core kernels only: Cin in {16,32,64,128}) */
+  const uint32_t* seed_dev;   /* as in vx_conv3d_args */
 } vx_convT_args;
 int vx_convT_k2s2(const vx_convT_args* a, vx_stream_t stream);
 
@@ -280,6 +289,7 @@ typedef struct vx_unet3d_run {
                             |activation| an un-normalised layer handed to a split-fp16 convolution; >= 65504.0f means
                             the fp16 split overflowed somewhere and the logits must not be used (re-run with
                             vx_config.conv_fp32 = 1, the native-fp32 kernels have no such limit) */
+  const uint32_t* seed_dev; /* nullable device word added to `seed` by every kernel (graph replays with fresh dropout) */
 } vx_unet3d_run;
 
 size_t vx_unet3d_workspace_bytes(int N, int D, int H, int W, int F);

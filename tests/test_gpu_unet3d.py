@@ -579,7 +579,7 @@ def test_fp16_range_guard_never_returns_nan_maps():
     from oracle.unet3d_oracle import unet3d_forward
     from values_amd import UNet3D, _lib, predict_uncertainty
     sd = formula_unet3d_state_dict(seed_tag=2)
-    sd["center.4.weight"] = sd["center.4.weight"] * 3e6
+    sd["center.4.weight"] = sd["center.4.weight"] * 3e7
     model = UNet3D(num_classes=2, do_dropout=False)
     model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
     model = model.cuda()
@@ -600,5 +600,54 @@ def test_fp16_range_guard_never_returns_nan_maps():
         assert np.abs(out["pred_entropy"][v].cpu().numpy() - r["pred_entropy"]).max() < MAP_TOL
     # an ordinary checkpoint stays far below the limit and takes no second pass
     ok = make_model(do_dropout=True)
-    predict_uncertainty([ok], x.float().cuda(), n_pred=3, seeds=[1])
+    predict_uncertainty([ok], x.float().cuda(), n_pred=3, seeds=[1], range_check="off")
     assert 0 < ok.range_max() < 1e3
+
+
+def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():
+    """values_amd.GraphedPredictor: forward + reduction captured into one hipGraph; a replay with device seed word s gives
+    the bits of the eager call with the same effective seed, another word other dropout samples, another input its maps"""
+    from values_amd import GraphedPredictor, predict_uncertainty
+    model = make_model(do_dropout=True)
+    x1 = torch.from_numpy(formula_volume((1, 1, 32, 32, 32), tag=97)).float().cuda()
+    x2 = torch.from_numpy(formula_volume((1, 1, 32, 32, 32), tag=98)).float().cuda()
+    gp = GraphedPredictor([model], x1.shape, n_pred=5)
+    a = {k: v.clone() for k, v in gp(x1, seed=7).items()}
+    b = {k: v.clone() for k, v in gp(x1, seed=7).items()}
+    c = {k: v.clone() for k, v in gp(x1, seed=8).items()}
+    d = {k: v.clone() for k, v in gp(x2, seed=7).items()}
+    for k in KEYS + ("softmax_variance", "mean_softmax", "pred_seg_mean"):
+        assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["epistemic_uncertainty"], c["epistemic_uncertainty"])
+    assert not torch.equal(a["pred_entropy"], d["pred_entropy"])
+    e = predict_uncertainty([model], x1, n_pred=5, seeds=[1000003 + 7])        # by-value seed + device word
+    for k in KEYS + ("mean_softmax",):
+        assert torch.equal(a[k], e[k]), k
+    det = make_model(do_dropout=False)
+    gd = GraphedPredictor([det], x1.shape, n_pred=1)
+    assert torch.equal(gd(x2)["logits"], predict_uncertainty([det], x2, n_pred=1)["logits"])
+
+
+@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=1), dict(s16_no_prenorm=1), dict(s16_no_xp8=1)])
+def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
+    """The level-0 data-flow variants behind vx_config: contr_1_2 / expand_1_1 normalising their own inputs with the raw
+    skip half in the concat buffer (s16_skip_raw), no normalise-on-load at all (s16_no_prenorm), and the general tile
+    kernels instead of the z-column kernel (s16_no_xp8) -- each against the float64 oracle with the exported hash
+    masks, MC-dropout (shared first layer) and TTA-style (src / flip) batches."""
+    from values_amd import predict_uncertainty
+    vxcfg.set(**knobs)
+    S, T, seed = 32, 3, 77
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(formula_volume((1, 1, S, S, S), tag=73))
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, T, S, S, S)]
+    logits, ref = _oracle_maps(formula_sd_torch(), x, [[m[t:t + 1] for m in masks] for t in range(T)])
+    assert np.abs(out["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
+    for k in KEYS:
+        assert np.abs(out[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
+    # the un-shared first layer (per-sample src / flip: the TTA path) with dropout off
+    det = make_model(do_dropout=False)
+    a = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
+    vxcfg.set(s16_skip_raw=0, s16_no_prenorm=0, s16_no_xp8=0)
+    b = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
+    assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5

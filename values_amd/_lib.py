@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                 ("head_out", _p), ("head_w", _p), ("head_b", _p), ("head_dst", _p), ("head_flip", _p),
                 ("head_C", _i32),
                 ("in_mean", _p), ("in_rstd", _p), ("in_drop_mode", _i32), ("in_drop_seed", _u32), ("in_drop_layer", _u32),
-                ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p)]
+                ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p)]
 
 
 class NormArgs(C.Structure):
@@ -40,7 +40,7 @@ class NormArgs(C.Structure):
                 ("pool_out", _p), ("pool_pitch", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
-                ("out_xblk", _i32), ("out_half", _i32)]
+                ("out_xblk", _i32), ("out_half", _i32), ("x_xblk", _i32), ("x_half", _i32), ("seed_dev", _p)]
 
 
 class ConvTArgs(C.Structure):
@@ -48,7 +48,7 @@ class ConvTArgs(C.Structure):
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
-                ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p)]
+                ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p)]
 
 
 class Conv2dArgs(C.Structure):
@@ -69,7 +69,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "conv_no_c8", "conv_dma", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
-        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_ping", "s16_no_xp8",
+        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_ping", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion", "s16_dbg", "c8_dbg", "dma_dbg", "dma_nw16", "c8_tile16",
         "s16_range_check")]
 
@@ -88,7 +88,7 @@ class UNet3DRun(C.Structure):
     _fields_ = [("x", _p), ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("repeat", _i32),
                 ("src", _p), ("flip", _p), ("dst", _p), ("drop_mode", _i32), ("seed", _u32),
                 ("masks", _p * 17), ("logits", _p), ("workspace", _p), ("workspace_bytes", C.c_size_t),
-                ("range_flag", _p)]
+                ("range_flag", _p), ("seed_dev", _p)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

@@ -50,6 +50,12 @@ __device__ __forceinline__ uint32_t vx_mix32(uint32_t h) {
 __device__ __forceinline__ uint32_t vx_drop_key(uint32_t seed, uint32_t layer, uint32_t sample) {
   return vx_mix32(seed * 0x9E3779B1u + layer * 0x85EBCA6Bu + sample * 0xC2B2AE35u + 0x27D4EB2Fu);
 }
+// seed of a launch: the by-value seed plus an optional DEVICE word -- a captured hipGraph replays with the kernel
+// arguments it was captured with, so a caller that wants fresh dropout bits per replay updates that word instead
+template <typename A>
+__device__ __forceinline__ uint32_t vx_seed_of(const A& a, uint32_t by_value) {
+  return by_value + (a.seed_dev ? *a.seed_dev : 0u);
+}
 // keep-bits for elements [e, e+4) of sample-local linear index e (e % 4 == 0)
 __device__ __forceinline__ uint32_t vx_drop_bits4(uint32_t key, uint32_t e) {
   uint32_t w = vx_mix32((e >> 5) * 0x9E3779B1u ^ key);

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_dma_kernel(ConvDArgs ka) {
       const unsigned e0 = vox0 * (unsigned)a.Cout;
       const __amdgpu_buffer_rsrc_t osrd =
           __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, D_NUMREC, 0x00020000);
-      const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+      const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
       const unsigned cshift = XP ? 0u : (unsigned)(blockIdx.y * 16);
       float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

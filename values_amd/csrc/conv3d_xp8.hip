@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
         p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq_thread * 4);
       }
       p_e0 = (unsigned)(((TZ * c.s) * a.H + ty * 8) * a.W + tx * 32) * 8u;
-      p_key = vx_drop_key(a.in_drop_seed, a.in_drop_layer, (uint32_t)n);
+      p_key = vx_drop_key(vx_seed_of(a, a.in_drop_seed), a.in_drop_layer, (uint32_t)n);
     }
   };
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
     if (ci != e_ci) {   // a new column: sample, tile row / column, dropout key, head pointers
       e_ci = ci;
       col_of(ci, e_n, e_ty, e_tx);
-      if (EPI == 1 || EPI == 2) e_key = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)e_n);
+      if (EPI == 1 || EPI == 2) e_key = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)e_n);
       if (EPI == 2) {
         e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
         const int slot = a.head_dst ? a.head_dst[e_n] : e_n;
@@ -425,31 +425,35 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
     const int item_k = cx.s - 1;
     int grp_c = grp_x + 1; if (grp_c == 3) grp_c = 0;               // group S_{j+1} goes into
     int rb = (grp_x == 0 ? 2 : grp_x - 1) * TZ + (TZ - 2);           // first plane of the item: group of S_{j-1}, plane TZ - 2
-    if (late && prev_ci >= 0) { epilogue(prev_ci, prev_k); prev_ci = -1; }
-    XP_STAMP(2);
-    if (!late) {
-      XP_WAIT_LOADS();
-      XP_STAMP(3);
-      if (cc.ci < ncol_wg) commit(grp_c);
-      XP_STAMP(4);
-      prefetch(cp);
-      XP_STAMP(5);
-    }
-    if (comp) multiply(rb);
-    XP_STAMP(1);
+    // waves 0..3:  stage S_{j+1}, load S_{j+2}, multiply(j), store(j)
+    // waves 4..7:  store(j-1), multiply(j), stage S_{j+1}, load S_{j+2}
+    // (measured alternative, tools/stamp_s16.py: multiply FIRST in waves 0..3 and LAST in waves 4..7, so that the two
+    // matrix phases never share the pipe -- 16 % slower: the loads, conversions and stores of an item are then issued by
+    // four waves at a time instead of eight, and it is the memory side, not the matrix pipe, that paces these layers)
     if (late) {
+      if (prev_ci >= 0) { epilogue(prev_ci, prev_k); prev_ci = -1; }
+      XP_STAMP(2);
+      if (comp) { multiply(rb); prev_ci = cx.ci; prev_k = item_k; }
+      XP_STAMP(1);
       XP_WAIT_LOADS();
       XP_STAMP(3);
       if (cc.ci < ncol_wg) commit(grp_c);
       XP_STAMP(4);
       prefetch(cp);
       XP_STAMP(5);
+    } else {
+      XP_WAIT_LOADS();
+      XP_STAMP(3);
+      if (cc.ci < ncol_wg) commit(grp_c);
+      XP_STAMP(4);
+      prefetch(cp);
+      XP_STAMP(5);
+      if (comp) multiply(rb);
+      XP_STAMP(1);
+      if (comp) epilogue(cx.ci, item_k);
+      XP_STAMP(2);
     }
-    if (comp) {
-      if (!late) epilogue(cx.ci, item_k);
-      else { prev_ci = cx.ci; prev_k = item_k; }
-      if (EPI == 0 && item_k == KZ - 1) { fl_ci = cx.ci; fl_at = j + 2; }
-    }
+    if (EPI == 0 && comp && item_k == KZ - 1) { fl_ci = cx.ci; fl_at = j + 2; }
     XP_STAMP(2);
 #ifdef VX_CONV_STAMPS
     ++st_iters;

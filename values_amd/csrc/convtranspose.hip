@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_
       }
     }
     const int oz = 2 * z + dz, oy = 2 * y + dy;
-    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const int ox = 2 * x + d;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, i
     }
     if (a.drop_mode == VX_DROP_HASH) {
       const uint32_t e = (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + cq * 4);
-      const uint32_t bits = vx_drop_bits4(vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n), e);
+      const uint32_t bits = vx_drop_bits4(vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n), e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
     } else if (a.drop_mode == VX_DROP_MASK) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
     q = ct_div(r, dc.mH); const int y = (int)(r - q * (unsigned)a.H); r = q;
     q = ct_div(r, dc.mD); const int z = (int)(r - q * (unsigned)a.D);
     const int n = (int)q;
-    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);

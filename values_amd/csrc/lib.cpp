@@ -64,6 +64,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
   g_cfg.s16_ping = env_int("VX_S16_PING", 0);
   g_cfg.s16_no_xp8 = env_int("VX_S16_NO_XP8", 0);
+  g_cfg.s16_skip_raw = env_int("VX_S16_SKIP_RAW", 0);
   g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
   g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);
   g_cfg.no_head_fusion = env_int("VX_NO_HEAD_FUSION", 0);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
       mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)ns * a.C + c);
       rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)ns * a.C + c);
     }
-    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
     f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     constexpr int NR = POOL ? (WIDE ? 8 : 4) : 1;
     f32x4 v[NR];
@@ -83,8 +83,15 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
       const int z = POOL ? bz * 2 + ((k >> 1) & 1) : bz;
       const int y = POOL ? by * 2 + (k & 1) : by;
       const int x = WIDE ? 2 * xq + (k >> 2) : xq;
-      const size_t svox = ((size_t)(ns * a.D + z) * a.H + y) * a.W + x;
-      v[k] = *reinterpret_cast<const f32x4*>(a.x + svox * a.x_pitch + c);
+      if (a.x_xblk) {   // the raw tensor sits in a concat buffer's half (dense blocks of xb voxels)
+        const size_t srow = (size_t)(ns * a.D + z) * a.H + y;
+        const int xb = a.x_xblk;
+        v[k] = *reinterpret_cast<const f32x4*>(a.x + srow * (2 * (size_t)a.W * a.C) + ((x / xb) * 2 + a.x_half) * xb * a.C +
+                                               (x % xb) * a.C + c);
+      } else {
+        const size_t svox = ((size_t)(ns * a.D + z) * a.H + y) * a.W + x;
+        v[k] = *reinterpret_cast<const f32x4*>(a.x + svox * a.x_pitch + c);
+      }
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -110,7 +117,9 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * t[j] : 0.f;
       }
-      if (a.out_xblk) {
+      if (!a.out) {
+        // pooled tensor only
+      } else if (a.out_xblk) {
         // concat buffer [N][D][H][W/xb][2][xb][C]: this kernel's half as dense blocks of xb voxels
         const size_t row = (size_t)(n * a.D + z) * a.H + y;
         const int xb = a.out_xblk;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args 
       const int n = ns * x_repeat + k;
       f32x4 t = t0;
       if (a.drop_mode == VX_DROP_HASH) {
-        const uint32_t bits = vx_drop_bits4(vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n), e);
+        const uint32_t bits = vx_drop_bits4(vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n), e);
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
       } else if (a.drop_mode == VX_DROP_MASK) {
@@ -204,12 +213,17 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
   if (!ap) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null args");
   if (x_repeat < 1) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: x_repeat must be >= 1");
   const vx_norm_args& a = *ap;
-  if (!a.x || !a.out) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null tensor");
+  if (!a.x || (!a.out && !a.pool_out)) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null tensor");
+  if (a.x_xblk && ((a.x_xblk != 1 && a.x_xblk != 2 && a.x_xblk != 4) || a.W % a.x_xblk || (a.x_half != 0 && a.x_half != 1)))
+    VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: bad concat input (xblk=%d, half=%d, W=%d)", a.x_xblk, a.x_half, a.W);
+  if (a.x_xblk && (x_repeat > 1 || !a.pool_out)) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: a concat input goes with pooling, x_repeat 1");
   if ((a.mean == nullptr) != (a.rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: mean/rstd must come together");
   if (a.N <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0 || a.C <= 0 || a.C % 4)
     VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: bad shape (C must be a multiple of 4)");
-  if (a.x_pitch % 4 || a.x_pitch < a.C) VX_FAIL(VX_E_ALIGN, "vx_norm_act_drop_pool: input pitch");
-  if (a.out_xblk) {
+  if (!a.x_xblk && (a.x_pitch % 4 || a.x_pitch < a.C)) VX_FAIL(VX_E_ALIGN, "vx_norm_act_drop_pool: input pitch");
+  if (!a.out) {
+    // pooled tensor only
+  } else if (a.out_xblk) {
     if ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || a.W % a.out_xblk || (a.out_half != 0 && a.out_half != 1))
       VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: bad concat layout (xblk=%d, half=%d, W=%d)", a.out_xblk, a.out_half, a.W);
   } else if (a.out_pitch % 4 || a.out_coff % 4 || a.out_pitch < a.out_coff + a.C) {

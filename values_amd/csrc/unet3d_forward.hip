@@ -23,6 +23,7 @@ struct Plan {
   Level lv[5];
   float *A[4], *B[4], *CAT[4], *P[5], *C0, *C1;
   float *stats, *mean, *rstd;
+  float *mean0, *rstd0;   // level-0 skip statistics: kept until the decoder normalises the skip half itself
   size_t bytes;
 };
 
@@ -63,6 +64,8 @@ static void make_plan(Plan& p, int N, int D, int H, int W, int F, char* base) {
   p.stats = carve(smax);
   p.mean = carve((size_t)N * p.lv[3].C);
   p.rstd = carve((size_t)N * p.lv[3].C);
+  p.mean0 = carve((size_t)N * p.lv[0].C);
+  p.rstd0 = carve((size_t)N * p.lv[0].C);
   p.bytes = off;
 }
 }  // namespace
@@ -143,7 +146,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
-                  int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1) {
+                  int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1,
+                  const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0) {
     vx_conv3d_args a = {};
     a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
     if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
@@ -161,19 +165,24 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
     a.drop_mask = drop_layer >= 0 ? mask(drop_layer) : nullptr;
     a.stats_partial = stats;
+    a.out_xblk = out_xblk; a.out_half = 1;
     if (pre_layer >= 0) {
-      a.in_mean = p.mean; a.in_rstd = p.rstd;
+      a.in_mean = pre_mean ? pre_mean : p.mean; a.in_rstd = pre_rstd ? pre_rstd : p.rstd;
       a.in_drop_mode = dm; a.in_drop_seed = r->seed; a.in_drop_layer = (uint32_t)pre_layer;
       a.in_repeat = pre_rep;
     }
+    a.seed_dev = r->seed_dev;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     return vx_conv3d_k3(&a, stream);
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
-                  int drop_layer, int x_repeat, int out_xblk) {
-    vx_norm_args a;
+                  int drop_layer, int x_repeat, int out_xblk, int x_xblk = 0, const float* mean = nullptr,
+                  const float* rstd = nullptr) {
+    vx_norm_args a = {};
     a.out_xblk = out_xblk; a.out_half = 1;
-    a.x = x; a.x_pitch = C; a.mean = p.mean; a.rstd = p.rstd;
+    a.x_xblk = x_xblk; a.x_half = 1;
+    a.seed_dev = r->seed_dev;
+    a.x = x; a.x_pitch = C; a.mean = mean ? mean : p.mean; a.rstd = rstd ? rstd : p.rstd;
     a.out = out; a.out_pitch = out_pitch; a.out_coff = out_coff;
     a.pool_out = pool; a.pool_pitch = C;
     a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.C = C;
@@ -185,6 +194,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
                    int drop_layer) {
     vx_convT_args a = {};
     a.range_flag = r->range_flag;
+    a.seed_dev = r->seed_dev;
     a.out_xblk = xblk_of(2 * Lin.W); a.out_half = 0;
     a.in = in; a.in_pitch = Cin; a.w_packed = w->up_w[ui]; a.bias = w->up_b[ui];
     a.out = out; a.out_pitch = out_pitch; a.out_coff = 0;
@@ -205,6 +215,15 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   static const char* kFin[8] = {"finalize:contr_1_1", "finalize:contr_1_2", "finalize:contr_2_1", "finalize:contr_2_2",
                                 "finalize:contr_3_1", "finalize:contr_3_2", "finalize:contr_4_1", "finalize:contr_4_2"};
   static const char* kUp[4] = {"center.4", "upscale4", "upscale3", "upscale2"};
+  // level 0 on the z-column kernel: contr_1_2 and expand_1_1 normalise their inputs themselves (no normalised
+  // full-resolution tensor is ever written); needs the hash generator or no dropout -- injected masks take the
+  // general kernels with their separate normalise passes
+  const bool pre0 = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && F == 8 &&
+                    vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F);
+  // contr_1_2's raw output straight into the skip half + a pooling-only pass + expand_1_1 normalising its skip half:
+  // measured NEUTRAL to slightly slower (the pass shrinks 1.09 -> 0.59 ms per 320 samples, expand_1_1 grows 2.33 -> 2.95:
+  // its staging is instruction-bound and the hash per piece is not free) -- opt-in (vx_config.s16_skip_raw)
+  const bool fuse0 = pre0 && vx_cfg().s16_skip_raw && vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   // ---------------- encoder ----------------
   for (int l = 0; l < 4; ++l) {
     const Level& L = p.lv[l];
@@ -215,16 +234,18 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     if (l == 0) {
       ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
       const int rep = r->repeat > 0 ? r->repeat : 1;
-      const bool fuse_norm = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && vx_conv3d_k3_prologue_ok(L.D, L.H, L.W, C, C);
+      const bool fuse_norm = pre0;
       if (!r->src && !r->flip && rep > 1 && N % rep == 0) {
         // MC-dropout: the T samples of a volume share this conv and its statistics -> once per volume into a
         // scratch (CAT_0 is free until contr_1_2's norm); contr_1_2 reads that scratch with T dropout patterns, or
         // (general kernels) the norm kernel fans it out
         const int V = N / rep;
-        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.CAT[0], C, V, L.D, L.H, L.W, C, 1, nullptr,
+        // (scratch: A_0 when CAT_0 takes contr_1_2's raw output; else CAT_0, free until contr_1_2's norm)
+        float* scratch = fuse0 ? p.A[0] : p.CAT[0];
+        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], scratch, C, V, L.D, L.H, L.W, C, 1, nullptr,
                                           nullptr, p.stats, stream));
         VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        if (fuse_norm) { in2 = p.CAT[0]; pre_layer = 0; pre_rep = rep; }
+        if (fuse_norm) { in2 = scratch; pre_layer = 0; pre_rep = rep; }
         else VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0));
       } else {
         VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, rep, r->src,
@@ -240,6 +261,16 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
     }
     ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+    if (l == 0 && fuse0) {
+      // contr_1_2's RAW output goes straight into the skip half of CAT_0; one pooling pass produces P_1 from it, and
+      // expand_1_1 normalises the skip half while it stages its tiles (statistics kept in mean0 / rstd0 until then):
+      // the full-resolution tensor is written once and read twice instead of written twice and read twice
+      VX_STEP(kConv[1], conv(in2, C, 1, p.CAT[0], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep, nullptr,
+                             nullptr, xblk_of(L.W)));
+      VX_STEP(kFin[1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean0, p.rstd0, stream));
+      VX_STEP("pool:contr_1_2", norm(p.CAT[0], C, nullptr, 0, 0, p.P[1], L, 1, 1, 0, xblk_of(L.W), p.mean0, p.rstd0));
+      continue;
+    }
     VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep));
     VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
     VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1, xblk_of(L.W)));
@@ -258,7 +289,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int C = L.C;
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
-    VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
+    if (l == 0 && fuse0)   // the skip half of CAT_0 is contr_1_2's raw output: normalise + LeakyReLU + dropout layer 1 on load
+      VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 1, 1,
+                              p.mean0, p.rstd0));
+    else
+      VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }

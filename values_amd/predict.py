@@ -113,7 +113,7 @@ def _volume_chunks(V: int, n_streams: Optional[int], pinned_inputs: bool, sample
 def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool = False,
                    x_noise: Optional[torch.Tensor] = None, dropout_masks=None, seeds=None,
                    n_aleatoric_samples: int = 10, eps=None, n_streams: Optional[int] = None, _after_chunk=None,
-                   **kw_ssn) -> torch.Tensor:
+                   seed_dev: Optional[torch.Tensor] = None, **kw_ssn) -> torch.Tensor:
     """x: (V,1,D,H,W).  Returns logits (V, n_total, C, D,H,W) f32 on the device, n_total = passes per volume in
     pred_idx order.  dropout_masks: optional [member][pass] -> 17 masks (parity tests).  n_streams: volume chunks
     run concurrently on that many HIP streams (default: VX_STREAMS or 1), each with its own workspace; every chunk
@@ -168,6 +168,8 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
                     if seeds is not None:
                         # one hash-dropout stream per (member seed, chunk): sample indices restart in every chunk
                         kw["seed"] = (int(seeds[mi]) + 0x9E3779B1 * ci) & 0xFFFFFFFF
+                    if seed_dev is not None:
+                        kw["seed_dev"] = seed_dev
                     model(xc, n_samples=n_pred, dst=dst, out=flat, **kw)
             if _after_chunk is not None:
                 _after_chunk(logits, v0, v1)
@@ -236,6 +238,43 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
                 return predict_uncertainty(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, ssn=ssn,
                                            want_sample_argmax=want_sample_argmax, range_check="off", **kw)
     return out
+
+
+class GraphedPredictor:
+    """predict_uncertainty for ONE batch geometry as a single captured hipGraph: the ~40 launches of a forward plus the
+    reduction replay with one host call (single-volume latency: the eager path is bound by launch overhead there).
+    `gp(x, seed=s)` copies x into the graph's input, sets the device seed word every dropout kernel adds to its seed
+    (a graph replays with the arguments it was captured with), replays, and returns the graph's OUTPUT tensors -- valid
+    until the next call.  MC-dropout / deterministic UNet3D members with hash or no dropout; the fp16 range word is not
+    read here (model.check_range())."""
+
+    def __init__(self, models: Sequence, shape, n_pred: int = 1, device=None, **predict_kw):
+        _lib.require_gpu()
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.models, self.n_pred = list(models), n_pred
+        self.x = torch.zeros(tuple(shape), dtype=torch.float32, device=self.dev)
+        self.seed_word = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        kw = dict(predict_kw, range_check="off", n_streams=1, seeds=[1000003 * (i + 1) for i in range(len(self.models))],
+                  seed_dev=self.seed_word)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):          # warm-up on the capture stream: weights packed, workspaces and index tensors exist
+            for _ in range(2):
+                predict_uncertainty(self.models, self.x, n_pred=n_pred, **kw)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out = predict_uncertainty(self.models, self.x, n_pred=n_pred, **kw)
+        self._calls = 0
+
+    def __call__(self, x: torch.Tensor, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        self.x.copy_(x, non_blocking=True)
+        self._calls += 1
+        s = (self._calls if seed is None else int(seed)) & 0x7FFFFFFF
+        self.seed_word.fill_(s)
+        self.graph.replay()
+        return self.out
 
 
 class HostPipeline:

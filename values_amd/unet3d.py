@@ -202,16 +202,18 @@ class UNet3D(nn.Module):
     def forward(self, x: torch.Tensor, enable_concat: bool = True, last_layer: bool = True, *,
                 n_samples: int = 1, src: Optional[torch.Tensor] = None, flip: Optional[torch.Tensor] = None,
                 dst: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                dropout_masks: Optional[Sequence[torch.Tensor]] = None, seed: Optional[int] = None):
+                dropout_masks: Optional[Sequence[torch.Tensor]] = None, seed: Optional[int] = None,
+                seed_dev: Optional[torch.Tensor] = None):
         if not enable_concat or not last_layer:
             raise NotImplementedError("values_amd.UNet3D: autoencoder / feature modes are training-only and not on the HIP path")
-        res = self._run(x, n_samples=n_samples, src=src, flip=flip, dst=dst, out=out, dropout_masks=dropout_masks, seed=seed)
+        res = self._run(x, n_samples=n_samples, src=src, flip=flip, dst=dst, out=out, dropout_masks=dropout_masks, seed=seed,
+                        seed_dev=seed_dev)
         if self.aleatoric_loss:
             mu, s = res.split(self.num_classes, 1)  # unet3D_module.py:367-369
             return mu, s
         return res
 
-    def _run(self, x, *, n_samples=1, src=None, flip=None, dst=None, out=None, dropout_masks=None, seed=None):
+    def _run(self, x, *, n_samples=1, src=None, flip=None, dst=None, out=None, dropout_masks=None, seed=None, seed_dev=None):
         """The whole network through vx_unet3d_forward: (N, head channels, D, H, W) in x's dtype."""
         _lib.require_gpu()
         lib = _lib.load()
@@ -255,6 +257,11 @@ class UNet3D(nn.Module):
                 seed = (self.seed * 1000003 + self._calls) & 0xFFFFFFFF
                 self._calls += 1
             run.seed = int(seed) & 0xFFFFFFFF
+            if seed_dev is not None:   # a device word added to the seed by every kernel (hipGraph replays, GraphedPredictor)
+                if seed_dev.dtype != torch.int32 or not seed_dev.is_cuda:
+                    raise ValueError("seed_dev: an int32 device tensor of one element")
+                hold.append(seed_dev)
+                run.seed_dev = seed_dev.data_ptr()
         else:
             run.drop_mode = _lib.VX_DROP_NONE
         flag = self._range.get(str(dev))

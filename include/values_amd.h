@@ -205,6 +205,11 @@ int vx_conv3d_k3_c1(const float* in, const float* w_torch /* (Cout,1,3,3,3) */, 
                     int out_pitch, int N, int D, int H, int W, int Cout, int repeat, const int32_t* src,
                     const int32_t* flip, float* stats_partial, vx_stream_t stream);
 
+/* in_channels > 1 (unet3D_module.py:8-35): (V, Cin, D, H, W) -> channels-last [N][D][H][W][8] (channels Cin..7 zero) for
+ * the general 3x3x3 kernels, with the per-sample source volume / TTA flip of vx_conv3d_k3_c1.  1 <= Cin <= 8. */
+int vx_pack_input_cl8(const float* in, float* out, int N, int Cin, int D, int H, int W, int repeat, const int32_t* src,
+                      const int32_t* flip, vx_stream_t stream);
+
 /* K2: reduce stats_partial -> mean[N][C], rstd[N][C] (biased variance, eps 1e-5:
  * nn.InstanceNorm3d defaults, unet3D_module.py:234). */
 int vx_instnorm_finalize(const float* stats_partial, int N, int ntiles, int C, int64_t nvox, float eps,
@@ -271,6 +276,9 @@ typedef struct vx_unet3d_weights {
   int32_t F;            /* initial_filter_size */
   int32_t num_classes;
   int32_t conv_family[18]; /* vx_conv3d_k3_family of each packed conv at pack time (entry 0, the Cin == 1 layer: 0) */
+  int32_t in_channels;     /* 0 or 1: conv_w[0] is the torch layout of a Cin == 1 layer (vx_conv3d_k3_c1); 2 .. 8: conv_w[0]
+                              is PACKED for Cin = 8 (weights zero-padded), the input goes through vx_pack_input_cl8 */
+  int32_t no_instancenorm; /* 1: do_instancenorm=False -- contract blocks are conv + LeakyReLU + Dropout (unet3D_module.py:238-243) */
 } vx_unet3d_weights;
 
 typedef struct vx_unet3d_run {

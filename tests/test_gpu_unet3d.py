@@ -331,7 +331,9 @@ def test_aleatoric_head_and_errors():
         mu, s = m(x)
     assert mu.shape == s.shape == (1, 2, 16, 16, 16)
     with pytest.raises(NotImplementedError):
-        UNet3D(num_classes=2, in_channels=2)
+        UNet3D(num_classes=2, in_channels=9)
+    with pytest.raises(NotImplementedError):
+        UNet3D(num_classes=2, kernel_size=5)
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, 16, 16, 16).cuda())
 
@@ -651,3 +653,53 @@ def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     vxcfg.set(s16_skip_raw=0, s16_no_prenorm=0, s16_no_xp8=0)
     b = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
     assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("in_channels,instancenorm,size", [(1, False, 16), (3, True, 16), (2, False, 32), (4, True, 32)])
+def test_ctor_variants_vs_oracle(in_channels, instancenorm, size):
+    """UNet3D(in_channels > 1) and UNet3D(do_instancenorm=False) (unet3D_module.py:8-35, 238-243): state-dict names and
+    shapes of the reference class, MC-dropout (masks injected and hash masks exported) and the per-sample src / flip path
+    against the float64 oracle."""
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
+    from values_amd import UNet3D, predict_uncertainty
+    from values_amd.formula import unet3d_param_shapes
+    sd = formula_unet3d_state_dict(seed_tag=6, in_channels=in_channels)
+    model = UNet3D(num_classes=2, in_channels=in_channels, do_instancenorm=instancenorm, do_dropout=True)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == dict(unet3d_param_shapes(in_channels=in_channels))
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    model = model.cuda()
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    V, T, seed = 2, 3, 31
+    x = torch.from_numpy(np.stack([formula_volume((in_channels, size, size, size), tag=200 + v) for v in range(V)]))
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, V * T, size, size, size)]
+    for v in range(V):
+        lg = []
+        with torch.no_grad():
+            for t in range(T):
+                n = v * T + t
+                mk = {name: masks[i][n:n + 1] for i, name in enumerate(DROPOUT_ORDER)}
+                lg.append(unet3d_forward(sdt, x[v:v + 1], masks=mk, instancenorm=instancenorm)[0].numpy())
+        lg = np.stack(lg)
+        assert np.abs(out["logits"][v].cpu().numpy() - lg).max() < LOGIT_TOL, (v, np.abs(out["logits"][v].cpu().numpy() - lg).max())
+        ref = uo.calculate_uncertainty(uo.softmax(lg, axis=1))
+        for k in KEYS:
+            assert np.abs(out[k][v].cpu().numpy() - ref[k]).max() < MAP_TOL, (k, v)
+    # injected masks (general kernels, separate passes) give the hash run's logits
+    rep = predict_uncertainty([model], x.float().cuda(), n_pred=T, dropout_masks=[masks])
+    assert (rep["logits"] - out["logits"]).abs().max().item() < 2e-5
+    # TTA views: per-sample source volume and flips on the multi-channel input; dropout off
+    det = UNet3D(num_classes=2, in_channels=in_channels, do_instancenorm=instancenorm, do_dropout=False)
+    det.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    det = det.cuda()
+    xn = x * 1.01
+    tta = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=xn.float().cuda())
+    from values_amd.predict import FLIP_DIMS
+    with torch.no_grad():
+        for vi, (src, dims) in enumerate([(x, None), (x, FLIP_DIMS[2]), (xn, FLIP_DIMS[6])]):
+            k = [0, 3, 8 + 7][vi]
+            xi = src[:1].float().double()
+            y = unet3d_forward(sdt, torch.flip(xi, dims) if dims else xi, instancenorm=instancenorm)
+            y = torch.flip(y, dims) if dims else y
+            assert (tta["logits"][0, k].cpu().double() - y[0]).abs().max().item() < LOGIT_TOL, vi

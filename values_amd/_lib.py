@@ -81,7 +81,8 @@ class UncOutputs(C.Structure):
 
 class UNet3DWeights(C.Structure):
     _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
-                ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32), ("conv_family", _i32 * 18)]
+                ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32), ("conv_family", _i32 * 18),
+                ("in_channels", _i32), ("no_instancenorm", _i32)]
 
 
 class UNet3DRun(C.Structure):
@@ -117,6 +118,7 @@ SIGNATURES = {
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "vx_pack_input_cl8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vx_instnorm_finalize": (_i, [_p, _i, _i, _i, _i64, C.c_float, _p, _p, _p]),
     "vx_norm_act_drop_pool": (_i, [C.POINTER(NormArgs), _p]),
     "vx_norm_act_drop_pool_bcast": (_i, [C.POINTER(NormArgs), _i, _p]),

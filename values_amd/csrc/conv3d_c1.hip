@@ -127,3 +127,48 @@ extern "C" int vx_conv3d_k3_c1(const float* in, const float* w_torch, const floa
   VX_CHECK_LAUNCH("vx_conv3d_k3_c1");
   return VX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// in_channels > 1 (unet3D_module.py:8-35): the first conv then runs on the general 3x3x3 kernels, which take
+// channels-last tensors with Cin % 8 == 0.  This kernel lays the reference's (V, Cin, D, H, W) input out as
+// [N][D][H][W][8] (channels Cin .. 7 zero; the weights are zero-padded to match at pack time), resolving the
+// per-sample source volume and TTA flip exactly as conv3d_k3_c1_kernel does.
+__global__ __launch_bounds__(256) void pack_input_cl8_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int Cin,
+                                                             int D, int H, int W, int repeat, const int32_t* __restrict__ src,
+                                                             const int32_t* __restrict__ flip) {
+  const int64_t nvox = (int64_t)D * H * W, total = (int64_t)N * nvox;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / nvox);
+    const int64_t v = i - (int64_t)n * nvox;
+    int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((int64_t)W * H));
+    const int vol = src ? src[n] : n / repeat;
+    const int fl = flip ? flip[n] : 0;
+    if (fl & 1) z = D - 1 - z;
+    if (fl & 2) y = H - 1 - y;
+    if (fl & 4) x = W - 1 - x;
+    const float* p = in + ((size_t)vol * Cin) * nvox + ((size_t)z * H + y) * W + x;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < Cin) lo[c] = p[(size_t)c * nvox];
+      if (c + 4 < Cin) hi[c] = p[(size_t)(c + 4) * nvox];
+    }
+    reinterpret_cast<f32x4*>(out + (size_t)i * 8)[0] = lo;
+    reinterpret_cast<f32x4*>(out + (size_t)i * 8)[1] = hi;
+  }
+}
+
+extern "C" int vx_pack_input_cl8(const float* in, float* out, int N, int Cin, int D, int H, int W, int repeat,
+                                 const int32_t* src, const int32_t* flip, vx_stream_t stream) {
+  if (!in || !out) VX_FAIL(VX_E_NULL, "vx_pack_input_cl8: null pointer");
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || repeat <= 0) VX_FAIL(VX_E_SHAPE, "vx_pack_input_cl8: empty tensor");
+  if (Cin < 1 || Cin > 8) VX_FAIL(VX_E_SHAPE, "vx_pack_input_cl8: in_channels %d (1 .. 8)", Cin);
+  if (!vx_aligned16(out)) VX_FAIL(VX_E_ALIGN, "vx_pack_input_cl8: output alignment");
+  const int64_t total = (int64_t)N * D * H * W;
+  int bx = (int)((total + 255) / 256);
+  if (bx > 16384) bx = 16384;
+  vx_note_kernel("pack_input_cl8_kernel");
+  hipLaunchKernelGGL(pack_input_cl8_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, in, out, N, Cin, D, H, W, repeat, src, flip);
+  VX_CHECK_LAUNCH("vx_pack_input_cl8");
+  return VX_OK;
+}

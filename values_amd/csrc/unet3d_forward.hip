@@ -125,6 +125,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   if ((((uintptr_t)r->workspace) & 255u) != 0) VX_FAIL(VX_E_ALIGN, "vx_unet3d_forward: workspace must be 256-byte aligned");
   for (int i = 0; i < 18; ++i)
     if (!w->conv_w[i] || !w->conv_b[i]) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: conv weight %d missing", i);
+  if (w->in_channels < 0 || w->in_channels > 8) VX_FAIL(VX_E_SHAPE, "vx_unet3d_forward: in_channels %d (1 .. 8)", w->in_channels);
   for (int i = 0; i < 4; ++i)
     if (!w->up_w[i] || !w->up_b[i]) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: transposed-conv weight %d missing", i);
   if (!w->final_w || !w->final_b) VX_FAIL(VX_E_NULL, "vx_unet3d_forward: final weights missing");
@@ -147,7 +148,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1,
-                  const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0) {
+                  const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0) {
     vx_conv3d_args a = {};
     a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
     if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
@@ -159,7 +160,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.w_family = w->conv_family[wi];
     a.in = in; a.w_packed = w->conv_w[wi]; a.bias = w->conv_b[wi]; a.out = out;
     a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.out_coff = out_coff;
-    a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.Cin = Cin; a.Cout = Cout;
+    a.N = n_samples > 0 ? n_samples : N; a.D = L.D; a.H = L.H; a.W = L.W; a.Cin = Cin; a.Cout = Cout;
     a.act = act;
     a.drop_mode = drop_layer >= 0 ? dm : VX_DROP_NONE;
     a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
@@ -177,17 +178,20 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
                   int drop_layer, int x_repeat, int out_xblk, int x_xblk = 0, const float* mean = nullptr,
-                  const float* rstd = nullptr) {
+                  const float* rstd = nullptr, bool normalise = true, int act = VX_ACT_LRELU) {
     vx_norm_args a = {};
     a.out_xblk = out_xblk; a.out_half = 1;
     a.x_xblk = x_xblk; a.x_half = 1;
     a.seed_dev = r->seed_dev;
-    a.x = x; a.x_pitch = C; a.mean = mean ? mean : p.mean; a.rstd = rstd ? rstd : p.rstd;
+    a.x = x; a.x_pitch = C;
+    a.mean = normalise ? (mean ? mean : p.mean) : nullptr;
+    a.rstd = normalise ? (rstd ? rstd : p.rstd) : nullptr;
     a.out = out; a.out_pitch = out_pitch; a.out_coff = out_coff;
     a.pool_out = pool; a.pool_pitch = C;
     a.N = N; a.D = L.D; a.H = L.H; a.W = L.W; a.C = C;
-    a.act = VX_ACT_LRELU; a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = (uint32_t)drop_layer;
-    a.drop_mask = mask(drop_layer);
+    a.act = act;
+    a.drop_mode = drop_layer >= 0 ? dm : VX_DROP_NONE; a.drop_seed = r->seed; a.drop_layer = (uint32_t)(drop_layer >= 0 ? drop_layer : 0);
+    a.drop_mask = drop_layer >= 0 ? mask(drop_layer) : nullptr;
     return vx_norm_act_drop_pool_bcast(&a, x_repeat, stream);
   };
   auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
@@ -218,13 +222,24 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // level 0 on the z-column kernel: contr_1_2 and expand_1_1 normalise their inputs themselves (no normalised
   // full-resolution tensor is ever written); needs the hash generator or no dropout -- injected masks take the
   // general kernels with their separate normalise passes
-  const bool pre0 = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && F == 8 &&
+  const bool pre0 = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && F == 8 && !w->no_instancenorm &&
                     vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F);
   // contr_1_2's raw output straight into the skip half + a pooling-only pass + expand_1_1 normalising its skip half:
   // measured NEUTRAL to slightly slower (the pass shrinks 1.09 -> 0.59 ms per 320 samples, expand_1_1 grows 2.33 -> 2.95:
   // its staging is instruction-bound and the hash per piece is not free) -- opt-in (vx_config.s16_skip_raw)
   const bool fuse0 = pre0 && vx_cfg().s16_skip_raw && vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   // ---------------- encoder ----------------
+  const bool inorm = !w->no_instancenorm;
+  const int ICH = w->in_channels > 1 ? w->in_channels : 1;
+  // the first conv over n_out samples (raw output + bias; statistics if asked): Cin == 1 on its own VALU kernel, more
+  // input channels zero-padded to 8 on the general kernels (input laid out channels-last in B_0, free until contr_1_2)
+  auto first_conv = [&](float* out, int n_out, int rep, const int32_t* src, const int32_t* flip, float* stats) -> int {
+    const Level& L = p.lv[0];
+    if (ICH == 1)
+      return vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], out, L.C, n_out, L.D, L.H, L.W, L.C, rep, src, flip, stats, stream);
+    VX_TRY(vx_pack_input_cl8(r->x, p.B[0], n_out, ICH, L.D, L.H, L.W, rep, src, flip, stream));
+    return conv(p.B[0], 8, 0, out, L.C, 0, L, 8, L.C, VX_ACT_NONE, -1, stats, 0, -1, 1, nullptr, nullptr, 0, n_out);
+  };
   for (int l = 0; l < 4; ++l) {
     const Level& L = p.lv[l];
     const int C = L.C;
@@ -232,35 +247,43 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     int pre_layer = -1, pre_rep = 1;       // contr_l_2 normalises its own input (no separate pass over A_l)
     const float* in2 = p.A[l];
     if (l == 0) {
-      ntiles = vx_conv3d_k3_c1_tiles(L.D, L.H, L.W);
+      ntiles = ICH == 1 ? vx_conv3d_k3_c1_tiles(L.D, L.H, L.W) : vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
       const int rep = r->repeat > 0 ? r->repeat : 1;
-      const bool fuse_norm = pre0;
+      const bool fuse_norm = pre0 && inorm;
       if (!r->src && !r->flip && rep > 1 && N % rep == 0) {
         // MC-dropout: the T samples of a volume share this conv and its statistics -> once per volume into a
-        // scratch (CAT_0 is free until contr_1_2's norm); contr_1_2 reads that scratch with T dropout patterns, or
-        // (general kernels) the norm kernel fans it out
+        // scratch; contr_1_2 reads that scratch with T dropout patterns, or (general kernels) the norm kernel fans it out
         const int V = N / rep;
         // (scratch: A_0 when CAT_0 takes contr_1_2's raw output; else CAT_0, free until contr_1_2's norm)
         float* scratch = fuse0 ? p.A[0] : p.CAT[0];
-        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], scratch, C, V, L.D, L.H, L.W, C, 1, nullptr,
-                                          nullptr, p.stats, stream));
-        VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+        VX_STEP(kConv[0], first_conv(scratch, V, 1, nullptr, nullptr, inorm ? p.stats : nullptr));
+        if (inorm) VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
         if (fuse_norm) { in2 = scratch; pre_layer = 0; pre_rep = rep; }
-        else VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0));
+        else VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0, 0, nullptr, nullptr, inorm));
       } else {
-        VX_STEP(kConv[0], vx_conv3d_k3_c1(r->x, w->conv_w[0], w->conv_b[0], p.A[0], C, N, L.D, L.H, L.W, C, rep, r->src,
-                                          r->flip, p.stats, stream));
-        VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
+        VX_STEP(kConv[0], first_conv(p.A[0], N, rep, r->src, r->flip, inorm ? p.stats : nullptr));
+        if (inorm) VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
         if (fuse_norm) pre_layer = 0;
-        else VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1, 0));
+        else VX_STEP(kNorm[0], norm(p.A[0], C, p.A[0], C, 0, nullptr, L, 0, 1, 0, 0, nullptr, nullptr, inorm));
       }
-    } else {
+    } else if (inorm) {
       ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats, 0));
       VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
       VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
+    } else {
+      // do_instancenorm=False (unet3D_module.py:238-243): conv + LeakyReLU + Dropout, all in the conv's epilogue
+      VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_LRELU, 2 * l, nullptr, 0));
     }
     ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+    if (!inorm) {
+      // second conv of the block with its activation / dropout fused; one streaming pass copies it into the skip half of
+      // the concat buffer and pools it (no normalisation, no activation)
+      VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, 2 * l + 1, nullptr, 0));
+      VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, -1, 1, xblk_of(L.W), 0, nullptr, nullptr, false,
+                                     VX_ACT_NONE));
+      continue;
+    }
     if (l == 0 && fuse0) {
       // contr_1_2's RAW output goes straight into the skip half of CAT_0; one pooling pass produces P_1 from it, and
       // expand_1_1 normalises the skip half while it stages its tiles (statistics kept in mean0 / rstd0 until then):

@@ -49,22 +49,22 @@ class UNet3D(nn.Module):
         super().__init__()
         if kernel_size != 3:
             raise NotImplementedError("values_amd.UNet3D: only kernel_size=3 (every shipped config) has a HIP kernel")
-        if in_channels != 1:
-            raise NotImplementedError("values_amd.UNet3D: only in_channels=1 (every shipped config) has a HIP kernel")
-        if not do_instancenorm:
-            raise NotImplementedError("values_amd.UNet3D: do_instancenorm=False has no HIP path yet")
+        if not 1 <= in_channels <= 8:
+            raise NotImplementedError("values_amd.UNet3D: in_channels must be 1 .. 8")
         if initial_filter_size not in (8, 16, 32):
             raise NotImplementedError("values_amd.UNet3D: initial_filter_size must be 8, 16 or 32")
         self.num_classes = num_classes
         self.aleatoric_loss = aleatoric_loss
+        self.in_channels = in_channels
+        self.do_instancenorm = bool(do_instancenorm)
         self.initial_filter_size = initial_filter_size
         self.dropout_prob = 0.5 if do_dropout else 0.0  # unet3D_module.py:31-34
         f, p = initial_filter_size, self.dropout_prob
         chans = [f, 2 * f, 4 * f, 8 * f]
         prev = in_channels
         for lvl, c in enumerate(chans, start=1):
-            setattr(self, f"contr_{lvl}_1", _block(prev, c, 3, True, p))
-            setattr(self, f"contr_{lvl}_2", _block(c, c, 3, True, p))
+            setattr(self, f"contr_{lvl}_1", _block(prev, c, 3, do_instancenorm, p))
+            setattr(self, f"contr_{lvl}_2", _block(c, c, 3, do_instancenorm, p))
             prev = c
         center = [nn.Conv3d(8 * f, 16 * f, 3, padding=1), nn.ReLU(inplace=True),
                   nn.Conv3d(16 * f, 16 * f, 3, padding=1), nn.ReLU(inplace=True),
@@ -105,7 +105,15 @@ class UNet3D(nn.Module):
         for i, name in enumerate(CONV_ORDER):
             wt, b = sd[name + ".weight"], sd[name + ".bias"]
             cout, cin = wt.shape[0], wt.shape[1]
-            if i == 0:
+            if i == 0 and cin > 1:
+                # in_channels > 1: zero-padded to 8 input channels for the general kernels (vx_pack_input_cl8 pads the input)
+                wt8 = torch.zeros((cout, 8) + tuple(wt.shape[2:]), dtype=torch.float32, device=device)
+                wt8[:, :cin] = wt
+                wt, cin = wt8.contiguous(), 8
+                n = lib.vx_conv3d_k3_packed_floats(cin, cout)
+                packed = torch.empty(n, dtype=torch.float32, device=device)
+                _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(packed), cin, cout, st), "vx_pack_conv3d_k3")
+            elif i == 0:
                 packed = wt  # Cin == 1 kernel reads the torch layout
             else:
                 n = lib.vx_conv3d_k3_packed_floats(cin, cout)
@@ -116,7 +124,7 @@ class UNet3D(nn.Module):
             keep += [packed, b, wt]
             w.conv_w[i] = packed.data_ptr()
             w.conv_b[i] = b.data_ptr()
-            w.conv_family[i] = 0 if i == 0 else lib.vx_conv3d_k3_family(cin, cout)
+            w.conv_family[i] = 0 if (i == 0 and cin == 1) else lib.vx_conv3d_k3_family(cin, cout)
         for i, name in enumerate(UP_ORDER):
             wt, b = sd[name + ".weight"], sd[name + ".bias"]
             cin, cout = wt.shape[0], wt.shape[1]
@@ -132,6 +140,8 @@ class UNet3D(nn.Module):
         w.final_b = fb.data_ptr()
         w.F = self.initial_filter_size
         w.num_classes = fw.shape[0]
+        w.in_channels = self.in_channels
+        w.no_instancenorm = 0 if self.do_instancenorm else 1
         self._packed = (w, keep)
         self._packed_key = key
         return self._packed
@@ -217,8 +227,8 @@ class UNet3D(nn.Module):
         """The whole network through vx_unet3d_forward: (N, head channels, D, H, W) in x's dtype."""
         _lib.require_gpu()
         lib = _lib.load()
-        if x.dim() != 5 or x.shape[1] != 1:
-            raise ValueError(f"expected (N,1,D,H,W) input, got {tuple(x.shape)}")
+        if x.dim() != 5 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected (N,{self.in_channels},D,H,W) input, got {tuple(x.shape)}")
         in_dtype = x.dtype
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         xf = x.detach().to(device=dev, dtype=torch.float32).contiguous()

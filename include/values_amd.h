@@ -50,6 +50,8 @@ enum { VX_DROP_NONE = 0, VX_DROP_HASH = 1, VX_DROP_MASK = 2 };
 
 int vx_version(void);
 const char* vx_last_error_string(void);
+/* diagnostic: the kernel instance (as rocprofv3 names it) the calling thread's last launch dispatched to, or "" */
+const char* vx_last_kernel_name(void);
 
 /* The keep-bits of VX_DROP_HASH as an explicit VX_DROP_MASK mask: mask[n][e] (uint8 0/1) for sample n, channels-last
  * element e = voxel * C + c of dropout layer `layer` (index in DROPOUT order: contr_1_1 .. contr_4_2, center,

@@ -96,6 +96,7 @@ class UNet3DRun(C.Structure):
 SIGNATURES = {
     "vx_version": (_i, []),
     "vx_last_error_string": (C.c_char_p, []),
+    "vx_last_kernel_name": (C.c_char_p, []),
     "vx_drop_hash_mask": (_i, [_u32, _u32, _i, _i64, _p, _p]),
     "vx_get_config": (_i, [C.POINTER(Config)]),
     "vx_set_config": (_i, [C.POINTER(Config)]),

@@ -437,6 +437,8 @@ static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
   if (per_cu > 2) per_cu = 2;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
+  static const char* kname = vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY);
+  vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(512), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv2d(s16)");
   return VX_OK;

@@ -95,5 +95,6 @@ extern "C" int vx_set_config(const vx_config* cfg) {
   return VX_OK;
 }
 
+extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
 extern "C" int vx_version(void) { return 200; /* 0.2.0 */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

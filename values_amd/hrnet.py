@@ -339,7 +339,15 @@ class HighResolutionNet(nn.Module):
         if stats:
             part = torch.empty((ntiles, cout, 2), dtype=torch.float32, device=x.t.device)
             a.stats_partial = part.data_ptr()
+        prof = getattr(self, "_prof", None)
+        if prof is not None:       # diagnostic (profile_forward): a HIP event pair around the launch, on its stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         _lib.check(lib.vx_conv2d(C.byref(a), self._st), "vx_conv2d " + name)
+        if prof is not None:
+            e1.record(torch.cuda.current_stream())
+            prof.append((lib.vx_last_kernel_name().decode(), 2.0 * ks * ks * cin * cout * n * oh * ow,
+                         4.0 * (n * h * w * cin + n * oh * ow * cout + ks * ks * cin * cout), e0, e1))
         self._hold += [out, part]
         act = _Act(out, pitch if (cout % 16 and stats) else cout)
         act.real_c = cout
@@ -585,6 +593,45 @@ class HighResolutionNet(nn.Module):
         if user_out:
             return out
         return out.view(n_samples, n, self.num_classes, h, w)
+
+    def profile_forward(self, x: torch.Tensor, peak_tflops: float, hbm_gbs: float, reps: int = 3):
+        """bench.py's roofline leg for the 2D path: one forward per rep on ONE stream with a HIP event pair around every
+        convolution launch; the dominant convolution kernel instance with its algorithmic TFLOP/s and GB/s and the roof
+        that binds it (the larger of flops / matrix roof and bytes / HBM roof)."""
+        import os
+        old = os.environ.get("VX_HRNET_SINGLE_STREAM")
+        os.environ["VX_HRNET_SINGLE_STREAM"] = "1"
+        acc = {}
+        try:
+            for rep in range(reps + 1):
+                self._prof = []
+                self.forward_samples(x, 1)
+                torch.cuda.synchronize()
+                rows, self._prof = self._prof, None
+                if rep == 0:
+                    continue
+                for name, fl, by, e0, e1 in rows:
+                    a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                    a["ms"] += e0.elapsed_time(e1); a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+        finally:
+            self._prof = None
+            if old is None:
+                os.environ.pop("VX_HRNET_SINGLE_STREAM", None)
+            else:
+                os.environ["VX_HRNET_SINGLE_STREAM"] = old
+        name, a = max(acc.items(), key=lambda kv: kv[1]["ms"])
+        sec = a["ms"] * 1e-3
+        tf, gb = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
+        bound = "mfma" if a["flops"] / (peak_tflops * 1e12) >= a["bytes"] / (hbm_gbs * 1e9) else "hbm"
+        conv_ms = sum(v["ms"] for v in acc.values()) / reps
+        return {"bound": bound, "kernel": name, "achieved": round(tf if bound == "mfma" else gb, 3),
+                "peak": peak_tflops if bound == "mfma" else hbm_gbs, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": round(tf / peak_tflops if bound == "mfma" else gb / hbm_gbs, 4),
+                "frac_mfma": round(tf / peak_tflops, 4), "frac_hbm": round(gb / hbm_gbs, 4),
+                "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_forward": a["launches"] // reps,
+                "conv_launches_per_forward": sum(v["launches"] for v in acc.values()) // reps,
+                "conv_ms_per_forward": round(conv_ms, 3), "share_of_conv_time": round(a["ms"] / reps / conv_ms, 3),
+                "traffic": None}
 
     def forward(self, x: torch.Tensor, mean_only: bool = False):
         if self.ssn:

@@ -183,8 +183,9 @@ typedef struct vx_conv3d_args {
   int32_t in_drop_mode; uint32_t in_drop_seed, in_drop_layer;   /* VX_DROP_NONE | VX_DROP_HASH of the producing block */
   int32_t in_repeat;    /* 0 or 1: sample n reads input sample n */
   int32_t out_xblk, out_half; /* out_xblk > 0: `out` is a concat buffer, this conv writes its half out_half (as vx_norm_args) */
-  uint32_t* range_flag; /* nullable device word: atomic max of the bit patterns of |stored values| (fp16 range guard of
-                           the split-fp16 consumers: anything >= 65504 must not reach them) */
+  uint32_t* range_flag; /* nullable device word: atomic max of the bit patterns of the |stored values| that reach 32768 (fp16
+                           range guard of the split-fp16 consumers: anything >= 65504 must not reach them; smaller
+                           magnitudes are not reported -- the word stays 0 for an ordinary tensor) */
   const uint32_t* seed_dev; /* nullable device word ADDED to drop_seed / in_drop_seed at run time (a captured hipGraph
                                replays with the arguments it was captured with; fresh dropout bits per replay = update
                                this word).  Same field in vx_norm_args / vx_convT_args / vx_unet3d_run. */
@@ -332,6 +333,11 @@ int vx_conv2d(const vx_conv2d_args* a, vx_stream_t stream);
  * (biased variance over count = N*OH*OW, eps 1e-5; hrnet_module.py:30, BN_MOMENTUM side effect not reproduced). */
 int vx_bn_finalize(const float* stats_partial, int ntiles, int C, int64_t count, float eps, const float* gamma,
                    const float* beta, float* scale, float* shift, vx_stream_t stream);
+/* G independent BatchNorm batches in one tensor (the TTA views of test_2D.py:299-311 are separate forwards, each with
+ * its own batch statistics; batched here as G groups of consecutive images): group g owns tiles
+ * [g * ntiles_per_group, ...) of the partials and row g of scale / shift [G][cpitch]. */
+int vx_bn_finalize_groups(const float* stats_partial, int ntiles_per_group, int G, int C, int cpitch, int64_t count_per_group,
+                          float eps, const float* gamma, const float* beta, float* scale, float* shift, vx_stream_t stream);
 
 /* K16/K17/K18: out[.., out_coff + c] = act( add + scale[c] * G(drop(x))[c] + shift[c] ); G = identity (OH,OW == H,W) or
  * F.interpolate(mode="bilinear", align_corners=False) from (H,W) to (OH,OW); add / scale / drop optional; `add` may
@@ -344,6 +350,7 @@ typedef struct vx_affine_args {
   int32_t N, H, W, C, OH, OW;
   int32_t act;                              /* VX_ACT_NONE | VX_ACT_RELU */
   int32_t drop_mode; uint32_t drop_seed, drop_layer; const uint8_t* drop_mask; /* F.dropout(x, 0.5, training=True) on x */
+  int32_t group_images;                     /* > 0: scale / shift are [G][C], image n uses row n / group_images */
 } vx_affine_args;
 int vx_affine_gather(const vx_affine_args* a, vx_stream_t stream);
 

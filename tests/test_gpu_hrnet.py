@@ -308,3 +308,34 @@ def test_config_C4_w18_8_view_tta_at_1024x512_properties():
     assert (out["mean_softmax"].sum(1) - 1).abs().max().item() < 1e-5
     assert torch.equal(out["pred_seg"], out["mean_softmax"].argmax(1).to(torch.uint8)) or \
         (out["pred_seg"] != out["mean_softmax"].argmax(1).to(torch.uint8)).float().mean().item() < 1e-5
+
+
+def test_batched_tta_views_equal_one_forward_per_view():
+    """predict_logits_2d(batch_views=True): the TTA views as ONE batch with BatchNorm statistics per view
+    (vx_bn_finalize_groups, vx_affine_args.group_images) give the bits of one forward per view (test_2D.py:299-311) --
+    W18 widths (zero-padded channels, persistent padded buffers) and the small W48-style net, 4 and 8 views, batch 2."""
+    from values_amd.formula import HRNET_W18S_EXTRA
+    from values_amd.hrnet import HighResolutionNet
+    from values_amd.predict2d import predict_logits_2d, tta_views_8
+    g = load_npz("hrnet_w18s.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    cfg = {"MODEL": {"EXTRA": dict(HRNET_W18S_EXTRA, DROPOUT_FINAL=False), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+           "DATASET": {"NUM_CLASSES": 5}}
+    m = HighResolutionNet(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    x = torch.from_numpy(g["input"]).cuda()
+    noisy = x + torch.from_numpy(formula_tensor(tuple(x.shape), tag=83, scale=0.1)).float().cuda()
+    views, hf, vf = tta_views_8(x, noisy)
+    for nv in (8, 4):
+        a = predict_logits_2d([m], views[:nv], tta=True, hflip_views=hf[:nv], vflip_views=vf[:nv], batch_views=True)
+        b = predict_logits_2d([m], views[:nv], tta=True, hflip_views=hf[:nv], vflip_views=vf[:nv], batch_views=False)
+        assert a.shape == (2, nv, 5, 64, 96) and torch.equal(a, b), nv
+        a2 = predict_logits_2d([m], views[:nv], tta=True, hflip_views=hf[:nv], vflip_views=vf[:nv], batch_views=True)
+        assert torch.equal(a, a2)          # the persistent padded buffers are clean on reuse
+    m2, gg, _ = make(dropout_final=False)
+    x2 = torch.from_numpy(gg["input"]).cuda()
+    v2, h2, w2 = tta_views_8(x2, x2 * 1.02)
+    assert torch.equal(predict_logits_2d([m2], v2, tta=True, hflip_views=h2, vflip_views=w2, batch_views=True),
+                       predict_logits_2d([m2], v2, tta=True, hflip_views=h2, vflip_views=w2, batch_views=False))

@@ -697,7 +697,9 @@ def test_conv3d_xp8_epilogues_match_oracle(cin, shape, xblk):
     s = st.double().sum(1)
     np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
-    assert abs(mx - got.abs().max().item()) < 1e-6            # the range guard saw the largest stored magnitude (either kernel)
+    assert mx == 0.0                                          # range guard: ordinary magnitudes are not reported ...
+    gotb, _, _, mxb = _xp8_conv(xd, cin, wt, b + 5e4, n, d, h, w, xblk=xblk)
+    assert abs(mxb - gotb.abs().max().item()) < 1e-2 * 5e4 and mxb > 4e4      # ... values near the fp16 limit are (either kernel)
     # LeakyReLU + hash dropout: the bit generator's mask exported and applied to the oracle
     got, _, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=91, layer=6, xblk=xblk)
     keep = _hash_mask(91, 6, n, 8, d, h, w)

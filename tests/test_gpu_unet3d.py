@@ -603,7 +603,7 @@ def test_fp16_range_guard_never_returns_nan_maps():
     # an ordinary checkpoint stays far below the limit and takes no second pass
     ok = make_model(do_dropout=True)
     predict_uncertainty([ok], x.float().cuda(), n_pred=3, seeds=[1], range_check="off")
-    assert 0 < ok.range_max() < 1e3
+    assert ok.range_max() == 0.0        # magnitudes below 32768 are not reported
 
 
 def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():

@@ -62,7 +62,8 @@ class AffineArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i32), ("scale", _p), ("shift", _p), ("add", _p), ("add_pitch", _i32),
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("OH", _i32), ("OW", _i32),
-                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p)]
+                ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
+                ("group_images", _i32)]
 
 
 class Config(C.Structure):
@@ -147,6 +148,7 @@ SIGNATURES = {
     "vx_conv2d_tiles": (_i, [_i, _i, _i, _i]),
     "vx_conv2d": (_i, [C.POINTER(Conv2dArgs), _p]),
     "vx_bn_finalize": (_i, [_p, _i, _i, _i64, C.c_float, _p, _p, _p, _p, _p]),
+    "vx_bn_finalize_groups": (_i, [_p, _i, _i, _i, _i, _i64, C.c_float, _p, _p, _p, _p, _p]),
     "vx_affine_gather": (_i, [C.POINTER(AffineArgs), _p]),
     "vx_bilinear_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vx_evalmetrics_workspace_bytes": (_i64, []),

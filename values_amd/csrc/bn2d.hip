@@ -15,9 +15,14 @@
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C,
                                                           double inv_count, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift, int cpitch) {
   __shared__ double s_s[4], s_q[4];
   const int c = blockIdx.x;
+  // blockIdx.y = statistics group (vx_bn_finalize_groups): its tiles are rows [g * ntiles, (g + 1) * ntiles) of the
+  // partials, its scale / shift row g of [G][cpitch]
+  partial += (size_t)blockIdx.y * ntiles * C * 2;
+  scale += (size_t)blockIdx.y * cpitch;
+  shift += (size_t)blockIdx.y * cpitch;
   double s = 0.0, q = 0.0;
   for (int t = threadIdx.x; t < ntiles; t += 256) {
     s += (double)partial[((size_t)t * C + c) * 2 + 0];
@@ -45,8 +50,22 @@ extern "C" int vx_bn_finalize(const float* stats_partial, int ntiles, int C, int
   if (!stats_partial || !scale || !shift) VX_FAIL(VX_E_NULL, "vx_bn_finalize: null pointer");
   if (ntiles <= 0 || C <= 0 || count <= 0) VX_FAIL(VX_E_SHAPE, "vx_bn_finalize: empty");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, stats_partial, ntiles, C,
-                     1.0 / (double)count, eps, gamma, beta, scale, shift);
+                     1.0 / (double)count, eps, gamma, beta, scale, shift, C);
   VX_CHECK_LAUNCH("vx_bn_finalize");
+  return VX_OK;
+}
+
+// The same for G statistics groups in one launch: the batch holds G independent BatchNorm batches (the TTA views of
+// test_2D.py:299-311 are separate forwards, each normalised with ITS batch statistics; here they travel as one batch of
+// G x B images and every group of B consecutive images keeps its own statistics -- bit for bit the separate forwards).
+extern "C" int vx_bn_finalize_groups(const float* stats_partial, int ntiles_per_group, int G, int C, int cpitch,
+                                     int64_t count_per_group, float eps, const float* gamma, const float* beta, float* scale,
+                                     float* shift, vx_stream_t stream) {
+  if (!stats_partial || !scale || !shift) VX_FAIL(VX_E_NULL, "vx_bn_finalize_groups: null pointer");
+  if (ntiles_per_group <= 0 || G <= 0 || C <= 0 || cpitch < C || count_per_group <= 0) VX_FAIL(VX_E_SHAPE, "vx_bn_finalize_groups: empty");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C, (unsigned)G), dim3(256), 0, (hipStream_t)stream, stats_partial,
+                     ntiles_per_group, C, 1.0 / (double)count_per_group, eps, gamma, beta, scale, shift, cpitch);
+  VX_CHECK_LAUNCH("vx_bn_finalize_groups");
   return VX_OK;
 }
 
@@ -99,7 +118,9 @@ __global__ __launch_bounds__(256) void affine_gather_kernel(vx_affine_args a, in
       v = fetch(oy, ox);
     }
     if (a.scale) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c), sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+      // group_images > 0: image n takes row n / group_images of scale / shift [G][C] (vx_bn_finalize_groups)
+      const size_t row = a.group_images > 0 ? (size_t)(n / a.group_images) * a.C : 0;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + row + c), sh = *reinterpret_cast<const f32x4*>(a.shift + row + c);
       v = v * sc + sh;
     }
     const size_t opix = ((size_t)n * a.OH + oy) * a.OW + ox;

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       float mx = rmax;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      if (lane == 0 && mx > 0.f) atomicMax(a.range_flag, __float_as_uint(mx));
+      if (lane == 0 && !(mx < 32768.f)) atomicMax(a.range_flag, __float_as_uint(mx));   // see conv3d_xp8.hip
     }
   };
   // ---- epilogue of item tl (conv3d_mfma.hip); its statistics go to the s_red slots at redo ----

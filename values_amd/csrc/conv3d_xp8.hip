@@ -471,7 +471,9 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
     float mx = rmax;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if (lane == 0 && mx > 0.f) atomicMax(a.range_flag, __float_as_uint(mx));
+    // only magnitudes within a factor two of the fp16 limit are reported: thousands of atomics on one word per launch
+    // cost tens of microseconds (they serialise at the memory side), and nobody needs the maximum of an ordinary tensor
+    if (lane == 0 && !(mx < 32768.f)) atomicMax(a.range_flag, __float_as_uint(mx));
   }
 #ifdef VX_CONV_STAMPS
   if (ka.stamps && lane == 0) {

@@ -257,6 +257,8 @@ class HighResolutionNet(nn.Module):
         # activation tensor has round16(C) channels whose tail is exactly 0 (zero weight rows, zero BN scale/shift)
         self._last_parts = list(pre)
         self._packed, self._packed_key = None, None
+        self._zcache = {}      # persistent zero-padded buffers (see _conv)
+        self._groups = 1       # statistics groups of the forward in flight (forward_samples)
         self.seed, self._calls = 123, 0
 
     @staticmethod
@@ -325,7 +327,13 @@ class HighResolutionNet(nn.Module):
         pitch = (cout + 3) // 4 * 4
         if cout % 16 and stats:     # feeds another conv: keep the zero-padded round16(C) layout (see __init__)
             pitch = _r16(cout)
-            out = torch.zeros((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
+            # the conv writes channels [0, round4(cout)) only, so the zero tail survives from forward to forward: one
+            # buffer per layer and geometry, zero-filled once (a fill kernel per conv launch was the top entry of the
+            # W18 profile)
+            key = (name, n, oh, ow, pitch, str(x.t.device), torch.cuda.current_stream().cuda_stream)
+            out = self._zcache.get(key)
+            if out is None:
+                out = self._zcache[key] = torch.zeros((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
         else:
             out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
         part = None
@@ -358,12 +366,20 @@ class HighResolutionNet(nn.Module):
         raw, part, ntiles = self._conv(x, conv_name)
         gamma, beta = self._pk[bn_name]
         creal = raw.real_c
-        alloc = torch.zeros if creal != raw.C else torch.empty
-        scale = alloc(raw.C, dtype=torch.float32, device=raw.t.device)
-        shift = alloc(raw.C, dtype=torch.float32, device=raw.t.device)
-        _lib.check(lib.vx_bn_finalize(_lib.ptr(part), ntiles, creal, raw.N * raw.H * raw.W, 1e-5, _lib.ptr(gamma),
-                                      _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), self._st), "vx_bn_finalize " + bn_name)
-        self._hold += [scale, shift]
+        G = self._groups
+        if creal != raw.C:      # padded channels: scale = shift = 0 there, written once (the finalize kernel fills [0, creal))
+            key = ("bn", bn_name, G, raw.C, str(raw.t.device), torch.cuda.current_stream().cuda_stream)
+            ss = self._zcache.get(key)
+            if ss is None:
+                ss = self._zcache[key] = torch.zeros((2, G, raw.C), dtype=torch.float32, device=raw.t.device)
+        else:
+            ss = torch.empty((2, G, raw.C), dtype=torch.float32, device=raw.t.device)
+        scale, shift = ss[0], ss[1]
+        # G statistics groups of N / G consecutive images each (the TTA views of one batched forward; G = 1: plain BatchNorm)
+        _lib.check(lib.vx_bn_finalize_groups(_lib.ptr(part), ntiles // G, G, creal, raw.C, (raw.N // G) * raw.H * raw.W, 1e-5,
+                                             _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), self._st),
+                   "vx_bn_finalize " + bn_name)
+        self._hold += [ss]
         return raw, scale, shift
 
     def _aff(self, x: _Act, scale=None, shift=None, relu=False, add: Optional[_Act] = None, out: Optional[_Act] = None,
@@ -376,6 +392,8 @@ class HighResolutionNet(nn.Module):
         a.x = x.t.data_ptr(); a.x_pitch = x.pitch
         if scale is not None:
             a.scale = scale.data_ptr(); a.shift = shift.data_ptr()
+            if self._groups > 1:
+                a.group_images = x.N // self._groups
         if add is not None:
             a.add = add.t.data_ptr(); a.add_pitch = add.pitch
         a.out = out.t.data_ptr(); a.out_pitch = out.pitch; a.out_coff = out_coff
@@ -551,7 +569,7 @@ class HighResolutionNet(nn.Module):
     def forward_samples(self, x: torch.Tensor, n_samples: int = 1, dropout_masks: Optional[Sequence] = None,
                         seeds: Optional[Sequence[int]] = None, hflip_back: bool = False,
                         out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0,
-                        vflip_back: bool = False) -> torch.Tensor:
+                        vflip_back: bool = False, groups: int = 1, group_flips: Optional[Sequence[int]] = None) -> torch.Tensor:
         """(n_samples, B, C, H, W) logits: backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
         [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
         (a HorizontalFlip TTA view, test_2D.py:304-309); vflip_back: along H (VerticalFlip, the 8-view extension)."""
@@ -562,12 +580,27 @@ class HighResolutionNet(nn.Module):
         self._st = _lib.stream_ptr()
         self._hold = []
         n, _, h, w = x.shape
-        feats = self._backbone(x)
+        # groups > 1: x holds `groups` independent BatchNorm batches of n / groups consecutive images (the TTA views of
+        # one image batch, test_2D.py:299-311: every view is its own forward with its own batch statistics); group g is
+        # un-flipped by group_flips[g] (bit 0 horizontal, bit 1 vertical) and lands in slot offset slot_offset + g
+        if groups < 1 or n % groups:
+            raise ValueError("forward_samples: the batch must hold `groups` equal groups of images")
+        if groups > 1 and n_samples != 1:
+            raise ValueError("forward_samples: batched view groups go with n_samples = 1")
+        self._groups = groups
+        try:
+            feats = self._backbone(x)
+        except Exception:
+            self._groups = 1
+            raise
         user_out = out is not None
         if out is None:
             out = torch.empty((n_samples * n, self.num_classes, h, w), dtype=torch.float32, device=dev)
         code = (1 if hflip_back else 0) | (2 if vflip_back else 0)
         flip = torch.full((n,), code, dtype=torch.int32, device=dev) if code else None
+        per = n // groups
+        if groups > 1 and group_flips is not None:
+            flip = torch.tensor([int(group_flips[i // per]) for i in range(n)], dtype=torch.int32, device=dev)
         for t in range(n_samples):
             mode = _lib.VX_DROP_NONE
             masks = None
@@ -583,13 +616,16 @@ class HighResolutionNet(nn.Module):
                 else:
                     seed = self.seed * 1000003 + self._calls
                     self._calls += 1
-            if user_out:  # image b, sample t -> slot b * slot_stride + slot_offset + t  (per-image (Npred, C, H, W) stacks)
+            if user_out and groups > 1:   # image b of view g -> slot b * slot_stride + slot_offset + g
+                dst = torch.tensor([(i % per) * slot_stride + slot_offset + i // per for i in range(n)], dtype=torch.int32, device=dev)
+            elif user_out:  # image b, sample t -> slot b * slot_stride + slot_offset + t  (per-image (Npred, C, H, W) stacks)
                 dst = torch.arange(n, dtype=torch.int32, device=dev) * slot_stride + (slot_offset + t)
             else:
                 dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
             self._hold.append(dst)
             self._head(feats, out, (h, w), dst, flip, mode, seed, masks)
         self._hold_last = self._hold  # keep everything alive until the stream has consumed it
+        self._groups = 1
         if user_out:
             return out
         return out.view(n_samples, n, self.num_classes, h, w)

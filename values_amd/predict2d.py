@@ -35,10 +35,12 @@ def tta_views_8(x: torch.Tensor, x_noisy: torch.Tensor):
 
 @torch.no_grad()
 def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False, hflip_views: Optional[Sequence[bool]] = None,
-                      dropout_masks=None, seeds=None, vflip_views: Optional[Sequence[bool]] = None) -> torch.Tensor:
+                      dropout_masks=None, seeds=None, vflip_views: Optional[Sequence[bool]] = None,
+                      batch_views: bool = True) -> torch.Tensor:
     """data: (B,3,H,W) tensor, or with tta a list of view tensors (the dataset's 4 views, cityscapes_dataset.py:76-99,
     or the 8 of tta_views_8) and hflip_views[i] = "HorizontalFlip" in transforms of view i (vflip_views likewise).
-    Returns logits (B, Npred_total, C, H, W)."""
+    Returns logits (B, Npred_total, C, H, W).  batch_views: the TTA views travel as ONE batch whose BatchNorm statistics
+    are kept per view (vx_bn_finalize_groups) -- the same numbers as one forward per view, an eighth of the launches."""
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     views = list(data) if tta else [data]
@@ -52,7 +54,13 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
     out = torch.empty((B * total, C, H, W), dtype=torch.float32, device=dev)
     for mi, model in enumerate(models):
         base = mi * per_model
-        if tta:
+        if tta and batch_views and len(views) > 1 and dropout_masks is None:
+            codes = [(1 if (hflip_views and hflip_views[vi]) else 0) | (2 if (vflip_views and vflip_views[vi]) else 0)
+                     for vi in range(len(views))]
+            model.forward_samples(torch.cat([v.to(dev, torch.float32) for v in views], 0), 1,
+                                  seeds=None if seeds is None else [seeds[mi] * 131], out=out, slot_stride=total,
+                                  slot_offset=base, groups=len(views), group_flips=codes)
+        elif tta:
             for vi, view in enumerate(views):
                 model.forward_samples(view, 1, hflip_back=bool(hflip_views[vi]) if hflip_views else False,
                                       vflip_back=bool(vflip_views[vi]) if vflip_views else False,

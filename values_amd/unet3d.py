@@ -170,8 +170,9 @@ class UNet3D(nn.Module):
 
     def range_max(self, reset: bool = False) -> float:
         """Largest |activation| an un-normalised layer (center, decoder, transposed convs) has handed to a split-fp16
-        convolution since the last reset, over all forwards of this model (a device word the kernels raise with an atomic
-        max; reading it synchronises).  At or beyond 65504 the fp16 split of that value overflowed: the logits of that
+        convolution since the last reset, over all forwards of this model -- 0.0 while everything stayed below 32768 (a
+        device word the kernels raise with an atomic max once a value gets within a factor two of the limit; reading it
+        synchronises).  At or beyond 65504 the fp16 split of that value overflowed: the logits of that
         forward are invalid.  The native-fp32 kernels (vx_config.conv_fp32 = 1) have no such limit."""
         worst = 0.0
         for flag in self._range.values():

@@ -542,13 +542,14 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
     roof = None
     if rank == 0 and not args.no_roofline and hasattr(model, "profile_forward"):
-        roof = model.profile_forward(views[0], peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS)
+        roof = model.profile_forward(torch.cat(views, 0), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=len(views))
     line = {"metric": "uncertainty-images/sec (HRNet-W18, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: HRNet-W18 (training-mode BatchNorm as the reference runs it), {W}x{H}, {NC} classes, "
                                    "8 TTA views per image + softmax / entropy / MI reduction",
-                       "images_per_gpu_per_step": B, "forwards_per_gpu_per_step": 8,
+                       "images_per_gpu_per_step": B, "views_per_image": 8,
+                       "batching": "the 8 views of a step travel as one batch of 8 B images with BatchNorm statistics per view",
                        "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": None}
     line.update(summarise(times, B * world * args.steps, args.steps))

@@ -630,7 +630,7 @@ class HighResolutionNet(nn.Module):
             return out
         return out.view(n_samples, n, self.num_classes, h, w)
 
-    def profile_forward(self, x: torch.Tensor, peak_tflops: float, hbm_gbs: float, reps: int = 3):
+    def profile_forward(self, x: torch.Tensor, peak_tflops: float, hbm_gbs: float, reps: int = 3, groups: int = 1):
         """bench.py's roofline leg for the 2D path: one forward per rep on ONE stream with a HIP event pair around every
         convolution launch; the dominant convolution kernel instance with its algorithmic TFLOP/s and GB/s and the roof
         that binds it (the larger of flops / matrix roof and bytes / HBM roof)."""
@@ -641,7 +641,7 @@ class HighResolutionNet(nn.Module):
         try:
             for rep in range(reps + 1):
                 self._prof = []
-                self.forward_samples(x, 1)
+                self.forward_samples(x, 1, groups=groups)
                 torch.cuda.synchronize()
                 rows, self._prof = self._prof, None
                 if rep == 0:

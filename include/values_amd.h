@@ -77,6 +77,7 @@ typedef struct vx_config {
   int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
   int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
+  int32_t s16_no_upfuse;   /* separate upscale2 launch + concat read instead of the up-convolution fused into expand_1_1 */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);
@@ -189,8 +190,19 @@ typedef struct vx_conv3d_args {
   const uint32_t* seed_dev; /* nullable device word ADDED to drop_seed / in_drop_seed at run time (a captured hipGraph
                                replays with the arguments it was captured with; fresh dropout bits per replay = update
                                this word).  Same field in vx_norm_args / vx_convT_args / vx_unet3d_run. */
+  /* Optional fused UP-CONVOLUTION (only where vx_conv3d_k3_upfuse_ok(D, H, W, Cin, Cout)): the decoder's
+   * upscale -> torch.cat([up, skip], 1) -> expand (unet3D_module.py:332-356) in one kernel.  Channels [0, 8) of the
+   * conv's input are ConvTranspose3d(16 -> 8, k = 2, s = 2)(up_in) + up_b, computed while the tiles are staged and never
+   * stored; `in` then holds only the skip half: the concat buffer as before (in_xblk > 0, its up half is not read) or a
+   * plain [N][D][H][W][in_pitch] tensor whose channels [0, 8) are the skip (in_xblk == 0).  The prologue fields apply to
+   * the skip half.  range_flag also covers the up values. */
+  const float* up_in;   /* nullable: [N][D/2][H/2][W/2][up_pitch], channels [0, 16) used */
+  const float* up_w;    /* vx_pack_convT_k2s2(Cin = 16, Cout = 8) */
+  const float* up_b;    /* [8] */
+  int32_t up_pitch;
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
+int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
  * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
  * skip half (s = 1, written by vx_norm_act_drop_pool) as alternating DENSE blocks of xb voxels, so both producers

@@ -637,7 +637,7 @@ def _hash_mask(seed, layer, n, c, d, h, w):
 
 
 def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, stats=False, xblk=0, head=None,
-              pre=None, out_xblk=0):
+              pre=None, out_xblk=0, up=None, in_pitch=None):
     """one vx_conv3d_k3 launch on a channels-last (or x-blocked) device input; returns (out NCDHW cpu, stats, head)"""
     lib = _lib.load()
     assert lib.vx_conv3d_k3_prologue_ok(d, h, wd, cin, 8) == 1
@@ -648,9 +648,15 @@ def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, s
     a.w_family = lib.vx_conv3d_k3_family(cin, 8)
     out = torch.full((n, d, h, wd, 16 if out_xblk else 8), -77.0, dtype=torch.float32, device=dev())
     a.in_ = x_cl.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
-    a.in_pitch, a.out_pitch, a.out_coff = cin, 8, 0
+    a.in_pitch, a.out_pitch, a.out_coff = in_pitch or cin, 8, 0
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, wd, cin, 8
     a.act, a.drop_mode, a.drop_seed, a.drop_layer, a.in_xblk = act, drop, seed, layer, xblk
+    if up is not None:   # (coarse channels-last device tensor, torch ConvTranspose3d weight (16, 8, 2, 2, 2), bias)
+        coarse, uw, ub = up
+        uwd, ubd = uw.float().contiguous().to(dev()), ub.float().contiguous().to(dev())
+        uwp = torch.empty(lib.vx_convT_k2s2_packed_floats(16, 8), dtype=torch.float32, device=dev())
+        _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(uwd), _lib.ptr(uwp), 16, 8, _lib.stream_ptr()), "packT")
+        a.up_in, a.up_w, a.up_b, a.up_pitch = coarse.data_ptr(), uwp.data_ptr(), ubd.data_ptr(), coarse.shape[-1]
     a.out_xblk, a.out_half = out_xblk, 1
     keep = [wdv, bd, wp, out]
     st = None
@@ -761,6 +767,60 @@ def test_conv3d_xp8_prologue_matches_oracle(cin, shape, rep, xblk, pmode):
     if st is not None:
         s = st.double().sum(1)
         np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape,xblk,pitch,pmode", [((2, 8, 16, 64), 4, 16, None), ((3, 12, 8, 32), 0, 16, None),
+                                                    ((1, 16, 24, 96), 4, 20, 1), ((2, 8, 8, 32), 0, 16, 0)])
+def test_conv3d_xp8_fused_upconvolution_matches_oracle(shape, xblk, pitch, pmode, vxcfg):
+    """upscale -> torch.cat([up, skip], 1) -> expand (unet3D_module.py:332-356) in ONE launch: the transposed
+    convolution of the coarse tensor is evaluated while the conv stages its tiles; the up half is neither read nor
+    written.  Skip half from a concat buffer (whose up half holds garbage) or from a plain 8-channel tensor; with and
+    without the normalise-on-load prologue on the skip half; coarse pitch > 16."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_upfuse_ok(d, h, w, 16, 8) == 1 and lib.vx_conv3d_k3_upfuse_ok(d, h, w, 8, 8) == 0
+    coarse = torch.from_numpy(formula_tensor((n, 16, d // 2, h // 2, w // 2), 331, scale=1.5)).float()
+    uw = torch.from_numpy(formula_tensor((16, 8, 2, 2, 2), 332, scale=0.25)).float()
+    ub = torch.from_numpy(formula_tensor((8,), 333, scale=0.3)).float()
+    raw = (torch.from_numpy(formula_tensor((n, 8, d, h, w), 334, scale=2.0)) + 0.4).float()
+    wt = torch.from_numpy(formula_tensor((8, 16, 3, 3, 3), 335, scale=(1.0 / (27 * 16)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((8,), 336, scale=0.2))
+    up_ref = F.conv_transpose3d(coarse.double(), uw.double(), ub.double(), stride=2)
+    pre = None
+    skip = raw.double()
+    if pmode is not None:
+        mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+        rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+        keep = _hash_mask(77, 1, n, 8, d, h, w) if pmode else torch.ones((n, 8, d, h, w), dtype=torch.float64)
+        skip = F.leaky_relu((raw.double() - mean.cpu().double().view(n, 8, 1, 1, 1)) * rstd.cpu().double().view(n, 8, 1, 1, 1), 0.01)
+        skip = skip * keep * (2.0 if pmode else 1.0)
+        pre = (mean, rstd, 1, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 77, 1)
+    ref = F.conv3d(torch.cat([up_ref, skip], 1), wt.float().double(), b.float().double(), padding=1)
+    cd = cl(coarse)
+    if pitch > 16:
+        cd = torch.cat([cd, torch.full(cd.shape[:-1] + (pitch - 16,), 9.0)], -1).contiguous()
+    cd = cd.to(dev())
+    garbage = torch.full((n, 8, d, h, w), 1e30)
+    xd = (to_xblk(garbage, raw, xblk) if xblk else cl(raw)).to(dev())
+    got, _, _, mx = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=93, layer=15,
+                              xblk=xblk, in_pitch=8 if not xblk else None, pre=pre, up=(cd, uw, ub))
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8_kernel<2,1,%d,1>" % (0 if pre is None else 1))
+    want = F.leaky_relu(ref, 0.01) * _hash_mask(93, 15, n, 8, d, h, w) * 2
+    err = (got.double() - want).abs().max().item()
+    assert err < 4e-5, err
+    assert mx == 0.0
+    got, _, _, _ = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None,
+                             pre=pre, up=(cd, uw, ub))                       # no dropout (eval-mode members)
+    assert (got.double() - F.leaky_relu(ref, 0.01)).abs().max().item() < 4e-5
+    # range guard: up values near the fp16 limit are reported although they are never stored
+    _, _, _, mxb = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None,
+                             pre=pre, up=(cd, uw, ub + 4.5e4))
+    assert mxb > 4e4
+    # refused, not silently ignored, where the column kernel does not run
+    vxcfg.set(s16_no_upfuse=1)
+    with pytest.raises(_lib.VxError):
+        _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None, pre=pre,
+                  up=(cd, uw, ub))
 
 
 def test_conv3d_xp8_agrees_with_general_kernel_and_refuses_what_it_cannot_do(vxcfg):

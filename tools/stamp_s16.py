@@ -3,7 +3,8 @@
 late (4..7) waves (s_memtime stamps, VX_CONV_STAMPS build; nothing of this is in the product library).
 Build:  mkdir -p /tmp/stamps && cp values_amd/csrc/*.hip values_amd/csrc/*.h values_amd/csrc/*.cpp values_amd/csrc/Makefile /tmp/stamps ...
         (tools/build_stamps.sh does it)
-Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head ...]   with VX_S16_PING=1 etc. to pick the variant"""
+Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head[:up] ...]   with VX_S16_PING=1 etc. to pick the variant
+        (up = 1: the fused up-convolution of conv3d_xp8.hip, the skip half from a plain 8-channel tensor)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -13,8 +14,10 @@ lib = _lib.load()
 dev = torch.device("cuda", 0)
 N = int(os.environ.get("STAMP_N", "160"))
 for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
-    cin, cout, edge, act, drop, head = map(int, spec.split(":"))
-    x = torch.randn((N, edge, edge, edge, cin), device=dev)
+    f = list(map(int, spec.split(":")))
+    cin, cout, edge, act, drop, head = f[:6]
+    up = f[6] if len(f) > 6 else 0
+    x = torch.randn((N, edge, edge, edge, 8 if up else cin), device=dev)
     w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05; b = torch.zeros(cout, device=dev)
     wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
     _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(w), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
@@ -24,7 +27,13 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
     a = _lib.ConvArgs()
     a.w_family = lib.vx_conv3d_k3_family(cin, cout)
     a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
-    a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+    a.in_pitch, a.out_pitch, a.out_coff = (8 if up else cin), cout, 0
+    if up:
+        coarse = torch.randn((N, edge // 2, edge // 2, edge // 2, 16), device=dev)
+        uw = torch.randn((16, 8, 2, 2, 2), device=dev) * 0.2; ub = torch.zeros(8, device=dev)
+        uwp = torch.empty(lib.vx_convT_k2s2_packed_floats(16, 8), dtype=torch.float32, device=dev)
+        _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(uw), _lib.ptr(uwp), 16, 8, _lib.stream_ptr()), "packT")
+        a.up_in, a.up_w, a.up_b, a.up_pitch = coarse.data_ptr(), uwp.data_ptr(), ub.data_ptr(), 16
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, 1, 2
     st = None

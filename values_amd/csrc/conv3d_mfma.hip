@@ -635,6 +635,10 @@ extern "C" int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout) 
   return vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
+extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
+  return Cin == 16 && !vx_cfg().s16_no_upfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
   const ConvCfg c = conv_config(Cin, Cout);
@@ -664,6 +668,16 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.out_xblk && ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || a.W % a.out_xblk || (a.out_half != 0 && a.out_half != 1)))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: bad concat output (xblk=%d, half=%d, W=%d)", a.out_xblk, a.out_half, a.W);
   if ((a.in_mean == nullptr) != (a.in_rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: in_mean / in_rstd must come together");
+  if (a.up_in) {
+    if (!a.up_w || !a.up_b) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: fused up-convolution without weights");
+    if (!vx_conv3d_k3_upfuse_ok(a.D, a.H, a.W, a.Cin, a.Cout) || a.drop_mode == VX_DROP_MASK || a.stats_partial || a.head_out)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: no fused up-convolution for this layer (see vx_conv3d_k3_upfuse_ok; hash or no "
+              "dropout, no statistics, no head): %dx%dx%d, %d -> %d", a.D, a.H, a.W, a.Cin, a.Cout);
+    if (a.up_pitch < 16 || a.up_pitch % 4 || !vx_aligned16(a.up_in) || !vx_aligned16(a.up_b))
+      VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: up_in pitch %d (>= 16, multiple of 4 floats) / alignment", a.up_pitch);
+    if ((int64_t)(a.D / 2 + 2) * (a.H / 2) * (a.W / 2) * a.up_pitch * 4 >= (1ll << 31))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: one coarse sample must stay below 2 GiB");
+  }
   if (a.in_drop_mode != VX_DROP_NONE && a.in_drop_mode != VX_DROP_HASH) VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: in_drop_mode %d", a.in_drop_mode);
   if (a.out && !a.out_xblk && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
@@ -671,7 +685,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     if (a.in_xblk != 1 && a.in_xblk != 2 && a.in_xblk != 4) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: in_xblk must be 0, 1, 2 or 4");
     if (a.W % a.in_xblk) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: W=%d not a multiple of in_xblk=%d", a.W, a.in_xblk);
     if (a.Cin % 16) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: concat input needs Cin %% 16 == 0 (two halves of Cin/2)");
-  } else if (a.in_pitch < a.Cin || a.in_pitch % 4) {
+  } else if (a.in_pitch < (a.up_in ? a.Cin / 2 : a.Cin) || a.in_pitch % 4) {
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: input pitch must be a multiple of 4 floats and cover the channels");
   }
   if (!vx_aligned16(a.in) || !vx_aligned16(a.out) || !vx_aligned16(a.w_packed) || !vx_aligned16(a.bias))
@@ -706,8 +720,8 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
-  if (a.in_mean || a.out_xblk)
-    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output are only available where "
+  if (a.in_mean || a.out_xblk || a.up_in)
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);
   {

@@ -17,6 +17,14 @@
 //     batch the T samples of a volume read the SAME raw tensor (in_repeat = T) with T different dropout patterns.
 //   * the two waves of a SIMD are staggered as in conv3d_s16.hip (DB = 2): waves 0..3 stage, multiply, store; waves 4..7
 //     store the previous item, multiply, stage.
+//   * optional FUSED UP-CONVOLUTION (UP = 1, two-chunk layer): the up half of the decoder's concat input is never read --
+//     and never written: the transposed 2x2x2 / stride-2 convolution that produces it (unet3D_module.py:332-356,
+//     upscale -> cat -> expand) is evaluated while the step is staged.  A fine voxel depends on ONE coarse voxel, so the
+//     up half of a step is 24 small GEMMs [(dx, co) 16 rows] x [16 coarse voxels] x [16 ci] per workgroup, one class
+//     (z-plane, y-parity) per wave pair: the B operands come straight from global memory (a wave instruction reads 16
+//     coarse voxels x 64 B, contiguous), three split-fp16 v_mfma_f32_16x16x16_f16 per tile, and the result (bias as the
+//     C operand, zero outside the volume) is split and written into the LDS image where the staged loads would have put
+//     it.  5.4 GB of HBM traffic per 320 samples (the write and the read of `up`) and one launch disappear.
 // Restrictions (the dispatch falls back to conv3d_s16.hip otherwise): W % 32 == 0, H % 8 == 0, D % 4 == 0, Cout == 8,
 // Cin in {8, 16}, dropout by hash or none (injected masks take the general kernels).
 #include "s16_common.h"
@@ -50,8 +58,9 @@ struct Xp8Args {
 // NCH: chunks of 8 input channels (1, 2).  EPI: 0 bias + statistics + store (an InstanceNorm follows), 1 LeakyReLU +
 // hash dropout + store, 2 = 1 with the fused 1x1x1 head instead of the store, 3 LeakyReLU / ReLU / none without dropout
 // (run-time act) + store.  PRE: 1 = the prologue above on the LAST chunk of the input.
-template <int NCH, int EPI, int PRE>
+template <int NCH, int EPI, int PRE, int UP>
 __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
+  static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
   constexpr int NW = 8, NTH = 512;
   constexpr int TZ = 4 / NCH;
   constexpr int R = TZ;                       // column tiles (y-rows of one z-plane) per wave
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
       const int blk = dx >= 0 ? dx / xb : -((-dx + xb - 1) / xb);
       xf = (blk * 2 + chunk) * xb * 8 + (dx - blk * xb) * 8 + qq * 4;
     } else {
-      xf = dx * a.in_pitch + chunk * 8 + qq * 4;
+      xf = dx * a.in_pitch + (UP ? 0 : chunk * 8) + qq * 4;   // UP: `in` is the skip tensor alone
     }
     voff[it] = (unsigned)(((dz * a.H + dy) * rowf + xf + biasf) * 4);
     ldst[it] = chunk * CHUNK_H + (hx & 1) * PP * 8 + ((pz * HY + hy) * HXP + (hx >> 1)) * 8 + qq * 4;
@@ -121,6 +130,47 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
   }
   const size_t in_sample = (size_t)a.D * a.H * rowf;
   const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
+
+  // ---- fused up-convolution: this wave's class and its three column tiles (fixed for the kernel's life) ----
+  // wave -> (plane u_pz of the step, y-parity u_ay, half u_th of the class's 6 column tiles).  Column c of a class is the
+  // coarse voxel (Yi, Xi) = (c / 18, c % 18) of the 5 x 18 coarse positions whose fine row of parity u_ay lies in the
+  // staged 10 x 34 window; rows of the product are (dx, co), so lane (m, g) ends with channels 4 (g & 1) .. + 3 of the
+  // fine voxel x = 2 X + (g >> 1) -- the piece layout of the staged loads.
+  constexpr int UT = 3;
+  const int u_pz = wave >> 2, u_ay = (wave >> 1) & 1, u_th = wave & 1;
+  const int Hc = a.H >> 1, Wc = a.W >> 1;
+  const int urow = Wc * a.up_pitch;
+  const int ubiasf = (Hc + 1) * urow + a.up_pitch;
+  unsigned u_voff[UP ? UT : 1];
+  int u_ldst[UP ? UT : 1];
+  unsigned ub_always = 0, ub_xlo = 0, ub_xhi = 0, ub_ylo = 0, ub_yhi = 0, u_nowrite = 0;
+  f16x4 u_ah = {0, 0, 0, 0}, u_al = {0, 0, 0, 0};
+  if constexpr (UP != 0) {
+#pragma unroll
+    for (int i = 0; i < UT; ++i) {
+      const int c = 16 * (UT * u_th + i) + m;
+      const int Yi = c / 18, Xi = c % 18;
+      const int Yrel = Yi + 1 - u_ay;                   // row of the 6-row coarse window (row 0 = coarse y of fine y = -1)
+      const int zrel = u_pz ? 0 : -1;                   // plane 2 s - 1 comes from coarse plane s - 1, plane 2 s from s
+      u_voff[i] = (unsigned)(((zrel * Hc + Yrel - 1) * urow + (Xi - 1) * a.up_pitch + g * 4 + ubiasf) * 4);
+      const int hy = 2 * Yrel + u_ay - 1, hx = 2 * Xi + (g >> 1) - 1;
+      u_ldst[i] = (hx & 1) * PP * 8 + ((u_pz * HY + hy) * HXP + (hx >> 1)) * 8 + (g & 1) * 4;
+      if (c >= 90) { ub_always |= 1u << i; u_nowrite |= 1u << i; }
+      if (hx < 0 || hx >= HX) u_nowrite |= 1u << i;
+      if (Xi == 0) ub_xlo |= 1u << i;
+      if (Xi == 17) ub_xhi |= 1u << i;
+      if (Yrel == 0) ub_ylo |= 1u << i;
+      if (Yrel == 5) ub_yhi |= 1u << i;
+    }
+    // A operand: row m = (dx, co), k = ci = 4 g .. 4 g + 3, tap (dz, dy) = (1 - u_pz, u_ay); vx_pack_convT_k2s2 layout
+    // [dz][dy][ci][dx][co]
+    f32x4 wv;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      wv[jj] = a.up_w[(((((1 - u_pz) * 2 + u_ay) * 16 + 4 * g + jj) * 2) + (m >> 3)) * 8 + (m & 7)];
+    vx_split4(wv, u_ah, u_al);
+  }
+  const size_t up_sample = (size_t)(a.D >> 1) * Hc * urow;
 
   // ---- compute-phase constants ----
   // B fragment of (kz, row j): s_img[chunk][prec][parity g & 1][(slot * HY + ly0 + j) * HXP + m + (g >> 1)]
@@ -188,6 +238,8 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
 
   // ---- register staging: the loads of one step (and what its commit needs to know) ----
   f32x4 ibuf[IN_IT];
+  f32x4 ubuf[UP ? UT : 1];
+  unsigned p_ubad = 0;
   f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
   unsigned p_bad = 0, p_e0 = 0, p_key = 0;
 
@@ -209,10 +261,28 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
         (void*)(a.in + (size_t)nin * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
+      if (UP != 0 && !(it & 1)) continue;               // chunk 0 is computed, not loaded
       const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
     p_bad = bad;
+    if constexpr (UP != 0) {
+      unsigned ub = ub_always;
+      if (tx == 0) ub |= ub_xlo;
+      if (tx == ka.tiles_x - 1) ub |= ub_xhi;
+      if (ty == 0) ub |= ub_ylo;
+      if (ty == ka.tiles_y - 1) ub |= ub_yhi;
+      if (!have || (c.s == 0 && u_pz == 0) || (c.s == KZ && u_pz == 1)) ub = 0xFFFFFFFFu;
+      const unsigned usoff = (unsigned)(((c.s * Hc + ty * 4) * urow + tx * 16 * a.up_pitch) * 4);
+      const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.up_in + (size_t)n * up_sample - ubiasf), 0, VX_NUMREC, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < UT; ++i) {
+        const unsigned vo = ((ub >> i) & 1u) ? VX_OOB : u_voff[i];
+        ubuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrd, (int)vo, (int)usoff, 0));
+      }
+      p_ubad = ub;
+    }
     if constexpr (PRE != 0) {
       if (have) {
         p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq_thread * 4);
@@ -223,6 +293,10 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
     }
   };
 
+  float rmax = 0.f;   // largest |value| this wave stored or produced (range guard of the split-fp16 consumers)
+  f32x4 ubias4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (UP != 0) ubias4 = *reinterpret_cast<const f32x4*>(a.up_b + (g & 1) * 4);
+
   auto commit = [&](int grp) {
     const int gofs = grp * GRP_H;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f};
@@ -232,6 +306,7 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
     }
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
+      if (UP != 0 && !(it & 1)) continue;
       if (tid + (NCH == 2 ? (it >> 1) : it) * NTH < PPS) {
         f32x4 v = ibuf[it];
         if constexpr (PRE != 0) if (NCH == 1 || (it & 1)) {
@@ -253,12 +328,39 @@ __global__ __launch_bounds__(512) void conv3d_xp8_kernel(Xp8Args ka) {
         *reinterpret_cast<f16x4*>(s_img + gofs + ldst[it] + PREC_H) = lo;
       }
     }
+    if constexpr (UP != 0) {
+      // the up half of the step: ConvTranspose3d(k = 2, s = 2) of the coarse voxels just loaded, three split products
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      f16x4 ubh[UT], ubl[UT];
+#pragma unroll
+      for (int i = 0; i < UT; ++i) vx_split4(ubuf[i], ubh[i], ubl[i]);
+      // vx_split4 writes the lo halves from inline assembly: the compiler does not know a VALU result is about to be a
+      // matrix operand and inserts no wait states for it (measured: stale lo operands without this)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < UT; ++i) {
+        const f16x4 bh = ubh[i], bl = ubl[i];
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16f16(u_ah, bh, ubias4, 0, 0, 0);
+        f32x4 dx = __builtin_amdgcn_mfma_f32_16x16x16f16(u_ah, bl, zero, 0, 0, 0);
+        dx = __builtin_amdgcn_mfma_f32_16x16x16f16(u_al, bh, dx, 0, 0, 0);
+        f32x4 v = d + dx * (1.0f / 2048.f);
+        if ((p_ubad >> i) & 1u) v = zero;               // outside the volume: the conv's zero padding, not the bias
+        rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        f16x4 hi, lo;
+        vx_split4(v, hi, lo);
+        if (!((u_nowrite >> i) & 1u)) {
+          *reinterpret_cast<f16x4*>(s_img + gofs + u_ldst[i]) = hi;
+          *reinterpret_cast<f16x4*>(s_img + gofs + u_ldst[i] + PREC_H) = lo;
+        }
+      }
+    }
   };
 
   // ---- accumulators ----
   f32x4 acc[R], accx[R];
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-  float rmax = 0.f;   // largest |value| this wave stored (range guard of the split-fp16 consumers)
 
   // the multiply phase of the item whose first plane sits in slot rb (slots rb .. rb + TZ + 1, modulo NZ)
   auto multiply = [&](int rb) {
@@ -491,13 +593,13 @@ bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout) {
   return Cout == 8 && (Cin == 8 || Cin == 16) && W % 32 == 0 && H % 8 == 0 && D % 4 == 0 && W >= 32 && H >= 8 && D >= 8;
 }
 
-template <int NCH, int EPI, int PRE>
+template <int NCH, int EPI, int PRE, int UP>
 static int launch_xp8(const Xp8Args& ka, hipStream_t s) {
   constexpr int TZ = 4 / NCH, NZ = 3 * TZ, ZP = 170;
   constexpr int PP = ((NZ * ZP + 15) / 16) * 16;
   constexpr size_t lds = (size_t)NCH * 2 * 2 * PP * 8 * 2 + (size_t)NCH * (9 * 2 * 32 * 8) * 2 + 8 * 16 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3d_xp8_kernel<NCH, EPI, PRE>;
+  auto kern = conv3d_xp8_kernel<NCH, EPI, PRE, UP>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -507,7 +609,7 @@ static int launch_xp8(const Xp8Args& ka, hipStream_t s) {
   int gx = 256;
   if (vx_cfg().s16_per_cu > 0) gx = 256 * vx_cfg().s16_per_cu;
   if (gx > ka.ncols) gx = ka.ncols;
-  static const char* kname = vx_kname("conv3d_xp8_kernel<%d,%d,%d>", NCH, EPI, PRE);
+  static const char* kname = vx_kname("conv3d_xp8_kernel<%d,%d,%d,%d>", NCH, EPI, PRE, UP);
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(xp8)");
@@ -540,9 +642,13 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   else epi = 3;
   if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // head without dropout: general kernel
   if (epi == 1 && a.act != VX_ACT_LRELU) return 1;
-#define XP8_CASE(N_, E_, P_) if (nch == N_ && epi == E_ && pre == P_) return launch_xp8<N_, E_, P_>(ka, s)
-  XP8_CASE(1, 0, 0); XP8_CASE(1, 0, 1); XP8_CASE(1, 1, 0); XP8_CASE(1, 2, 0); XP8_CASE(1, 3, 0); XP8_CASE(1, 3, 1);
-  XP8_CASE(2, 1, 0); XP8_CASE(2, 1, 1); XP8_CASE(2, 3, 0); XP8_CASE(2, 3, 1);
+  const int up = a.up_in ? 1 : 0;
+#define XP8_CASE(N_, E_, P_, U_) if (nch == N_ && epi == E_ && pre == P_ && up == U_) return launch_xp8<N_, E_, P_, U_>(ka, s)
+  XP8_CASE(1, 0, 0, 0); XP8_CASE(1, 0, 1, 0); XP8_CASE(1, 1, 0, 0); XP8_CASE(1, 2, 0, 0); XP8_CASE(1, 3, 0, 0); XP8_CASE(1, 3, 1, 0);
+  XP8_CASE(2, 1, 0, 0); XP8_CASE(2, 1, 1, 0); XP8_CASE(2, 3, 0, 0); XP8_CASE(2, 3, 1, 0);
+  XP8_CASE(2, 1, 0, 1); XP8_CASE(2, 1, 1, 1); XP8_CASE(2, 3, 0, 1); XP8_CASE(2, 3, 1, 1);
 #undef XP8_CASE
+  if (up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): no fused up-convolution for this epilogue (act=%d, drop_mode=%d, statistics=%d)",
+                  a.act, a.drop_mode, a.stats_partial ? 1 : 0);
   return 1;   // not taken: the caller uses the general kernel
 }

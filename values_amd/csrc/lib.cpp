@@ -74,6 +74,7 @@ static void cfg_from_env() {
   g_cfg.dma_nw16 = env_int("VX_DMA_NW16", 0);
   g_cfg.c8_tile16 = env_int("VX_C8_TILE16", 0);
   g_cfg.s16_range_check = env_int("VX_S16_RANGE_CHECK", 1);
+  g_cfg.s16_no_upfuse = env_int("VX_S16_NO_UPFUSE", 0);
 }
 
 const vx_config& vx_cfg() {

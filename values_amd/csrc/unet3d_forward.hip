@@ -148,8 +148,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1,
-                  const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0) {
+                  const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0,
+                  const float* up_in = nullptr, int up_idx = 0, int up_pitch = 0) {
     vx_conv3d_args a = {};
+    if (up_in) { a.up_in = up_in; a.up_w = w->up_w[up_idx]; a.up_b = w->up_b[up_idx]; a.up_pitch = up_pitch; }
     a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
     if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
       a.head_out = r->logits; a.head_w = w->final_w; a.head_b = w->final_b; a.head_C = NC;
@@ -227,6 +229,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // contr_1_2's raw output straight into the skip half + a pooling-only pass + expand_1_1 normalising its skip half:
   // measured NEUTRAL to slightly slower (the pass shrinks 1.09 -> 0.59 ms per 320 samples, expand_1_1 grows 2.33 -> 2.95:
   // its staging is instruction-bound and the hash per piece is not free) -- opt-in (vx_config.s16_skip_raw)
+  // upscale2 inside expand_1_1: the up half of CAT_0 is computed from B_1 while expand_1_1 stages its tiles and never
+  // exists in memory (conv3d_xp8.hip, UP = 1)
+  const bool fuse_up = dm != VX_DROP_MASK && F == 8 && vx_conv3d_k3_upfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   const bool fuse0 = pre0 && vx_cfg().s16_skip_raw && vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
@@ -312,13 +317,18 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int C = L.C;
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
+    const float* up_in = l == 0 && fuse_up ? p.B[1] : nullptr;
     if (l == 0 && fuse0)   // the skip half of CAT_0 is contr_1_2's raw output: normalise + LeakyReLU + dropout layer 1 on load
-      VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 1, 1,
-                              p.mean0, p.rstd0));
+      VX_STEP(up_in ? "upscale2+expand_1_1" : kConv[wi],
+              conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 1, 1,
+                   p.mean0, p.rstd0, 0, 0, up_in, 3, 2 * C));
+    else if (up_in)
+      VX_STEP("upscale2+expand_1_1", conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr,
+                                          xblk_of(L.W), -1, 1, nullptr, nullptr, 0, 0, up_in, 3, 2 * C));
     else
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
-    if (l > 0) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
+    if (l > 1 || (l == 1 && !fuse_up)) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------
   if (!fuse_head)

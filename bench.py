@@ -74,15 +74,32 @@ def layer_table(F=8, S=64):
 
 
 def launch_cost(kind, ci, co, edge, N):
-    """(algorithmic FLOPs, algorithmic bytes) of one launch over N samples."""
+    """(algorithmic FLOPs, input bytes, output bytes, weight bytes) of one layer over N samples."""
     vox = edge ** 3
     if kind == "conv":
-        return 2.0 * 27 * ci * co * vox * N, 4.0 * ((ci + co) * vox * N + 27 * ci * co)
+        return 2.0 * 27 * ci * co * vox * N, 4.0 * ci * vox * N, 4.0 * co * vox * N, 4.0 * 27 * ci * co
     if kind == "convT":
-        return 2.0 * ci * co * 8 * vox * N, 4.0 * ((ci + 8 * co) * vox * N + 8 * ci * co)
+        return 2.0 * ci * co * 8 * vox * N, 4.0 * ci * vox * N, 4.0 * 8 * co * vox * N, 4.0 * 8 * ci * co
     if kind == "conv1x1":
-        return 2.0 * ci * co * vox * N, 4.0 * (ci + co) * vox * N
-    return 0.0, 0.0
+        return 2.0 * ci * co * vox * N, 4.0 * ci * vox * N, 4.0 * co * vox * N, 4.0 * ci * co
+    return 0.0, 0.0, 0.0, 0.0
+
+
+def fused_cost(parts, tab, n_of):
+    """Algorithmic FLOPs and bytes of ONE launch that computes the layers `parts` in sequence: a tensor handed from one
+    fused layer to the next is never moved, so the launch reads the first layer's input plus what each later layer takes
+    from elsewhere (expand_1_1 after upscale2: the skip half) and writes the last layer's output."""
+    fl = by = 0.0
+    prev_out = None
+    for k, part in enumerate(parts):
+        if part not in tab:
+            continue
+        kind, ci, co, edge = tab[part]
+        f1, bi, bo, bw = launch_cost(kind, ci, co, edge, n_of(part))
+        fl += f1
+        by += bw + (bi if prev_out is None else max(bi - prev_out, 0.0))
+        prev_out = bo
+    return fl, by + (prev_out or 0.0)
 
 
 def profiled_forward(model, x, n_samples, seed):
@@ -136,14 +153,9 @@ def roofline_leg(model, x, T, reps=3):
             Vc = v1 - v0
             for label, kname, ms in rows:
                 per_label.setdefault(label, []).append(ms)
-                fl, by = 0.0, 0.0
-                for part in label.split("+"):          # a fused launch carries every layer it computes
-                    if part in tab:
-                        kind, ci, co, edge = tab[part]
-                        # MC-dropout: contr_1_1 runs once per volume (its T samples share input and statistics)
-                        f1, b1 = launch_cost(kind, ci, co, edge, Vc if part == "contr_1_1" else Vc * T)
-                        fl += f1
-                        by += b1
+                # a fused launch carries every layer it computes; MC-dropout: contr_1_1 runs once per volume (its T
+                # samples share input and statistics)
+                fl, by = fused_cost(label.split("+"), tab, lambda part: Vc if part == "contr_1_1" else Vc * T)
                 name = kname or label.split(":")[0]
                 a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
                 a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1

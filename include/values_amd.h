@@ -78,6 +78,9 @@ typedef struct vx_config {
   int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
   int32_t s16_no_upfuse;   /* separate upscale2 launch + concat read instead of the up-convolution fused into expand_1_1 */
+  int32_t s16_no_wspec;    /* z-column kernel: every wave stages and multiplies (conv3d_xp8.hip) instead of producer / consumer waves */
+  int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
+  int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);

@@ -804,7 +804,7 @@ def test_conv3d_xp8_fused_upconvolution_matches_oracle(shape, xblk, pitch, pmode
     xd = (to_xblk(garbage, raw, xblk) if xblk else cl(raw)).to(dev())
     got, _, _, mx = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=93, layer=15,
                               xblk=xblk, in_pitch=8 if not xblk else None, pre=pre, up=(cd, uw, ub))
-    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8_kernel<2,1,%d,1>" % (0 if pre is None else 1))
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8w_kernel<2,1,%d,1," % (0 if pre is None else 1))
     want = F.leaky_relu(ref, 0.01) * _hash_mask(93, 15, n, 8, d, h, w) * 2
     err = (got.double() - want).abs().max().item()
     assert err < 4e-5, err

@@ -9,7 +9,8 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from values_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "values_amd", "libvalues_amd_stamps.so")
+if not os.environ.get("STAMP_PRODUCT"):      # STAMP_PRODUCT=1: time the product library (no stamps; for rocprofv3 --pmc)
+    _lib.LIB_PATH = os.path.join(ROOT, "values_amd", "libvalues_amd_stamps.so")
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 N = int(os.environ.get("STAMP_N", "160"))
@@ -22,7 +23,7 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
     wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
     _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(w), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
     out = torch.empty((N, edge, edge, edge, cout), device=dev)
-    dbg = torch.zeros((4096, 8, 8), dtype=torch.int64, device=dev)
+    dbg = torch.zeros((4096, 16, 8), dtype=torch.int64, device=dev)   # conv3d_xp8w.hip: up to 16 waves
     os.environ["VX_CONV_DBG_PTR"] = str(dbg.data_ptr())
     a = _lib.ConvArgs()
     a.w_family = lib.vx_conv3d_k3_family(cin, cout)
@@ -57,8 +58,17 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
     ms = e0.elapsed_time(e1) / reps
     d = dbg.cpu().double()
     names = ["barrier wait", "multiply", "epilogue", "load wait", "convert+lds", "issue loads"]
-    print(f"{spec}: {ms:.4f} ms/launch at {N} samples (stamped build)")
-    for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+    print(f"{spec}: {ms:.4f} ms/launch at {N} samples (stamped build) abl={os.environ.get('VX_XP_ABL', '0')} {lib.vx_last_kernel_name().decode()}")
+    if os.environ.get("STAMP_TERSE"):
+        continue
+    kname = lib.vx_last_kernel_name().decode()
+    print("  kernel", kname)
+    if "xp8w" not in kname:
+        d = d.reshape(-1, 8, 8)[: 4096]      # 8-wave kernels index [workgroup][8 waves]
+    groups = [("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))]
+    if "xp8w" in kname:
+        groups.append(("producers", slice(8, 16)))
+    for half, sl in groups:
         dd = d[:, sl]
         used = dd[:, :, 6] > 0
         it = dd[:, :, 6][used].mean().item()

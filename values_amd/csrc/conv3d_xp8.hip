@@ -616,6 +616,8 @@ static int launch_xp8(const Xp8Args& ka, hipStream_t s) {
   return VX_OK;
 }
 
+int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s);   // conv3d_xp8w.hip; 1 = not taken
+
 int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   Xp8Args ka;
   ka.a = a;
@@ -634,6 +636,10 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if ((int64_t)a.N * cps >= (1ll << 31)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): too many columns");
   if (a.stats_partial && (stat_tiles % cps || a.act != VX_ACT_NONE || a.drop_mode != VX_DROP_NONE || a.head_out))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): statistics go with a plain epilogue");
+  if (!vx_cfg().s16_no_wspec) {   // producer / consumer waves
+    const int rc = vx_conv3d_k3_xp8w(a, stat_tiles, s);
+    if (rc != 1) return rc;
+  }
   const int pre = a.in_mean ? 1 : 0;
   int epi;
   if (a.stats_partial) epi = 0;

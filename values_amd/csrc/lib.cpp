@@ -64,7 +64,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
   g_cfg.s16_ping = env_int("VX_S16_PING", 0);
   g_cfg.s16_no_xp8 = env_int("VX_S16_NO_XP8", 0);
-  g_cfg.s16_skip_raw = env_int("VX_S16_SKIP_RAW", 0);
+  g_cfg.s16_skip_raw = env_int("VX_S16_SKIP_RAW", 1);
   g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
   g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);
   g_cfg.no_head_fusion = env_int("VX_NO_HEAD_FUSION", 0);
@@ -75,6 +75,9 @@ static void cfg_from_env() {
   g_cfg.c8_tile16 = env_int("VX_C8_TILE16", 0);
   g_cfg.s16_range_check = env_int("VX_S16_RANGE_CHECK", 1);
   g_cfg.s16_no_upfuse = env_int("VX_S16_NO_UPFUSE", 0);
+  g_cfg.s16_no_wspec = env_int("VX_S16_NO_WSPEC", 0);
+  g_cfg.s16_pw = env_int("VX_S16_PW", 0);
+  g_cfg.s16_prio = env_int("VX_S16_PRIO", 0);
 }
 
 const vx_config& vx_cfg() {

@@ -226,9 +226,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // general kernels with their separate normalise passes
   const bool pre0 = dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && F == 8 && !w->no_instancenorm &&
                     vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F);
-  // contr_1_2's raw output straight into the skip half + a pooling-only pass + expand_1_1 normalising its skip half:
-  // measured NEUTRAL to slightly slower (the pass shrinks 1.09 -> 0.59 ms per 320 samples, expand_1_1 grows 2.33 -> 2.95:
-  // its staging is instruction-bound and the hash per piece is not free) -- opt-in (vx_config.s16_skip_raw)
+  // contr_1_2's raw output straight into the skip half + a pooling-only pass + expand_1_1 normalising its skip half
+  // (vx_config.s16_skip_raw, default 1): the pass shrinks 1.10 -> 0.58 ms per 320 samples, expand_1_1 grows 2.38 -> 2.69
+  // now that its staging runs in producer waves (on the kernel where every wave staged AND multiplied it grew 2.33 -> 2.95
+  // and the fusion was neutral)
   // upscale2 inside expand_1_1: the up half of CAT_0 is computed from B_1 while expand_1_1 stages its tiles and never
   // exists in memory (conv3d_xp8.hip, UP = 1)
   const bool fuse_up = dm != VX_DROP_MASK && F == 8 && vx_conv3d_k3_upfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);

@@ -339,3 +339,38 @@ def test_batched_tta_views_equal_one_forward_per_view():
     v2, h2, w2 = tta_views_8(x2, x2 * 1.02)
     assert torch.equal(predict_logits_2d([m2], v2, tta=True, hflip_views=h2, vflip_views=w2, batch_views=True),
                        predict_logits_2d([m2], v2, tta=True, hflip_views=h2, vflip_views=w2, batch_views=False))
+
+
+def test_graphed_predictor_2d_replays_the_eager_bits():
+    """GraphedPredictor2D: predict_logits_2d + process_output_2d captured into one hipGraph (branches on side streams
+    inside the capture) -- the replay gives the eager path's bits, for new inputs too; wrong shapes are refused."""
+    from values_amd.formula import HRNET_W18S_EXTRA
+    from values_amd.hrnet import HighResolutionNet
+    from values_amd.predict2d import GraphedPredictor2D, predict_logits_2d, process_output_2d, tta_views_8
+    g = load_npz("hrnet_w18s.npz")
+    shapes = json.loads(bytes(g["shapes_json"]).decode())
+    sd = {k: torch.from_numpy(v).float() for k, v in formula_state_dict_from_shapes(shapes).items()}
+    cfg = {"MODEL": {"EXTRA": dict(HRNET_W18S_EXTRA, DROPOUT_FINAL=False), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+           "DATASET": {"NUM_CLASSES": 5}}
+    m = HighResolutionNet(cfg)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    x = torch.from_numpy(g["input"]).cuda()
+    noisy = x + torch.from_numpy(formula_tensor(tuple(x.shape), tag=83, scale=0.1)).float().cuda()
+    views, hf, vf = tta_views_8(x, noisy)
+    gp = GraphedPredictor2D([m], views, tta=True, hflip_views=hf, vflip_views=vf)
+    for scale in (1.0, 0.7, 1.0):
+        vs = [v * scale for v in views]
+        out = gp(vs)
+        lg = predict_logits_2d([m], vs, tta=True, hflip_views=hf, vflip_views=vf)
+        ref = process_output_2d(lg)
+        torch.cuda.synchronize()
+        assert torch.equal(gp.logits, lg), scale
+        for k in ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax", "pred_seg"):
+            assert torch.equal(out[k], ref[k]), (k, scale)
+    with pytest.raises(ValueError):
+        gp(views[:4])
+    # a DROPOUT_FINAL member without explicit seeds is refused (the seeds are baked into the graph)
+    m3, gg, _ = make(dropout_final=True)
+    with pytest.raises(ValueError):
+        GraphedPredictor2D([m3], torch.from_numpy(gg["input"]).cuda(), n_pred=2)

@@ -324,7 +324,7 @@ static inline int c2_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1
 extern "C" int vx_conv2d_family(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return 0;
   if (!c2_split16()) return 3;
-  return vx_conv2d_s16_row_tiles(KS, Cout) == 5 ? 2 : 1;
+  return 10 + vx_conv2d_s16_row_tiles(KS, Cout);   // the packed layout is [row group][...][row tile]: bound to the tile count
 }
 
 extern "C" int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS) {

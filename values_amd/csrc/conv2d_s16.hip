@@ -357,7 +357,17 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 struct C2SCfg { int NT, NSUB, TY; };
 static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   C2SCfg c;
-  c.NT = (Cout % 48 == 0) ? 3 : ((Cout % 32 == 0) ? 2 : 1);
+  // row tiles (16 output channels each) per workgroup: every workgroup of a row group stages the SAME input tile, so the
+  // fewer groups the better -- all rows in one group up to 3 tiles (HRNet-W18: 18 -> 2 tiles, 36 -> 3), otherwise the
+  // largest of 3 / 5 / 2 that divides the tile count (72 -> 5 tiles x 1 group, 144 -> 3 x 3, W48: 48 / 96 / 192 / 384 ->
+  // 3 tiles).  The rule used to look at Cout % 48 / % 32 only, which left W18's 18-, 36- and 72-channel layers at ONE
+  // tile per group: 2, 3 and 5 groups re-staging the input and re-reading the image fragments.
+  const int r16 = (Cout + 15) / 16;
+  if (r16 <= 3) c.NT = r16;
+  else if (r16 % 3 == 0) c.NT = 3;
+  else if (r16 % 5 == 0 && !vx_cfg().c2s_no_nt5) c.NT = 5;
+  else if (r16 % 2 == 0) c.NT = 2;
+  else c.NT = 1;
   // wide 1x1 layers (the 720 -> 720 head conv): five row tiles per workgroup -- the input tile is re-staged once per
   // group of output channels, 9 times instead of 15
   if (KS == 1 && Cout % 80 == 0 && Cout >= 240 && !vx_cfg().c2s_no_nt5) c.NT = 5;
@@ -446,9 +456,7 @@ static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
 
 template <int KS, int S, int NSUB, int TY>
 static int dispatch_c2s(const Conv2dSArgs& ka, int NT, hipStream_t s) {
-  if constexpr (KS == 1) {
-    if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
-  }
+  if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
   if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY>(ka, s);
   if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY>(ka, s);
   return launch_c2s<KS, S, 1, NSUB, TY>(ka, s);

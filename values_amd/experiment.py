@@ -43,9 +43,25 @@ class ExperimentVersion:
         return naming_scheme_version.format(**kwargs)
 
 
+def set_seed(seed: int) -> None:
+    """evaluation/utils/set_seed.py:9-18 without the Lightning call: python / numpy / torch generators (the downstream
+    tasks that sample -- Platt-scaling splits, threshold searches -- start from the experiment's seed)"""
+    import random
+    import numpy as np
+    import torch
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+
 class ExperimentDataloader:
     def __init__(self, exp_version: ExperimentVersion, dataset_split):
         self.exp_version = exp_version
+        if "seed" in getattr(exp_version, "version_params", {}):      # experiment_dataloader.py:14
+            set_seed(int(exp_version.version_params["seed"]))
         self.dataset_split = dataset_split
         self.dataset_path = exp_version.exp_path / dataset_split if dataset_split else exp_version.exp_path
         self.pred_seg_dir = self.dataset_path / "pred_seg"

@@ -408,6 +408,16 @@ class HighResolutionNet(nn.Module):
         self._hold.append(out.t)
         return out
 
+    def _itensor(self, values, dev):
+        """small int32 index tensor (slot / flip tables), uploaded once per content: a hipGraph capture cannot contain the
+        synchronous host-to-device copy torch.tensor(list, device=...) makes"""
+        cache = self.__dict__.setdefault("_icache", {})
+        key = (tuple(int(v) for v in values), str(dev))
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.tensor(list(key[0]), dtype=torch.int32, device=dev)
+        return t
+
     def _streams(self, n):
         if not hasattr(self, "_side") or len(self._side) < n:
             self._side = [torch.cuda.Stream() for _ in range(n)]
@@ -600,7 +610,7 @@ class HighResolutionNet(nn.Module):
         flip = torch.full((n,), code, dtype=torch.int32, device=dev) if code else None
         per = n // groups
         if groups > 1 and group_flips is not None:
-            flip = torch.tensor([int(group_flips[i // per]) for i in range(n)], dtype=torch.int32, device=dev)
+            flip = self._itensor([int(group_flips[i // per]) for i in range(n)], dev)
         for t in range(n_samples):
             mode = _lib.VX_DROP_NONE
             masks = None
@@ -617,7 +627,7 @@ class HighResolutionNet(nn.Module):
                     seed = self.seed * 1000003 + self._calls
                     self._calls += 1
             if user_out and groups > 1:   # image b of view g -> slot b * slot_stride + slot_offset + g
-                dst = torch.tensor([(i % per) * slot_stride + slot_offset + i // per for i in range(n)], dtype=torch.int32, device=dev)
+                dst = self._itensor([(i % per) * slot_stride + slot_offset + i // per for i in range(n)], dev)
             elif user_out:  # image b, sample t -> slot b * slot_stride + slot_offset + t  (per-image (Npred, C, H, W) stacks)
                 dst = torch.arange(n, dtype=torch.int32, device=dev) * slot_stride + (slot_offset + t)
             else:

@@ -8,9 +8,10 @@
 One "step" = one batch of V synthetic 64^3 1-channel volumes per GPU through the whole hot path:
 T=10 MC-dropout forwards of UNet3D (batched on device as V*T samples, hash dropout, float32 tensors, the 3x3x3
 products evaluated fp32-accurately on the f16 matrix cores by operand splitting) -> logits in their pred_idx slots ->
-fused softmax / entropy / MI / variance / argmax reduction -> (N>1) RCCL gather of the per-volume maps to rank 0.
+fused softmax / entropy / MI / variance / argmax reduction.
 Inputs are resident in HBM before the timed region.  Volumes are sharded over ranks (weak scaling: V per GPU fixed),
-no collective on the data path except that gather.
+no collective on the data path: the maps stay on the rank that computed them (--gather: additionally an overlapped RCCL
+gather of every step's maps to rank 0, inside the timed region).
 
 --config C3: the 5-member deep ensemble of BASELINE config 3, (member, volume block) items dealt over the ranks, one
 RCCL sum-reduce of sufficient statistics per step (values_amd.dist.ensemble_uncertainty_sharded).
@@ -320,12 +321,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4"))
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
-    ap.add_argument("--volumes", type=int, default=None, help="units per GPU per step (C2: 32 volumes, C3: 16, C4: 2 images)")
+    ap.add_argument("--volumes", type=int, default=None, help="units per GPU per step (C2: 32 volumes, C3: 16, C4: 4 images)")
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
+                    help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
+    ap.add_argument("--gather", action="store_true", help="C2, N > 1: also collect every rank's maps on rank 0 (overlapped RCCL gather)")
     ap.add_argument("--eager", action="store_true", help="C4: eager launches instead of the captured hipGraph")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
     ap.add_argument("--detail", type=str, default=None, help="write the per-kernel breakdown JSON here")
@@ -403,9 +407,11 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((V, 1, S, S, S), generator=g).to(dev)  # z-scored synthetic volumes, resident in HBM
 
-    # maps are collected on rank 0 with the gather of step i overlapping the kernels of the following steps;
-    # everything is flushed before the closing barrier, so the timed region contains every transfer
-    pipe = MapGatherPipeline(world, rank, depth=2)
+    # the volumes are independent: every rank keeps the maps of its shard (as the reference's per-case result files would
+    # be written by whichever process ran the case) -- no collective on the data path.  --gather additionally collects
+    # the maps on rank 0, the gather of step i overlapping the kernels of the following steps, everything flushed before
+    # the closing barrier so that the timed region contains every transfer
+    pipe = MapGatherPipeline(world if args.gather else 1, rank, depth=2)
 
     def step(i):
         out = predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off")
@@ -452,7 +458,9 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
             "config": {"workload": f"C2: {S}^3 1-channel volumes, UNet3D(initial_filter_size=8, 2 classes), T={T} "
                                    "MC-dropout passes + fused softmax/entropy/MI/variance/argmax reduction",
                        "volumes_per_gpu_per_step": V, "samples_per_gpu_per_step": V * T,
-                       "sharding": f"volumes over {world} rank(s); gather of maps to rank 0" if world > 1 else "single GPU",
+                       "sharding": (f"volumes over {world} rank(s); " + ("maps gathered to rank 0 (RCCL, overlapped)" if args.gather
+                                    else "maps stay on the rank that computed them, no data-path collective"))
+                       if world > 1 else "single GPU",
                        "dropout": "hash bit generator, new seed every step", "weights": "torch default init, seed 123"},
             "roofline": roof, "cpu_baseline": cpu}
     line.update(summarise(times, V * world * args.steps, args.steps))
@@ -534,12 +542,13 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     sharded over the ranks.  One step = B images per GPU = 8 B forwards (every view is its own batch, as test_2D.py:299-311
     runs them: training-mode BatchNorm sees one view at a time)."""
     import torch
-    from values_amd.formula import hrnet_w18_extra
+    from values_amd.formula import hrnet_w18_extra, hrnet_w48_extra
     from values_amd.hrnet import HighResolutionNet
     from values_amd.predict2d import GraphedPredictor2D, predict_logits_2d, process_output_2d, tta_views_8
-    B = args.volumes or 2
+    B = args.volumes or 4
     H, W, NC = 512, 1024, 19
-    cfg = {"MODEL": {"EXTRA": hrnet_w18_extra(False), "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
+    extra = hrnet_w48_extra(False) if args.hrnet_width == 48 else hrnet_w18_extra(False)
+    cfg = {"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},
            "DATASET": {"NUM_CLASSES": NC}}
     torch.manual_seed(123)
     model = HighResolutionNet(cfg).to(dev)
@@ -567,10 +576,10 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     roof = None
     if rank == 0 and not args.no_roofline and hasattr(model, "profile_forward"):
         roof = model.profile_forward(torch.cat(views, 0), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=len(views))
-    line = {"metric": "uncertainty-images/sec (HRNet-W18, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
+    line = {"metric": f"uncertainty-images/sec (HRNet-W{args.hrnet_width}, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C4: HRNet-W18 (training-mode BatchNorm as the reference runs it), {W}x{H}, {NC} classes, "
+            "config": {"workload": f"C4: HRNet-W{args.hrnet_width} (training-mode BatchNorm as the reference runs it), {W}x{H}, {NC} classes, "
                                    "8 TTA views per image + softmax / entropy / MI reduction",
                        "images_per_gpu_per_step": B, "views_per_image": 8,
                        "batching": "the 8 views of a step travel as one batch of 8 B images with BatchNorm statistics per view",

@@ -21,10 +21,12 @@ find gpurun_out/prof_${tag} -name "*kernel_stats.csv" -exec cp {} gpurun_out/${t
 python3 bench.py --config C4 --steps 5 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4_bench.json 2> gpurun_out/${tag}_c4_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_c4 -o ${tag}_c4 -- python3 bench.py --config C4 --steps 3 --warmup 1 --repeats 1 --no-roofline > gpurun_out/${tag}_c4_prof.log 2>&1
 find gpurun_out/prof_${tag}_c4 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_c4_kernel_stats.csv \;
+python3 bench.py --config C4 --hrnet-width 48 --steps 4 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4w48_bench.json 2> gpurun_out/${tag}_c4w48_bench.err
 python3 bench.py --config C3 --steps 10 --warmup 3 --repeats 3 > gpurun_out/${tag}_c3_bench.json 2> gpurun_out/${tag}_c3_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-600
 head -12 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
 head -30 gpurun_out/${tag}_pmc_hbm.txt
 tail -c 900 gpurun_out/${tag}_c4_bench.json
 head -8 gpurun_out/${tag}_c4_kernel_stats.csv | cut -c1-160
+tail -c 700 gpurun_out/${tag}_c4w48_bench.json
 tail -c 500 gpurun_out/${tag}_c3_bench.json

@@ -100,5 +100,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 200; /* 0.2.0 */ }
+extern "C" int vx_version(void) { return 210; /* 0.2.1: vx_conv3d_args.up_*, vx_config.s16_no_upfuse / s16_no_wspec / s16_pw / s16_prio */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

@@ -74,7 +74,8 @@ def test_host_only_queries(lib, vxcfg):
     assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (3, 8))] == [2, 1, 0]
     # 2D split-fp16 family = 10 + row tiles per workgroup (the packed layout is [row group][...][row tile])
     assert [lib.vx_conv2d_family(64, co, ks) for co, ks in ((64, 3), (720, 1), (64, 5))] == [12, 15, 0]
-    assert [lib.vx_conv2d_family(18, co, 3) for co in (18, 36, 72, 144, 48, 96, 19)] == [12, 13, 15, 13, 13, 13, 12]
+    assert [lib.vx_conv2d_family(18, co, 3) for co in (18, 36, 72, 144, 48, 96, 19)] == [12, 13, 13, 13, 13, 13, 12]
+    assert [lib.vx_conv2d_family(270, co, 1) for co in (270, 720, 19)] == [15, 15, 12]
     vxcfg.set(conv_fp32=1)      # native-fp32 kernels: their own packings and families
     assert lib.vx_conv3d_k3_packed_floats(16, 8) == 27 * 16 * 8   # Cout == 8, Cin in {8, 16}: 4x4x1 kernel, dense
     assert lib.vx_conv3d_k3_packed_floats(24, 8) == 16 * 24 * 36  # other Cout == 8: x-pair packing, 16 rows x (9*4 taps)

@@ -357,20 +357,22 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 struct C2SCfg { int NT, NSUB, TY; };
 static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   C2SCfg c;
-  // row tiles (16 output channels each) per workgroup: every workgroup of a row group stages the SAME input tile, so the
-  // fewer groups the better -- all rows in one group up to 3 tiles (HRNet-W18: 18 -> 2 tiles, 36 -> 3), otherwise the
-  // largest of 3 / 5 / 2 that divides the tile count (72 -> 5 tiles x 1 group, 144 -> 3 x 3, W48: 48 / 96 / 192 / 384 ->
-  // 3 tiles).  The rule used to look at Cout % 48 / % 32 only, which left W18's 18-, 36- and 72-channel layers at ONE
-  // tile per group: 2, 3 and 5 groups re-staging the input and re-reading the image fragments.
+  // row tiles (16 output channels each) per workgroup: every workgroup of a row group stages the SAME input tile and
+  // reads the same image fragments, so fewer groups are better as long as the padding they need (rows beyond Cout hold
+  // zero weights and are not stored) costs less: minimise groups x (staging + tiles) with the staging of a 1x1 layer
+  // weighing ~3 tiles of products and that of a 3x3 layer ~0.7.  HRNet-W18: 18 -> 2 tiles, 36 -> 3, 72 -> 5, 144 -> 3 x 3,
+  // the 270 -> 270 head conv 4 groups of 5 (it ran as 17 groups of one tile: 4.8 ms of a 43 ms step); W48: 48 / 96 /
+  // 192 / 384 -> 3 tiles, the 720 -> 720 head conv 9 x 5.  Five tiles only on 1x1 layers: the 3x3 instance needs 256
+  // VGPRs plus scratch.
   const int r16 = (Cout + 15) / 16;
-  if (r16 <= 3) c.NT = r16;
-  else if (r16 % 3 == 0) c.NT = 3;
-  else if (r16 % 5 == 0 && !vx_cfg().c2s_no_nt5) c.NT = 5;
-  else if (r16 % 2 == 0) c.NT = 2;
-  else c.NT = 1;
-  // wide 1x1 layers (the 720 -> 720 head conv): five row tiles per workgroup -- the input tile is re-staged once per
-  // group of output channels, 9 times instead of 15
-  if (KS == 1 && Cout % 80 == 0 && Cout >= 240 && !vx_cfg().c2s_no_nt5) c.NT = 5;
+  const float cs = KS == 1 ? 3.0f : 0.7f;
+  float bestc = 1e30f;
+  c.NT = 1;
+  for (int nt : {1, 2, 3, 5}) {
+    if (nt == 5 && (vx_cfg().c2s_no_nt5 || KS == 3)) continue;   // 3x3 with five tiles: 256 VGPRs and scratch
+    const float cost = (float)((r16 + nt - 1) / nt) * (cs + (float)nt);
+    if (cost < bestc) { bestc = cost; c.NT = nt; }   // ties: the smaller tile count (less padding)
+  }
   c.NSUB = KS == 1 ? 4 : 1;
   c.TY = S == 2 ? 8 : 16;
   return c;
@@ -456,7 +458,9 @@ static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
 
 template <int KS, int S, int NSUB, int TY>
 static int dispatch_c2s(const Conv2dSArgs& ka, int NT, hipStream_t s) {
-  if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
+  if constexpr (KS == 1) {
+    if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
+  }
   if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY>(ka, s);
   if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY>(ka, s);
   return launch_c2s<KS, S, 1, NSUB, TY>(ka, s);

@@ -488,6 +488,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 #pragma unroll
               for (int kk = 0; kk < 4; ++kk) part = fmaf(hw4[c][kk], v[kk], part);
               part = vx_add_xor16(part);
+              // (measured alternative: the g-odd lane finishing and storing class c + 1 -- one exchange and one store per
+              // class pair with all 64 lanes active -- 1.282 instead of 1.249 ms per 320 samples, same box)
               if (!(g & 1)) o[(size_t)c * hnvox] = part;
             }
           }

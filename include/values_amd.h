@@ -81,6 +81,7 @@ typedef struct vx_config {
   int32_t s16_no_wspec;    /* z-column kernel: every wave stages and multiplies (conv3d_xp8.hip) instead of producer / consumer waves */
   int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
   int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
+  int32_t s16_no_poolfuse; /* separate pooling pass over contr_1_2's output instead of the window maxima from its epilogue */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);
@@ -203,9 +204,23 @@ typedef struct vx_conv3d_args {
   const float* up_w;    /* vx_pack_convT_k2s2(Cin = 16, Cout = 8) */
   const float* up_b;    /* [8] */
   int32_t up_pitch;
+  /* Optional POOLED OUTPUT of a contract block's second conv (only where vx_conv3d_k3_poolfuse_ok(D, H, W, Cin, Cout);
+   * needs stats_partial): besides its raw output and statistics the conv leaves what the block's
+   * InstanceNorm -> LeakyReLU -> Dropout -> MaxPool3d(2, 2) (unet3D_module.py:231-237, 303-310) needs of every 2 x 2 x 2
+   * window: the maximum over the raw values the dropout KEEPS (drop_mode / drop_seed / drop_layer describe that dropout;
+   * -inf when none is kept) and an any-dropped bit per channel.  vx_pool_finish turns them into the pooled tensor once the
+   * statistics exist -- the full-resolution tensor is not read again. */
+  float* pool_out;      /* nullable: [N][D/2][H/2][W/2][8] raw window maxima */
+  uint32_t* pool_flags; /* [N][D/2][H/2][W/2][2]: bit j of word q = a dropped element of channel 4 q + j in the window */
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
+int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
+/* pooled[c] = any_dropped ? max(s f(m), 0) : s f(m) with f(m) = LeakyReLU((m - mean[n][c]) * rstd[n][c]), s = 2 with
+ * dropout (drop_scale2 != 0) else 1: the MaxPool3d(2, 2) of Dropout(LeakyReLU(InstanceNorm(x))) from the window maxima and
+ * flags vx_conv3d_k3 left in pool_out / pool_flags (bit-identical to pooling the normalised tensor: f is monotone). */
+int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd, float* out,
+                   int out_pitch, int N, int64_t voxels_per_sample, int drop_scale2, vx_stream_t stream);
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
  * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
  * skip half (s = 1, written by vx_norm_act_drop_pool) as alternating DENSE blocks of xb voxels, so both producers

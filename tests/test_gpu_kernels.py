@@ -870,3 +870,77 @@ def test_weights_packed_under_another_configuration_are_refused(vxcfg):
     vxcfg.set(conv_fp32=1)
     assert lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()) == -3      # VX_E_DTYPE
     assert b"family" in lib.vx_last_error_string()
+
+
+@pytest.mark.parametrize("shape,pmode,rep", [((2, 8, 16, 64), 1, 1), ((1, 16, 8, 32), 0, 1), ((2, 8, 8, 32), 1, 3)])
+def test_conv3d_xp8_pooled_output_matches_oracle(shape, pmode, rep, vxcfg):
+    """contract block tail in two launches (unet3D_module.py:231-237, 303-310): the conv leaves its raw output, its
+    statistics AND, per 2 x 2 x 2 window, the maximum of the raw values the block's dropout keeps plus an any-dropped bit;
+    vx_pool_finish applies InstanceNorm + LeakyReLU + the dropout's 2 to those -- equal to
+    MaxPool3d(Dropout(LeakyReLU(InstanceNorm(conv)))) computed from the full tensor (the functions in between are
+    monotone).  With the normalise-on-load prologue in front (rep > 1: MC-dropout samples sharing the input) and without."""
+    lib = _lib.load()
+    n_in, d, h, w = shape
+    n = n_in * rep
+    assert lib.vx_conv3d_k3_poolfuse_ok(d, h, w, 8, 8) == 1 and lib.vx_conv3d_k3_poolfuse_ok(d, h, w, 16, 8) == 0
+    x = torch.from_numpy(formula_tensor((n_in, 8, d, h, w), 341, scale=1.5)).float()
+    wt = torch.from_numpy(formula_tensor((8, 8, 3, 3, 3), 342, scale=(1.0 / (27 * 8)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((8,), 343, scale=0.2))
+    pre = None
+    xin = x.double().repeat_interleave(rep, 0)
+    if rep > 1:     # the input is a raw tensor normalised on load with the previous block's dropout (layer 0)
+        mean0 = x.double().mean((2, 3, 4)).float().contiguous().to(dev())
+        rstd0 = (1.0 / torch.sqrt(x.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+        keep0 = _hash_mask(21, 0, n, 8, d, h, w)
+        xin = F.leaky_relu((x.double() - mean0.cpu().double().view(n_in, 8, 1, 1, 1)) * rstd0.cpu().double().view(n_in, 8, 1, 1, 1), 0.01)
+        xin = xin.repeat_interleave(rep, 0) * keep0 * 2
+        pre = (mean0, rstd0, rep, _lib.VX_DROP_HASH, 21, 0)
+    ref = F.conv3d(xin, wt.float().double(), b.float().double(), padding=1)
+    # --- launch 1: conv + statistics + window maxima
+    wdv, bd = wt.float().contiguous().to(dev()), b.float().contiguous().to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(8, 8), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wdv), _lib.ptr(wp), 8, 8, _lib.stream_ptr()), "pack")
+    xd = cl(x).to(dev())
+    out = torch.full((n, d, h, w, 8), -77.0, dtype=torch.float32, device=dev())
+    nt = lib.vx_conv3d_k3_tiles_for(d, h, w, 8)
+    st = torch.full((n, nt, 8, 2), 5.0, dtype=torch.float32, device=dev())
+    praw = torch.full((n, d // 2, h // 2, w // 2, 8), 123.0, dtype=torch.float32, device=dev())
+    pfl = torch.full((n, d // 2, h // 2, w // 2, 2), -1, dtype=torch.int32, device=dev())
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(8, 8)
+    a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = 8, 8, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, 8, 8
+    a.stats_partial = st.data_ptr()
+    a.pool_out, a.pool_flags = praw.data_ptr(), pfl.data_ptr()
+    a.drop_mode, a.drop_seed, a.drop_layer = (_lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE), 57, 1
+    if pre is not None:
+        a.in_mean, a.in_rstd, a.in_repeat = pre[0].data_ptr(), pre[1].data_ptr(), pre[2]
+        a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = pre[3], pre[4], pre[5]
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8w_kernel<1,4,%d,0," % (0 if pre is None else 1))
+    got = ncdhw(out).cpu()
+    assert (got.double() - ref).abs().max().item() < 4e-5
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=2e-3)
+    # --- launch 2: statistics of the conv's own output, then the pooled tensor
+    mean = got.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(got.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    pooled = torch.full((n, d // 2, h // 2, w // 2, 12), -9.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pool_finish(_lib.ptr(praw), _lib.ptr(pfl), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pooled), 12, n,
+                                  (d // 2) * (h // 2) * (w // 2), 1 if pmode else 0, _lib.stream_ptr()), "vx_pool_finish")
+    torch.cuda.synchronize()
+    keep = _hash_mask(57, 1, n, 8, d, h, w) if pmode else torch.ones((n, 8, d, h, w), dtype=torch.float64)
+    # the float32 arithmetic of the product on the conv's float32 output: (x - mean) * rstd, LeakyReLU, x 2, mask, max
+    t = (got - mean.cpu().view(n, 8, 1, 1, 1)) * rstd.cpu().view(n, 8, 1, 1, 1)
+    t = torch.maximum(t, 0.01 * t) * (2.0 if pmode else 1.0) * keep.float()
+    want = F.max_pool3d(t, 2, 2)
+    assert torch.equal(ncdhw(pooled[..., :8]).cpu(), want)            # bit for bit: every function in between is monotone
+    assert (pooled[..., 8:] == -9.0).all()
+    if pmode:
+        frac = (pfl.cpu() & 0xF).float().ne(0).float().mean().item()
+        assert frac > 0.9                                            # 8 elements per window and channel: a drop almost surely
+    # refused where the producer / consumer kernel does not run
+    vxcfg.set(s16_no_wspec=1)
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")

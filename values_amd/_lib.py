@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
                 ("head_C", _i32),
                 ("in_mean", _p), ("in_rstd", _p), ("in_drop_mode", _i32), ("in_drop_seed", _u32), ("in_drop_layer", _u32),
                 ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p),
-                ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32)]
+                ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p)]
 
 
 class NormArgs(C.Structure):
@@ -73,7 +73,7 @@ class Config(C.Structure):
         "conv_fp32", "conv_no_c8", "conv_dma", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
         "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_ping", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion", "s16_dbg", "c8_dbg", "dma_dbg", "dma_nw16", "c8_tile16",
-        "s16_range_check", "s16_no_upfuse", "s16_no_wspec", "s16_pw", "s16_prio")]
+        "s16_range_check", "s16_no_upfuse", "s16_no_wspec", "s16_pw", "s16_prio", "s16_no_poolfuse")]
 
 
 class UncOutputs(C.Structure):
@@ -119,6 +119,8 @@ SIGNATURES = {
     "vx_conv3d_k3_head_fusable": (_i, [_i, _i]),
     "vx_conv3d_k3_prologue_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_upfuse_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_poolfuse_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

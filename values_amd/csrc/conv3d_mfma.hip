@@ -639,6 +639,10 @@ extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
   return Cin == 16 && !vx_cfg().s16_no_upfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
+extern "C" int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout) {
+  return Cin == 8 && !vx_cfg().s16_no_poolfuse && !vx_cfg().s16_no_wspec && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
   const ConvCfg c = conv_config(Cin, Cout);
@@ -677,6 +681,13 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
       VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: up_in pitch %d (>= 16, multiple of 4 floats) / alignment", a.up_pitch);
     if ((int64_t)(a.D / 2 + 2) * (a.H / 2) * (a.W / 2) * a.up_pitch * 4 >= (1ll << 31))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: one coarse sample must stay below 2 GiB");
+  }
+  if (a.pool_out) {
+    if (!a.pool_flags || !a.stats_partial) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: pool_out goes with pool_flags and stats_partial");
+    if (!vx_conv3d_k3_poolfuse_ok(a.D, a.H, a.W, a.Cin, a.Cout) || a.drop_mode == VX_DROP_MASK || a.act != VX_ACT_NONE || a.head_out)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: no pooled output for this layer (see vx_conv3d_k3_poolfuse_ok; hash or no dropout, "
+              "no activation): %dx%dx%d, %d -> %d", a.D, a.H, a.W, a.Cin, a.Cout);
+    if (!vx_aligned16(a.pool_out)) VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: pool_out alignment");
   }
   if (a.in_drop_mode != VX_DROP_NONE && a.in_drop_mode != VX_DROP_HASH) VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: in_drop_mode %d", a.in_drop_mode);
   if (a.out && !a.out_xblk && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
@@ -720,7 +731,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
-  if (a.in_mean || a.out_xblk || a.up_in)
+  if (a.in_mean || a.out_xblk || a.up_in || a.pool_out)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);

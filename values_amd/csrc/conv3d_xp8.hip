@@ -634,12 +634,13 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   if ((int64_t)a.N * cps >= (1ll << 31)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): too many columns");
-  if (a.stats_partial && (stat_tiles % cps || a.act != VX_ACT_NONE || a.drop_mode != VX_DROP_NONE || a.head_out))
+  if (a.stats_partial && (stat_tiles % cps || a.act != VX_ACT_NONE || (a.drop_mode != VX_DROP_NONE && !a.pool_out) || a.head_out))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): statistics go with a plain epilogue");
   if (!vx_cfg().s16_no_wspec) {   // producer / consumer waves
     const int rc = vx_conv3d_k3_xp8w(a, stat_tiles, s);
     if (rc != 1) return rc;
   }
+  if (a.pool_out) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8): the pooled output needs the producer / consumer kernel (vx_config.s16_no_wspec = 0)");
   const int pre = a.in_mean ? 1 : 0;
   int epi;
   if (a.stats_partial) epi = 0;

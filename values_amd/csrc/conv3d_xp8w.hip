@@ -46,6 +46,12 @@ struct Xp8wArgs {
 #endif
 
 // NCH, EPI, PRE, UP: as conv3d_xp8.hip.  NPW: producer waves (4 or 8).
+// EPI = 4 (one-chunk layers): EPI 0 (bias + statistics + store) PLUS the 2 x 2 x 2 max-pool of the block that follows the
+// InstanceNorm (conv -> norm -> LeakyReLU -> Dropout -> MaxPool, unet3D_module.py:231-237, 303-310) -- the statistics are
+// not known yet, but (x - mean) * rstd and LeakyReLU are monotone, so max over the window of drop(f(x)) =
+// max(2 f(max over the KEPT x), 0 if any element was dropped): the epilogue writes the maximum of the kept RAW values and
+// an any-dropped bit per channel; vx_pool_finish applies the statistics to 1/8 of the voxels later.  For this a consumer
+// wave owns 2 rows x 2 planes (whole windows in one lane pair) instead of 4 rows of one plane.
 template <int NCH, int EPI, int PRE, int UP, int NPW>
 __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka) {
   static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
@@ -64,6 +70,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
   constexpr int IT_C = (PPS + PT - 1) / PT;
   constexpr int IN_IT = NCH * IT_C;
   constexpr int GRP_H = TZ * ZP * 8;          // halves between two slot groups
+  constexpr bool STATS = EPI == 0 || EPI == 4;
   static_assert(IN_IT <= 16, "staging iterations");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -340,10 +347,12 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       advance(cx); advance(cc); advance(cp);
       grp_x = grp_c;
     }
-    if (EPI == 0) __syncthreads();
+    if (STATS) __syncthreads();
   } else {
     // =============================================== CONSUMER ===============================================
-    const int lz = wave / WPZ, ly0 = (wave % WPZ) * R;
+    constexpr bool POOLM = EPI == 4;            // tile r of this wave = plane lz + (r >> 1), row ly0 + (r & 1)
+    static_assert(!POOLM || (NCH == 1 && R == 4), "pooling epilogue: one-chunk layers");
+    const int lz = POOLM ? (wave >> 2) * 2 : wave / WPZ, ly0 = POOLM ? (wave & 3) * 2 : (wave % WPZ) * R;
     const bool late = wave >= NW / 2;
     if (ka.prio == 2) __builtin_amdgcn_s_setprio(2);
     if (ka.prio == 3 && late) __builtin_amdgcn_s_setprio(1);
@@ -357,10 +366,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     unsigned ovoff[R], eoff[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int ovox = (lz * a.H + ly0 + r) * a.W + lx;
+      const int tz_ = lz + (POOLM ? (r >> 1) : 0), ty_ = ly0 + (POOLM ? (r & 1) : r);
+      const int ovox = (tz_ * a.H + ty_) * a.W + lx;
       if (a.out_xblk) {
         const int oxb = a.out_xblk;
-        ovoff[r] = (unsigned)((((lz * a.H + ly0 + r) * (2 * a.W * 8)) + ((lx / oxb) * 2 + a.out_half) * oxb * 8 + (lx % oxb) * 8 + oc) * 4);
+        ovoff[r] = (unsigned)((((tz_ * a.H + ty_) * (2 * a.W * 8)) + ((lx / oxb) * 2 + a.out_half) * oxb * 8 + (lx % oxb) * 8 + oc) * 4);
       } else {
         ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * 4);
       }
@@ -369,7 +379,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const int out_voxf = a.out_xblk ? 16 : a.out_pitch;
     const size_t out_sample = (size_t)a.D * a.H * a.W * out_voxf;
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + oc);
-    const bool f_lrelu = EPI == 3 ? a.act == VX_ACT_LRELU : EPI != 0;
+    const bool f_lrelu = EPI == 3 ? a.act == VX_ACT_LRELU : !STATS;
     const bool f_relu = EPI == 3 && a.act == VX_ACT_RELU;
     // fused head: this lane's 4 of the 8 weights of up to 4 classes; the bias rides in the g-even lane (conv3d_s16.hip)
     constexpr int HC = EPI == 2 ? 4 : 1;
@@ -391,6 +401,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // ---- accumulators ----
     f32x4 acc[R], accx[R];
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    float pl_max[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // EPI 4: maximum of the kept raw values of the window
+    uint32_t pl_any = 0;                                              //        bit j: an element of channel oc + j was dropped
 
     // the multiply phase of the item whose first plane sits in slot rb (slots rb .. rb + TZ + 1, modulo NZ)
     // (measured alternative: explicitly software-pipelined LDS reads -- weights one step ahead, the next group's image
@@ -404,14 +416,20 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         const _Float16* wch = s_w + chunk * W_H + wslot * 8;
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
-          int slot = rb + lz + kz;
-          if (slot >= NZ) slot -= NZ;
-          const _Float16* row0 = img + slot * (ZP * 8);
-          f16x8 bh[R + 2], bl[R + 2];
+          // rows of the image this wave's tiles read at this kz: R + 2 rows of one plane, or (EPI 4: 2 rows x 2 planes per
+          // wave) 4 rows of each of two planes -- row index of tile r at ky: BR(r) + ky
+          constexpr int NROW = POOLM ? 8 : R + 2;
+          f16x8 bh[NROW], bl[NROW];
 #pragma unroll
-          for (int j = 0; j < R + 2; ++j) {
-            bh[j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8);
-            bl[j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8 + PREC_H);
+          for (int pq = 0; pq < (POOLM ? 2 : 1); ++pq) {
+            int slot = rb + lz + pq + kz;
+            if (slot >= NZ) slot -= NZ;
+            const _Float16* row0 = img + slot * (ZP * 8);
+#pragma unroll
+            for (int j = 0; j < (POOLM ? 4 : R + 2); ++j) {
+              bh[pq * 4 + j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8);
+              bl[pq * 4 + j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8 + PREC_H);
+            }
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
@@ -422,9 +440,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
             for (int r = 0; r < R; ++r) {
               const bool fresh = chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
               const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
+              const int br = (POOLM ? (r >> 1) * 4 + (r & 1) : r) + ky;
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[br], fresh ? bias4 : acc[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[br], fresh ? zero : accx[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[br], accx[r], 0, 0, 0);
             }
           }
         }
@@ -441,7 +460,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (ci != e_ci) {   // a new column: sample, tile row / column, dropout key, head pointers
         e_ci = ci;
         col_of(ci, e_n, e_ty, e_tx);
-        if (EPI == 1 || EPI == 2) e_key = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)e_n);
+        if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)e_n);
         if (EPI == 2) {
           e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
           const int slot = a.head_dst ? a.head_dst[e_n] : e_n;
@@ -463,9 +482,17 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v = acc[r] + accx[r] * (1.0f / 2048.f);
-        if (EPI == 0) {
+        if (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
+        }
+        if constexpr (POOLM) {
+          // the block's dropout (applied after the InstanceNorm that is not known yet): maximum over the KEPT raw values
+          uint32_t bits = 0xFu;
+          if (a.drop_mode == VX_DROP_HASH) bits = vx_drop_bits4(e_key, e0 + eoff[r]);
+          pl_any |= ~bits & 0xFu;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pl_max[j] = fmaxf(pl_max[j], ((bits >> j) & 1u) ? v[j] : -INFINITY);
         }
         if (f_lrelu) {
 #pragma unroll
@@ -502,7 +529,27 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (EPI == 0 && k == KZ - 1) {
+      if constexpr (POOLM) {
+        // the x-neighbour voxel (same channels) sits 32 lanes away: lanes 0..31 finish the window and store it
+        f32x4 o;
+        uint32_t oany;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(pl_max[j], 32, 64);
+        oany = (uint32_t)__shfl_xor((int)pl_any, 32, 64);
+        if (lane < 32) {
+          f32x4 mx;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mx[j] = fmaxf(pl_max[j], o[j]);
+          const int Dp = a.D >> 1, Hp = a.H >> 1, Wp = a.W >> 1;
+          const size_t pv = (((size_t)e_n * Dp + ((k * TZ + lz) >> 1)) * Hp + ((e_ty * 8 + ly0) >> 1)) * Wp + e_tx * 16 + m;
+          *reinterpret_cast<f32x4*>(a.pool_out + pv * 8 + oc) = mx;
+          a.pool_flags[pv * 2 + (g & 1)] = pl_any | oany;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pl_max[j] = -INFINITY;
+        pl_any = 0;
+      }
+      if (STATS && k == KZ - 1) {
         // the column is complete for this wave: sum over its 16 pair columns and leave the 4 x 2 values of row group g
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -548,7 +595,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     while (cx.ci < ncol_wg) {
       __syncthreads();
       XP_STAMP(0);
-      if (EPI == 0 && fl_ci >= 0 && j >= fl_at && !late) { flush_col(fl_ci); fl_ci = -1; }
+      if (STATS && fl_ci >= 0 && j >= fl_at && !late) { flush_col(fl_ci); fl_ci = -1; }
       const bool comp = cx.s >= 1;
       const int item_k = cx.s - 1;
       int grp_c = grp_x + 1; if (grp_c == 3) grp_c = 0;
@@ -565,7 +612,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if (comp && !(XP_ABL & 2)) epilogue(cx.ci, item_k);
         XP_STAMP(2);
       }
-      if (EPI == 0 && comp && item_k == KZ - 1) { fl_ci = cx.ci; fl_at = j + 2; }
+      if (STATS && comp && item_k == KZ - 1) { fl_ci = cx.ci; fl_at = j + 2; }
 #ifdef VX_CONV_STAMPS
       ++st_iters;
 #endif
@@ -574,7 +621,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       ++j;
     }
     if (late && prev_ci >= 0) epilogue(prev_ci, prev_k);
-    if (EPI == 0) {
+    if (STATS) {
       __syncthreads();
       if (fl_ci >= 0 && !late) flush_col(fl_ci);
     }
@@ -642,7 +689,7 @@ int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
 #endif
   const int pre = a.in_mean ? 1 : 0;
   int epi;
-  if (a.stats_partial) epi = 0;
+  if (a.stats_partial) epi = a.pool_out ? 4 : 0;
   else if (a.head_out) epi = 2;
   else if (a.drop_mode == VX_DROP_HASH) epi = 1;
   else epi = 3;
@@ -651,10 +698,13 @@ int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   const int up = a.up_in ? 1 : 0;
   // producer waves: two per SIMD where the staging is heavy; the head epilogue (32 scattered 4-byte stores per lane and
   // item) is the longer side of its layer and runs better against one (measured per layer, tools/show_layers.py)
-  const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 ? 4 : 8);
+  // (the pooling epilogue holds 8 image rows + the window state: 128 VGPRs at 16 waves would spill 28 dwords)
+  const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 4 ? 4 : 8);
+  if (a.pool_out && nch != 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): the pooled output goes with Cin = 8");
 #define XP8W_CASE(N_, E_, P_, U_)                                                         \
   if (nch == N_ && epi == E_ && pre == P_ && up == U_)                                    \
     return npw == 8 ? launch_xp8w<N_, E_, P_, U_, 8>(ka, s) : launch_xp8w<N_, E_, P_, U_, 4>(ka, s)
+  XP8W_CASE(1, 4, 0, 0); XP8W_CASE(1, 4, 1, 0);
   XP8W_CASE(1, 0, 0, 0); XP8W_CASE(1, 0, 1, 0); XP8W_CASE(1, 1, 0, 0); XP8W_CASE(1, 2, 0, 0); XP8W_CASE(1, 3, 0, 0); XP8W_CASE(1, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 0); XP8W_CASE(2, 1, 1, 0); XP8W_CASE(2, 3, 0, 0); XP8W_CASE(2, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 1); XP8W_CASE(2, 1, 1, 1); XP8W_CASE(2, 3, 0, 1); XP8W_CASE(2, 3, 1, 1);

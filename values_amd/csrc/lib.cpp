@@ -78,6 +78,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_wspec = env_int("VX_S16_NO_WSPEC", 0);
   g_cfg.s16_pw = env_int("VX_S16_PW", 0);
   g_cfg.s16_prio = env_int("VX_S16_PRIO", 0);
+  g_cfg.s16_no_poolfuse = env_int("VX_S16_NO_POOLFUSE", 0);
 }
 
 const vx_config& vx_cfg() {
@@ -100,5 +101,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 210; /* 0.2.1: vx_conv3d_args.up_*, vx_config.s16_no_upfuse / s16_no_wspec / s16_pw / s16_prio */ }
+extern "C" int vx_version(void) { return 211; /* 0.2.1x: vx_conv3d_args.pool_out, vx_pool_finish; 0.2.1: vx_conv3d_args.up_*, vx_config.s16_no_upfuse / s16_no_wspec / s16_pw / s16_prio */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

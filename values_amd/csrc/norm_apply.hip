@@ -308,3 +308,45 @@ extern "C" int vx_drop_hash_mask(uint32_t seed, uint32_t layer, int N, int64_t e
   VX_CHECK_LAUNCH("vx_drop_hash_mask");
   return VX_OK;
 }
+
+// The second half of a pooled contract block whose conv left window maxima and any-dropped bits (vx_conv3d_args.pool_out):
+// one thread = one 16-byte piece (4 channels of one pooled voxel, C = 8).
+__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ raw, const uint32_t* __restrict__ flags,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          float* __restrict__ out, int out_pitch, unsigned pieces, float s) {
+  const int n = blockIdx.y;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
+    const unsigned vox = i >> 1, q = i & 1u;
+    const size_t pv = (size_t)n * (pieces >> 1) + vox;
+    const f32x4 m = *reinterpret_cast<const f32x4*>(raw + pv * 8 + q * 4);
+    const uint32_t fl = flags[pv * 2 + q];
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * 8 + q * 4);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * 8 + q * 4);
+    f32x4 t = (m - mu) * rs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = fmaxf(t[j], 0.01f * t[j]) * s;       // as vx_norm_act_drop_pool: normalise, LeakyReLU, then the dropout's 2
+      if ((fl >> j) & 1u) v = fmaxf(v, 0.f);          // a dropped element contributes 0 to the window
+      t[j] = v;
+    }
+    *reinterpret_cast<f32x4*>(out + pv * out_pitch + q * 4) = t;
+  }
+}
+
+extern "C" int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd,
+                              float* out, int out_pitch, int N, int64_t voxels_per_sample, int drop_scale2,
+                              vx_stream_t stream) {
+  if (!pool_raw || !pool_flags || !mean || !rstd || !out) VX_FAIL(VX_E_NULL, "vx_pool_finish: null pointer");
+  if (N <= 0 || voxels_per_sample <= 0 || voxels_per_sample >= (1ll << 30)) VX_FAIL(VX_E_SHAPE, "vx_pool_finish: empty / too large");
+  if (out_pitch < 8 || out_pitch % 4 || !vx_aligned16(pool_raw) || !vx_aligned16(out))
+    VX_FAIL(VX_E_ALIGN, "vx_pool_finish: pitch %d / alignment", out_pitch);
+  const unsigned pieces = (unsigned)(voxels_per_sample * 2);
+  unsigned bx = (pieces + 255u) / 256u;
+  if (bx > 64u) bx = 64u;
+  if (N >= 65536) VX_FAIL(VX_E_SHAPE, "vx_pool_finish: N");
+  vx_note_kernel("pool_finish_kernel");
+  hipLaunchKernelGGL(pool_finish_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags, mean,
+                     rstd, out, out_pitch, pieces, drop_scale2 ? 2.f : 1.f);
+  VX_CHECK_LAUNCH("vx_pool_finish");
+  return VX_OK;
+}

@@ -146,6 +146,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !vx_cfg().no_head_fusion;
   // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
+  float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
+  uint32_t* pool_flags_ = nullptr;
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1,
                   const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0,
@@ -176,6 +178,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     }
     a.seed_dev = r->seed_dev;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
+    if (pool_raw_ && wi == 1) {   // contr_1_2 also leaves the window maxima of its block's MaxPool (dropout layer 1)
+      a.pool_out = pool_raw_; a.pool_flags = pool_flags_;
+      a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = 1;
+    }
     return vx_conv3d_k3(&a, stream);
   };
   auto norm = [&](const float* x, int C, float* out, int out_pitch, int out_coff, float* pool, const Level& L,
@@ -233,6 +239,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // upscale2 inside expand_1_1: the up half of CAT_0 is computed from B_1 while expand_1_1 stages its tiles and never
   // exists in memory (conv3d_xp8.hip, UP = 1)
   const bool fuse_up = dm != VX_DROP_MASK && F == 8 && vx_conv3d_k3_upfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
+  // MaxPool of the first block out of contr_1_2's epilogue (window maxima of the kept raw values + any-dropped bits, then
+  // vx_pool_finish on 1/8 of the voxels) instead of a pass that re-reads the full-resolution tensor
+  const bool fuse_pool = dm != VX_DROP_MASK && vx_conv3d_k3_poolfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F);
   const bool fuse0 = pre0 && vx_cfg().s16_skip_raw && vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
@@ -294,10 +303,20 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       // contr_1_2's RAW output goes straight into the skip half of CAT_0; one pooling pass produces P_1 from it, and
       // expand_1_1 normalises the skip half while it stages its tiles (statistics kept in mean0 / rstd0 until then):
       // the full-resolution tensor is written once and read twice instead of written twice and read twice
+      if (fuse_pool) {   // B_0 is free until the decoder: window maxima [N][nvox / 8][8] + flag words [N][nvox / 8][2]
+        pool_raw_ = p.B[0];
+        pool_flags_ = reinterpret_cast<uint32_t*>(p.B[0] + (size_t)N * p.lv[1].nvox * 8);
+      }
       VX_STEP(kConv[1], conv(in2, C, 1, p.CAT[0], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep, nullptr,
                              nullptr, xblk_of(L.W)));
+      float* praw = pool_raw_;
+      uint32_t* pfl = pool_flags_;
+      pool_raw_ = nullptr; pool_flags_ = nullptr;
       VX_STEP(kFin[1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean0, p.rstd0, stream));
-      VX_STEP("pool:contr_1_2", norm(p.CAT[0], C, nullptr, 0, 0, p.P[1], L, 1, 1, 0, xblk_of(L.W), p.mean0, p.rstd0));
+      if (praw)
+        VX_STEP("poolfin:contr_1_2", vx_pool_finish(praw, pfl, p.mean0, p.rstd0, p.P[1], C, N, p.lv[1].nvox, dm == VX_DROP_HASH, stream));
+      else
+        VX_STEP("pool:contr_1_2", norm(p.CAT[0], C, nullptr, 0, 0, p.P[1], L, 1, 1, 0, xblk_of(L.W), p.mean0, p.rstd0));
       continue;
     }
     VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep));

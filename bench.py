@@ -563,16 +563,18 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
 
     # the product path for a fixed image geometry: the step captured once as a hipGraph (the eager walk is ~950 launches
     # from Python and host-bound), replayed per step with the views copied into the graph's inputs
+    eager = None
+    if not args.eager and rank == 0:     # the eager walk first (side number), its cached blocks returned before the capture
+        et = timed_regions(step_eager, lambda: None, torch.cuda.synchronize, max(2, args.steps // 2), 1, 1, lambda v: v)
+        eager = summarise(et, B * max(2, args.steps // 2), max(2, args.steps // 2))
+        model._hold_last = None
+        torch.cuda.empty_cache()
     gp = None if args.eager else GraphedPredictor2D([model], views, tta=True, hflip_views=hf, vflip_views=vf)
 
     def step(i):
         return gp(views) if gp is not None else step_eager(i)
 
     times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
-    eager = None
-    if gp is not None and rank == 0:
-        et = timed_regions(step_eager, lambda: None, torch.cuda.synchronize, max(2, args.steps // 2), 1, 1, lambda v: v)
-        eager = summarise(et, B * max(2, args.steps // 2), max(2, args.steps // 2))
     roof = None
     if rank == 0 and not args.no_roofline and hasattr(model, "profile_forward"):
         roof = model.profile_forward(torch.cat(views, 0), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=len(views))

@@ -588,6 +588,10 @@ class HighResolutionNet(nn.Module):
         x = x.detach().to(dev, torch.float32)
         self._pk = self._ensure_packed(dev)
         self._st = _lib.stream_ptr()
+        # the previous forward's intermediates were kept until now (its kernels are enqueued ahead of everything this call
+        # launches, on streams this call joins before reusing memory): release them BEFORE allocating this forward's, or two
+        # forwards' worth of activations are alive at once (W48 at 32 views: ~2 x 150 GB)
+        self._hold_last = None
         self._hold = []
         n, _, h, w = x.shape
         # groups > 1: x holds `groups` independent BatchNorm batches of n / groups consecutive images (the TTA views of
@@ -693,6 +697,10 @@ class HighResolutionNet(nn.Module):
         x = x.detach().to(dev, torch.float32)
         self._pk = self._ensure_packed(dev)
         self._st = _lib.stream_ptr()
+        # the previous forward's intermediates were kept until now (its kernels are enqueued ahead of everything this call
+        # launches, on streams this call joins before reusing memory): release them BEFORE allocating this forward's, or two
+        # forwards' worth of activations are alive at once (W48 at 32 views: ~2 x 150 GB)
+        self._hold_last = None
         self._hold = []
         n, _, h, w = x.shape
         feats = self._backbone(x)

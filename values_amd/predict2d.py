@@ -108,6 +108,13 @@ class GraphedPredictor2D:
         with torch.cuda.graph(self.graph, stream=side):
             self.logits, self.out = run()
         self._keep = [getattr(m, "_hold_last", None) for m in self.models]
+        # the two warm-up walks left their intermediates cached in the side stream's pool (a forward holds every
+        # intermediate until its end: tens of GB at 1024 x 512 x 32 views); the graph has its own pool -- give the
+        # warm-up blocks back, or a later eager forward in this process may not fit beside them
+        for m in self.models:
+            if hasattr(m, "_hold_last"):
+                m._hold_last = None
+        torch.cuda.empty_cache()
 
     def __call__(self, views) -> Dict[str, torch.Tensor]:
         vs = list(views) if self.tta else [views]

@@ -410,26 +410,61 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // one-chunk layers where the extra live rows spill; operands-in-registers rate of this instruction is 78 % of the
     // nominal peak and the plain loop already runs at 71 %)
     auto multiply = [&](int rb) {
+      if constexpr (POOLM) {
+        // 2 rows x 2 planes per wave: per kz the three weight fragments stay in registers while the two planes' four rows
+        // each pass through the same row registers (live: 24 + 32 VGPRs instead of 8 + 64 for both planes at once)
+        const _Float16* img = s_img + bfrag0;
+        const _Float16* wch = s_w + wslot * 8;
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          f16x8 ah[3], al[3];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const _Float16* wp = wch + (kz * 3 + ky) * (2 * 32 * 8);
+            ah[ky] = *reinterpret_cast<const f16x8*>(wp);
+            al[ky] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+          }
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            int slot = rb + lz + pq + kz;
+            if (slot >= NZ) slot -= NZ;
+            const _Float16* row0 = img + slot * (ZP * 8);
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+              bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8);
+              bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+              for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * pq + rr;
+                const bool fresh = kz == 0 && ky == 0;      // the bias is the first product's C operand
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ky], bh[rr + ky], fresh ? bias4 : acc[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ky], bl[rr + ky], fresh ? zero : accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ky], bh[rr + ky], accx[r], 0, 0, 0);
+              }
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int chunk = 0; chunk < NCH; ++chunk) {
         const _Float16* img = s_img + chunk * CHUNK_H + bfrag0;
         const _Float16* wch = s_w + chunk * W_H + wslot * 8;
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
-          // rows of the image this wave's tiles read at this kz: R + 2 rows of one plane, or (EPI 4: 2 rows x 2 planes per
-          // wave) 4 rows of each of two planes -- row index of tile r at ky: BR(r) + ky
-          constexpr int NROW = POOLM ? 8 : R + 2;
-          f16x8 bh[NROW], bl[NROW];
+          int slot = rb + lz + kz;
+          if (slot >= NZ) slot -= NZ;
+          const _Float16* row0 = img + slot * (ZP * 8);
+          f16x8 bh[R + 2], bl[R + 2];
 #pragma unroll
-          for (int pq = 0; pq < (POOLM ? 2 : 1); ++pq) {
-            int slot = rb + lz + pq + kz;
-            if (slot >= NZ) slot -= NZ;
-            const _Float16* row0 = img + slot * (ZP * 8);
-#pragma unroll
-            for (int j = 0; j < (POOLM ? 4 : R + 2); ++j) {
-              bh[pq * 4 + j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8);
-              bl[pq * 4 + j] = *reinterpret_cast<const f16x8*>(row0 + j * HXP * 8 + PREC_H);
-            }
+          for (int jr = 0; jr < R + 2; ++jr) {
+            bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8);
+            bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
@@ -440,10 +475,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
             for (int r = 0; r < R; ++r) {
               const bool fresh = chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
               const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-              const int br = (POOLM ? (r >> 1) * 4 + (r & 1) : r) + ky;
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[br], fresh ? bias4 : acc[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[br], fresh ? zero : accx[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[br], accx[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
             }
           }
         }
@@ -531,11 +565,21 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       }
       if constexpr (POOLM) {
         // the x-neighbour voxel (same channels) sits 32 lanes away: lanes 0..31 finish the window and store it
+        // (v_permlane32_swap: the upper half of the first operand <-> the lower half of the second; with both = x the
+        // second ends as [x.hi, x.hi] -- lanes 0..31 read their partner's value without a trip through the LDS queue)
         f32x4 o;
         uint32_t oany;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(pl_max[j], 32, 64);
-        oany = (uint32_t)__shfl_xor((int)pl_any, 32, 64);
+        for (int j = 0; j < 4; ++j) {
+          float sa = pl_max[j], sb = pl_max[j];
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(sa), "+v"(sb));
+          o[j] = sb;
+        }
+        {
+          uint32_t sa = pl_any, sb = pl_any;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(sa), "+v"(sb));
+          oany = sb;
+        }
         if (lane < 32) {
           f32x4 mx;
 #pragma unroll

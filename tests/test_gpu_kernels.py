@@ -944,3 +944,50 @@ def test_conv3d_xp8_pooled_output_matches_oracle(shape, pmode, rep, vxcfg):
     vxcfg.set(s16_no_wspec=1)
     with pytest.raises(_lib.VxError):
         _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+
+
+@pytest.mark.parametrize("cin,cout,shape,pmode", [(16, 16, (2, 8, 16, 32), 1), (32, 32, (2, 6, 10, 12), 1), (64, 64, (3, 4, 4, 4), 1),
+                                                  (16, 16, (1, 5, 33, 20), 0), (8, 16, (2, 4, 8, 16), 1), (128, 128, (2, 2, 2, 2), 1)])
+def test_conv3d_tile_kernel_prologue_matches_oracle(cin, cout, shape, pmode, vxcfg):
+    """normalise-on-load in the general split-fp16 tile kernel (the second conv of the contract blocks below full
+    resolution, unet3D_module.py:231-237): raw input + statistics + the producing block's dropout -> the conv of the
+    normalised, activated, dropped tensor; ragged tiles, several channel chunks, with statistics of its own."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_prologue_ok(d, h, w, cin, cout) == 1
+    raw = (torch.from_numpy(formula_tensor((n, cin, d, h, w), 351, scale=2.0)) + 0.3).float()
+    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 352, scale=(1.0 / (27 * cin)) ** 0.5))
+    b = torch.from_numpy(formula_tensor((cout,), 353, scale=0.2))
+    mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    keep = _hash_mask(61, 4, n, cin, d, h, w) if pmode else torch.ones((n, cin, d, h, w), dtype=torch.float64)
+    xin = F.leaky_relu((raw.double() - mean.cpu().double().view(n, cin, 1, 1, 1)) * rstd.cpu().double().view(n, cin, 1, 1, 1), 0.01)
+    xin = xin * keep * (2.0 if pmode else 1.0)
+    ref = F.conv3d(xin, wt.float().double(), b.float().double(), padding=1)
+    wdv, bd = wt.float().contiguous().to(dev()), b.float().contiguous().to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wdv), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+    xd = cl(raw).to(dev())
+    out = torch.full((n, d, h, w, cout), -77.0, dtype=torch.float32, device=dev())
+    nt = lib.vx_conv3d_k3_tiles_for(d, h, w, cout)
+    st = torch.zeros((n, nt, cout, 2), dtype=torch.float32, device=dev())
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+    a.in_ = xd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+    a.stats_partial = st.data_ptr()
+    a.in_mean, a.in_rstd, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1
+    a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = (_lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE), 61, 4
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_k3_s16_kernel")
+    got = ncdhw(out).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 4e-5, err
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=2e-3)
+    # a padded input pitch is refused (the element index of the dropout bits is derived from the dense layout)
+    a.in_pitch = cin + 4
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")

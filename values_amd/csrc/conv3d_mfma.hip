@@ -631,8 +631,12 @@ static int dispatch_tile_xp(const ConvKArgs& ka, const TileCfg& t, hipStream_t s
   return launch_conv<CB, 1, 4, 4, 4, 4, 1>(ka, s);
 }
 
+bool vx_conv3d_s16_prologue_ok(int Cin, int Cout);
 extern "C" int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout) {
-  return vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+  if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
+  if (vx_conv3d_xp8_applies(D, H, W, Cin, Cout)) return 1;
+  // the split-fp16 tile kernel's plain layers (dense input, see vx_conv3d_k3)
+  return conv_config(Cin, Cout).S16 && vx_conv3d_s16_prologue_ok(Cin, Cout) ? 1 : 0;
 }
 
 extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
@@ -731,7 +735,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
-  if (a.in_mean || a.out_xblk || a.up_in || a.pool_out)
+  const bool tile_pre = a.in_mean && c.S16 && vx_conv3d_s16_prologue_ok(a.Cin, a.Cout) && !a.in_xblk && a.in_pitch == a.Cin &&
+                        a.in_drop_mode != VX_DROP_MASK;
+  if ((a.in_mean && !tile_pre) || a.out_xblk || a.up_in || a.pool_out)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);

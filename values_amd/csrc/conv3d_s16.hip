@@ -214,6 +214,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   const f32x4* w_cg = reinterpret_cast<const f32x4*>(a.w_packed) + (size_t)cg * ka.nchunks * (W_H / 8);
   f32x4 ibuf[IN_IT];
   f32x4 wbuf[W_IT];
+  // normalise-on-load prologue (plain layers, dense input): the input is the RAW output of the previous conv of a
+  // contract block; InstanceNorm with the given statistics, LeakyReLU and that conv's dropout are applied on the way into
+  // LDS (unet3D_module.py:231-237), as conv3d_xp8.hip does for the full-resolution layers.  Run-time flag: the element
+  // index of a piece is (soff + voff) / 4 - biasf because the tensor is dense (in_pitch == Cin), so it costs no table.
+  const bool pre = !XP && a.in_mean != nullptr;
+  const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
+  f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
+  unsigned p_bad = 0, p_e0 = 0, p_key = 0;
   const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
 
@@ -233,12 +241,23 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     else if (cper) coff = (chunk / cper) * xb * Csrc + (chunk % cper) * CB;
     else coff = 0;
     const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TXV * voxf + coff) * 4);
+    const int n_in = have ? n / in_rep : 0;
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+        (void*)(a.in + (size_t)n_in * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
       const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
+    }
+    if (pre) {
+      p_bad = bad;
+      p_e0 = (soff >> 2) - (unsigned)biasf;
+      p_key = vx_drop_key(vx_seed_of(a, a.in_drop_seed), a.in_drop_layer, (uint32_t)n);
+      if (have) {
+        const size_t mo = (size_t)n_in * a.Cin + chunk * CB + (tid % Q) * 4;
+        p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + mo);
+        p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + mo);
+      }
     }
     const f32x4* src = w_cg + (size_t)chunk * (W_H / 8);
 #pragma unroll
@@ -254,6 +273,22 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     for (int it = 0; it < IN_IT; ++it) {
       if (tid + it * NTH < NHALO * Q) {
         f16x4 hi, lo;
+        if (pre) {
+          f32x4 v = ibuf[it];
+          // dropout's factor 2 rides in the scale: 2 lrelu(t) = lrelu(2 t)
+          const f32x4 sc = p_rstd * (a.in_drop_mode == VX_DROP_HASH ? 2.f : 1.f);
+          uint32_t bits = 0xFu;
+          if (a.in_drop_mode == VX_DROP_HASH) bits = vx_drop_bits4(p_key, p_e0 + (voff[it] >> 2));
+          if ((p_bad >> it) & 1u) bits = 0u;             // zero padding belongs to the normalised tensor
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = (v[j] - p_mean[j]) * sc[j];
+            t = fmaxf(t, 0.01f * t);
+            const int keep = __builtin_amdgcn_sbfe(bits, j, 1);
+            v[j] = __int_as_float(__float_as_int(t) & keep);
+          }
+          ibuf[it] = v;
+        }
         vx_split4(ibuf[it], hi, lo);
         *reinterpret_cast<f16x4*>(s_hi + bofs + ldst[it]) = hi;
         *reinterpret_cast<f16x4*>(s_lo + bofs + ldst[it]) = lo;
@@ -916,6 +951,8 @@ void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
 // +2.6 % end to end over the separate conv1x1 kernel (2088 vs 2036 volumes/s) once the lane's weights are hoisted out of
 // the item loop; a first version with per-piece weight loads measured no gain.  VX_NO_HEAD_FUSION=1 (forward) disables it.
 bool vx_conv3d_s16_head_fusable(int Cin, int Cout) { return s16_config(Cin, Cout).XP != 0; }
+// the tile kernel takes the normalise-on-load prologue on its plain (not x-pair) layers
+bool vx_conv3d_s16_prologue_ok(int Cin, int Cout) { return s16_config(Cin, Cout).XP == 0; }
 int vx_conv3d_s16_head_max_classes() { return 4; }
 
 int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {

@@ -285,7 +285,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats, 0));
       VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-      VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
+      // contr_l_2 normalises the raw A_l on load (tile kernel prologue) -- or a pass rewrites A_l in place
+      if (dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && vx_conv3d_k3_prologue_ok(L.D, L.H, L.W, C, C)) pre_layer = 2 * l;
+      else VX_STEP(kNorm[2 * l], norm(p.A[l], C, p.A[l], C, 0, nullptr, L, 2 * l, 1, 0));
     } else {
       // do_instancenorm=False (unet3D_module.py:238-243): conv + LeakyReLU + Dropout, all in the conv's epilogue
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_LRELU, 2 * l, nullptr, 0));

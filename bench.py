@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
                     help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
+    ap.add_argument("--graph", action="store_true", help="C2: replay the step as one captured hipGraph (GraphedPredictor)")
     ap.add_argument("--gather", action="store_true", help="C2, N > 1: also collect every rank's maps on rank 0 (overlapped RCCL gather)")
     ap.add_argument("--eager", action="store_true", help="C4: eager launches instead of the captured hipGraph")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
@@ -413,8 +414,14 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
     # the closing barrier so that the timed region contains every transfer
     pipe = MapGatherPipeline(world if args.gather else 1, rank, depth=2)
 
+    # --graph: the step (33 forward launches + the reduction) captured once and replayed with a fresh device seed word
+    gp = None
+    if args.graph:
+        from values_amd import GraphedPredictor
+        gp = GraphedPredictor([model], tuple(x.shape), n_pred=T)
+
     def step(i):
-        out = predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off")
+        out = gp(x, seed=i) if gp is not None else predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off")
         return pipe.submit(out)
 
     times = timed_regions(step, pipe.flush, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)

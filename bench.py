@@ -16,6 +16,7 @@ gather of every step's maps to rank 0, inside the timed region).
 --config C3: the 5-member deep ensemble of BASELINE config 3, (member, volume block) items dealt over the ranks, one
 RCCL sum-reduce of sufficient statistics per step (values_amd.dist.ensemble_uncertainty_sharded).
 --config C4: HRNet-W18 at 1024x512, 8 TTA views per image (BASELINE config 4), images sharded over the ranks.
+--config C5: 128^3 images through the sliding-window path (64^3 patches, overlap 0.5, T = 20; BASELINE config 5).
 
 Rank 0 prints ONE JSON line; it carries `roofline` (dominant kernel, live HIP-event timing, algorithmic FLOPs and
 bytes, the binding roof named by max(flops / peak, bytes / bandwidth)) and, at N=1, `cpu_baseline` (the oracle =
@@ -319,7 +320,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4"))
+    ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4", "C5"))
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--volumes", type=int, default=None, help="units per GPU per step (C2: 32 volumes, C3: 16, C4: 4 images)")
     ap.add_argument("--T", type=int, default=10)
@@ -376,6 +377,8 @@ def main():
         line = run_c2(args, world, rank, dev, barrier, reduce_max)
     elif args.config == "C3":
         line = run_c3(args, world, rank, dev, barrier, reduce_max)
+    elif args.config == "C5":
+        line = run_c5(args, world, rank, dev, barrier, reduce_max)
     else:
         line = run_c4(args, world, rank, dev, barrier, reduce_max)
     if world > 1:
@@ -541,6 +544,40 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
                        "sharding": f"{M} members x volume blocks over {world} rank(s)"},
             "roofline": None, "cpu_baseline": None}
     line.update(summarise(times, V * args.steps, args.steps))
+    return line
+
+
+def run_c5(args, world, rank, dev, barrier, reduce_max):
+    """BASELINE config 5: 128^3 images, sliding 64^3 patches at half-patch overlap (27 patches per image), T = 20 MC-dropout
+    passes per patch, softmax sums + count map accumulated on the device, maps of the whole image from one reduction;
+    images sharded over the ranks (one step = `--volumes` images per GPU)."""
+    import torch
+    from values_amd import UNet3D
+    from values_amd.sliding import predict_image_sliding
+    torch.manual_seed(123)
+    model = UNet3D(num_classes=2, do_dropout=True).to(dev)
+    B, T, S, P = args.volumes or 2, 20, 128, 64
+    g = torch.Generator(device="cpu").manual_seed(123 + rank)
+    imgs = [torch.randn((S, S, S), generator=g).to(dev) for _ in range(B)]
+
+    def step(i):
+        out = None
+        for b, im in enumerate(imgs):
+            out = predict_image_sliding([model], im, patch_size=P, patch_overlap=0.5, n_pred=T, patch_batch=16,
+                                        seeds=[1000 * i + b])
+        return out
+
+    times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    line = {"metric": "uncertainty-images/sec (128^3 sliding window, T=20 MC-dropout)", "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5: {S}^3 images, {P}^3 patches at overlap 0.5 (27 per image), T={T} MC-dropout passes per "
+                                   "patch, on-device softmax accumulation + count map, one uncertainty reduction per image",
+                       "images_per_gpu_per_step": B, "patch_forwards_per_step": B * 27 * T,
+                       "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
+            "roofline": None, "cpu_baseline": None}
+    line.update(summarise(times, B * world * args.steps, args.steps))
+    line["patch_volumes_per_s"] = round(line["value"] * 27, 1)       # comparable with C2's 64^3 volumes/s at T = 20
     return line
 
 

@@ -23,6 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_c
 find gpurun_out/prof_${tag}_c4 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_c4_kernel_stats.csv \;
 python3 bench.py --config C4 --hrnet-width 48 --steps 4 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4w48_bench.json 2> gpurun_out/${tag}_c4w48_bench.err
 python3 bench.py --config C3 --steps 10 --warmup 3 --repeats 3 > gpurun_out/${tag}_c3_bench.json 2> gpurun_out/${tag}_c3_bench.err
+python3 bench.py --config C5 --steps 4 --warmup 1 --repeats 3 > gpurun_out/${tag}_c5_bench.json 2> gpurun_out/${tag}_c5_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-600
 head -12 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
 head -30 gpurun_out/${tag}_pmc_hbm.txt

@@ -5,6 +5,10 @@ inputs and the network weights that produced them are regenerated from these
 integer-hash formulas, identically in tools/gen_golden.py (run once, in the
 container that has /root/reference) and in the tests (run anywhere).  All
 arithmetic is exact in uint64/float64, so the values do not depend on libm.
+
+Not part of the product path: nothing in values_amd imports this module; its users are tests/, tools/gen_golden.py,
+__graft_entry__.smoke() and bench.py (synthetic weights and inputs of the named shapes).  It lives in the package so that
+those four can share ONE definition on the GPU box, where /root/reference does not exist.
 """
 from __future__ import annotations
 

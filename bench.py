@@ -10,8 +10,9 @@ T=10 MC-dropout forwards of UNet3D (batched on device as V*T samples, hash dropo
 products evaluated fp32-accurately on the f16 matrix cores by operand splitting) -> logits in their pred_idx slots ->
 fused softmax / entropy / MI / variance / argmax reduction.
 Inputs are resident in HBM before the timed region.  Volumes are sharded over ranks (weak scaling: V per GPU fixed),
-no collective on the data path: the maps stay on the rank that computed them (--gather: additionally an overlapped RCCL
-gather of every step's maps to rank 0, inside the timed region).
+no collective on the COMPUTE path; at N > 1 every step's maps are collected on rank 0 by an overlapped RCCL gather
+INSIDE the timed region (SURVEY 8d: "maps resident in rank-0 device memory after the gather") -- `value` is that rate;
+the rate with the maps left on their ranks is printed next to it as `no_gather` (--no-gather makes it the only one).
 
 --config C3: the 5-member deep ensemble of BASELINE config 3, (member, volume block) items dealt over the ranks, one
 RCCL sum-reduce of sufficient statistics per step (values_amd.dist.ensemble_uncertainty_sharded).
@@ -273,14 +274,39 @@ def cpu_baseline_leg(T=10, budget_s=25.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them: /sys/class/kfd/kfd/topology/nodes/*/properties, a node with
+    simd_count > 0 is a GPU (CPU nodes have 0).  Reads sysfs only: neither HIP nor amdsmi nor torch is touched, so the
+    launching parent stays a process that never initialised a GPU runtime.  None when the topology is not readable
+    (then the children find out: rank 0 of a short world exits non-zero)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    seen = False
+    for d in nodes:
+        try:
+            txt = open(os.path.join(base, d, "properties")).read()
+        except OSError:
+            continue
+        seen = True
+        for ln in txt.splitlines():
+            f = ln.split()
+            if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                n += 1
+    return n if seen else None
+
+
 def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` BEFORE this
-    process touches a GPU (a parent that has initialised HIP must never re-exec, and need not: it only waits)."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run`.  This parent
+    never imports torch and never touches HIP / amdsmi (the GPU count comes from sysfs): it only waits for the child and
+    passes its exit code on."""
     import socket
-    import torch
-    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
-    if have < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+    have = kfd_gpu_count()
+    if have is not None and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the kfd topology of this node lists {have} GPU(s)", file=sys.stderr)
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -293,9 +319,11 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def timed_regions(step, flush, barrier, steps, warmup, repeats, reduce_max):
+def timed_regions(step, flush, barrier, steps, warmup, repeats, reduce_max, min_seconds=0.0, max_regions=64):
     """W untimed steps, then `repeats` regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both
-    sides; per region the max over ranks.  Returns the list of region times (seconds)."""
+    sides; per region the max over ranks.  With `min_seconds`, further regions of the same K steps follow until the timed
+    regions add up to that much GPU time (so that a sampler outside this process sees the GPU busy); every rank takes the
+    same decision because the region times are the max over ranks.  Returns the list of region times (seconds)."""
     k = 0
     for _ in range(warmup):
         step(k)
@@ -303,7 +331,7 @@ def timed_regions(step, flush, barrier, steps, warmup, repeats, reduce_max):
     flush()
     barrier()
     times = []
-    for _ in range(repeats):
+    while len(times) < repeats or (sum(times) < min_seconds and len(times) < max_regions):
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -322,6 +350,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4", "C5"))
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
+    ap.add_argument("--min-gpu-seconds", type=float, default=4.0,
+                    help="C2: keep adding timed regions of --steps steps until they add up to this much GPU time")
     ap.add_argument("--volumes", type=int, default=None, help="units per GPU per step (C2: 32 volumes, C3: 16, C4: 4 images)")
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
@@ -331,7 +361,9 @@ def main():
     ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
                     help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
     ap.add_argument("--graph", action="store_true", help="C2: replay the step as one captured hipGraph (GraphedPredictor)")
-    ap.add_argument("--gather", action="store_true", help="C2, N > 1: also collect every rank's maps on rank 0 (overlapped RCCL gather)")
+    ap.add_argument("--no-gather", action="store_true", help="C2, N > 1: leave the maps on the ranks that computed them (default: "
+                    "every step's maps are gathered on rank 0 inside the timed region, the metric SURVEY 8d defines)")
+    ap.add_argument("--gather", action="store_true", help="(default since round 3; kept so that old command lines still parse)")
     ap.add_argument("--eager", action="store_true", help="C4: eager launches instead of the captured hipGraph")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
     ap.add_argument("--detail", type=str, default=None, help="write the per-kernel breakdown JSON here")
@@ -411,11 +443,12 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((V, 1, S, S, S), generator=g).to(dev)  # z-scored synthetic volumes, resident in HBM
 
-    # the volumes are independent: every rank keeps the maps of its shard (as the reference's per-case result files would
-    # be written by whichever process ran the case) -- no collective on the data path.  --gather additionally collects
-    # the maps on rank 0, the gather of step i overlapping the kernels of the following steps, everything flushed before
-    # the closing barrier so that the timed region contains every transfer
-    pipe = MapGatherPipeline(world if args.gather else 1, rank, depth=2)
+    # the volumes are independent: no collective on the compute path.  The metric counts a volume once its
+    # maps are resident on rank 0, so at N > 1 every step's maps are gathered there, the gather of step i overlapping the
+    # kernels of the following steps, everything flushed before the closing barrier so that the timed region contains
+    # every transfer.  --no-gather: the maps stay on their ranks (timed as a side number by default).
+    gather = world > 1 and not args.no_gather
+    pipe = MapGatherPipeline(world if gather else 1, rank, depth=2)
 
     # --graph: the step (33 forward launches + the reduction) captured once and replayed with a fresh device seed word
     gp = None
@@ -427,7 +460,16 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
         out = gp(x, seed=i) if gp is not None else predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off")
         return pipe.submit(out)
 
-    times = timed_regions(step, pipe.flush, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    times = timed_regions(step, pipe.flush, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max,
+                          min_seconds=args.min_gpu_seconds)
+    side = None
+    if gather:
+        # side number: the same steps with the maps left on their ranks (what the gather costs is value vs this)
+        local = MapGatherPipeline(1, rank, depth=2)
+
+        def step_local(i):
+            return local.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
+        side = timed_regions(step_local, local.flush, barrier, args.steps, 1, min(3, max(1, args.repeats)), reduce_max)
     model.check_range()      # the fp16-range word keeps the running maximum over every step above
 
     pcie = None
@@ -468,12 +510,18 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
             "config": {"workload": f"C2: {S}^3 1-channel volumes, UNet3D(initial_filter_size=8, 2 classes), T={T} "
                                    "MC-dropout passes + fused softmax/entropy/MI/variance/argmax reduction",
                        "volumes_per_gpu_per_step": V, "samples_per_gpu_per_step": V * T,
-                       "sharding": (f"volumes over {world} rank(s); " + ("maps gathered to rank 0 (RCCL, overlapped)" if args.gather
+                       "sharding": (f"volumes over {world} rank(s); " + ("maps gathered to rank 0 inside the timed region (RCCL, "
+                                    "overlapped with the next steps' kernels)" if gather
                                     else "maps stay on the rank that computed them, no data-path collective"))
                        if world > 1 else "single GPU",
                        "dropout": "hash bit generator, new seed every step", "weights": "torch default init, seed 123"},
             "roofline": roof, "cpu_baseline": cpu}
     line.update(summarise(times, V * world * args.steps, args.steps))
+    line["gpu_seconds_timed"] = round(sum(times), 3)
+    if side is not None:
+        ss = summarise(side, V * world * args.steps, args.steps)
+        line["no_gather"] = {"value": ss["value"], "ms_per_step": ss["ms_per_step"],
+                             "note": "same steps, maps left on the ranks that computed them"}
     if lat is not None:
         line["latency_single_volume"] = lat
     if detail is not None:

@@ -70,15 +70,12 @@ typedef struct vx_config {
   int32_t conv_fp32;      /* 0: split-fp16 products on the f16 matrix cores (default); 1: native fp32 matrix kernels;
                              2: native fp32 only for Cout == 8 layers */
   int32_t conv_no_c8;     /* fp32 mode: x-pair kernel instead of the 4x4x1 kernel for Cout == 8 */
-  int32_t conv_dma;       /* fp32 mode: LDS-DMA double-buffered schedule (conv3d_dma.hip) */
   int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
   int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
-  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_ping, s16_no_xp8, s16_skip_raw;
+  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_no_xp8, s16_skip_raw;
   int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
-  int32_t s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16;    /* tuning experiments */
   int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
   int32_t s16_no_upfuse;   /* separate upscale2 launch + concat read instead of the up-convolution fused into expand_1_1 */
-  int32_t s16_no_wspec;    /* z-column kernel: every wave stages and multiplies (conv3d_xp8.hip) instead of producer / consumer waves */
   int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
   int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
   int32_t s16_no_poolfuse; /* separate pooling pass over contr_1_2's output instead of the window maxima from its epilogue */

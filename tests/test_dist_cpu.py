@@ -151,6 +151,31 @@ def test_ensemble_work_items_cover_every_member_and_volume_once():
         assert busy == min(world, len(seen) if vols == 1 else world) or busy >= min(world, members)
 
 
+def test_ensemble_work_items_are_balanced_over_the_ranks():
+    """config C3 (5 members, 8 ranks): every rank carries the same number of (member, volume block) items and the same
+    number of member-volumes (round 2 dealt 10 items over 8 ranks: 62 % ideal efficiency by construction)"""
+    from values_amd.dist import ensemble_work_items
+    for members, vols, world in [(5, 128, 8), (5, 16, 8), (5, 8, 8), (5, 32, 4), (5, 32, 2), (3, 16, 8), (5, 64, 1)]:
+        per_rank = ensemble_work_items(members, vols, world)
+        counts = [len(it) for it in per_rank]
+        work = [sum(hi - lo for _, lo, hi in it) for it in per_rank]
+        assert max(counts) == min(counts), (members, vols, world, counts)
+        assert max(work) == min(work), (members, vols, world, work)
+
+
+def test_bench_parent_counts_gpus_without_a_gpu_runtime():
+    """bench.py --gpus N without a launcher: the parent that starts the ranks must not import torch or touch HIP /
+    amdsmi -- it reads the kfd topology from sysfs (None where there is none, as in the build container)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.kfd_gpu_count(); "
+            "assert n is None or n >= 0; assert 'torch' not in sys.modules, 'the launching parent imported torch'; "
+            "print('ok', n)") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr
+
+
 def test_gather_maps_world1_is_identity():
     m = _fake_maps(0, 3)
     assert gather_maps(m, 1, 0) is m

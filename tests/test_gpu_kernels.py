@@ -940,8 +940,8 @@ def test_conv3d_xp8_pooled_output_matches_oracle(shape, pmode, rep, vxcfg):
     if pmode:
         frac = (pfl.cpu() & 0xF).float().ne(0).float().mean().item()
         assert frac > 0.9                                            # 8 elements per window and channel: a drop almost surely
-    # refused where the producer / consumer kernel does not run
-    vxcfg.set(s16_no_wspec=1)
+    # refused where the z-column kernel does not run
+    vxcfg.set(s16_no_xp8=1)
     with pytest.raises(_lib.VxError):
         _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
 

@@ -3,7 +3,7 @@
 late (4..7) waves (s_memtime stamps, VX_CONV_STAMPS build; nothing of this is in the product library).
 Build:  mkdir -p /tmp/stamps && cp values_amd/csrc/*.hip values_amd/csrc/*.h values_amd/csrc/*.cpp values_amd/csrc/Makefile /tmp/stamps ...
         (tools/build_stamps.sh does it)
-Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head[:up] ...]   with VX_S16_PING=1 etc. to pick the variant
+Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head[:up] ...]   with VX_S16_DBG / VX_XP_ABL (diagnostic build only) for phase ablation
         (up = 1: the fused up-convolution of conv3d_xp8.hip, the skip half from a plain 8-channel tensor)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

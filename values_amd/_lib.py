@@ -70,10 +70,10 @@ class AffineArgs(C.Structure):
 class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
-        "conv_fp32", "conv_no_c8", "conv_dma", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
-        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_ping", "s16_no_xp8", "s16_skip_raw",
-        "c2s_no_nt5", "convt_no_mfma", "no_head_fusion", "s16_dbg", "c8_dbg", "dma_dbg", "dma_nw16", "c8_tile16",
-        "s16_range_check", "s16_no_upfuse", "s16_no_wspec", "s16_pw", "s16_prio", "s16_no_poolfuse")]
+        "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
+        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
+        "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
+        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse")]
 
 
 class UncOutputs(C.Structure):

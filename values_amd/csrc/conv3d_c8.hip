@@ -32,11 +32,12 @@ struct ConvC8Args {
   int tiles_x, tiles_y, tiles_z;
   unsigned mx, my, mz;   // ceil(2^32 / tiles_*) for the tile decode
   int no_xcd;            // A/B knob (VX_CONV_NO_XCD): round-robin tile order
-  int dbg;               // tuning experiments only (VX_C8_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
+  int dbg;               // DIAGNOSTIC BUILD ONLY (-DVX_CONV_STAMPS, env VX_C8_DBG): phase ablation, wrong results by design
   unsigned long long* stamps;  // VX_CONV_STAMPS diagnostic builds only
 };
 
 #ifdef VX_CONV_STAMPS
+#define C8_DBG ka.dbg
 #define VX_STAMP(i)                                                                      \
   do {                                                                                   \
     unsigned long long t_;                                                               \
@@ -47,6 +48,7 @@ struct ConvC8Args {
     st_last = t_;                                                                        \
   } while (0)
 #else
+#define C8_DBG 0
 #define VX_STAMP(i) do {} while (0)
 #endif
 
@@ -204,16 +206,16 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
   while (have) {
-    if (ka.dbg < 3) __syncthreads();   // everyone finished reading the previous item from LDS
+    if (C8_DBG < 3) __syncthreads();   // everyone finished reading the previous item from LDS
     VX_STAMP(0);
-    if (ka.dbg < 2) commit();          // (waits for the prefetched loads)
+    if (C8_DBG < 2) commit();          // (waits for the prefetched loads)
     VX_STAMP(1);
-    if (ka.dbg < 3) __syncthreads();
+    if (C8_DBG < 3) __syncthreads();
     VX_STAMP(2);
     int ntile = tile_lin, nchunk = chunk + 1;
     if (nchunk == NCH) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
     const bool nhave = ntile < total;
-    if (ka.dbg < 2) prefetch(ntile, nchunk, nhave);
+    if (C8_DBG < 2) prefetch(ntile, nchunk, nhave);
     VX_STAMP(3);
     __builtin_amdgcn_s_setprio(0);
 
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
 
     __builtin_amdgcn_s_setprio(3);
     VX_STAMP(4);
-    if (ka.dbg >= 1) {
+    if (C8_DBG >= 1) {
       asm volatile("" :: "v"(acc0), "v"(acc1));
     } else if (chunk == NCH - 1) {
       // ---- epilogue: this lane's voxel, 8 channels ----
@@ -411,23 +413,18 @@ static int launch_c8(const ConvC8Args& ka, hipStream_t s) {
 int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_t s) {
   ConvC8Args ka;
   ka.a = a;
-  ka.dbg = vx_cfg().c8_dbg;
+  ka.dbg = 0;   // phase ablation: diagnostic build only (below)
   ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("VX_C8_DBG")) ka.dbg = atoi(e);
 #endif
   ka.tiles_x = (a.W + txv - 1) / txv; ka.tiles_y = (a.H + ty - 1) / ty; ka.tiles_z = (a.D + tz - 1) / tz;
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   const int nch = a.Cin / 8;
-  if (txv == 32 && vx_cfg().c8_tile16) {   // experiment: 4-wave workgroups, tile 16 x 4 x 4 (stats layout differs!)
-    txv = 16; ty = 4; tz = 4;
-    ka.tiles_x = (a.W + txv - 1) / txv;
-    ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
-    return nch == 1 ? launch_c8<1, 16, 4, 4>(ka, s) : launch_c8<2, 16, 4, 4>(ka, s);
-  }
   if (txv == 32) return nch == 1 ? launch_c8<1, 32, 4, 4>(ka, s) : launch_c8<2, 32, 4, 4>(ka, s);
   if (txv == 16) return nch == 1 ? launch_c8<1, 16, 8, 4>(ka, s) : launch_c8<2, 16, 8, 4>(ka, s);
   return nch == 1 ? launch_c8<1, 8, 4, 4>(ka, s) : launch_c8<2, 8, 4, 4>(ka, s);

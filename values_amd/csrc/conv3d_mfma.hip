@@ -37,7 +37,6 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-int vx_conv3d_k3_try_dma(const vx_conv3d_args& a, hipStream_t s);  // conv3d_dma.hip
 // conv3d_c8.hip: the Cout = 8, Cin in {8, 16} layers on the 4x4x1 matrix instruction
 bool vx_conv3d_c8_applies(int Cin, int Cout);
 int vx_pack_conv3d_k3_c8(const float* w_torch, float* w_packed, int Cin, hipStream_t s);
@@ -644,7 +643,7 @@ extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
 }
 
 extern "C" int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout) {
-  return Cin == 8 && !vx_cfg().s16_no_poolfuse && !vx_cfg().s16_no_wspec && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+  return Cin == 8 && !vx_cfg().s16_no_poolfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
@@ -731,7 +730,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (c.C8 && !a.in_mean && !a.out_xblk) return vx_conv3d_k3_c8(a, t.TXV, t.TY, t.TZ, s);
   if (c.S16 && vx_conv3d_xp8_applies(a.D, a.H, a.W, a.Cin, a.Cout) && a.drop_mode != VX_DROP_MASK &&
       a.in_drop_mode != VX_DROP_MASK) {
-    // the full-resolution layers: z-column walk with a rolling LDS window (conv3d_xp8.hip)
+    // the full-resolution layers: z-column walk with a rolling LDS window (conv3d_xp8w.hip)
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
@@ -741,10 +740,6 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);
-  {
-    const int rc = vx_conv3d_k3_try_dma(a, s);   // opt-in (VX_CONV_DMA=1) LDS-DMA schedule; 1 = not taken
-    if (rc != 1) return rc;
-  }
   if (c.XP) return dispatch_tile_xp<8>(ka, t, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_tile<16, 1>(ka, t, s);
   if (c.CB == 16 && c.NT == 2) return dispatch_tile<16, 2>(ka, t, s);

@@ -35,7 +35,8 @@ struct ConvSArgs {
   int no_xcd;
   int ty8;   // 16 x 8 x 4 tiles (vx_conv3d_s16_tile)
   int w_all; // every chunk's weights fit in LDS next to the image: staged once, never re-staged per item
-  int dbg;   // tuning experiments only (VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no barriers
+  int dbg;   // DIAGNOSTIC BUILD ONLY (-DVX_CONV_STAMPS, env VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no
+             // barriers -- phase ablation, the results are wrong by design; the product library compiles S16_DBG to 0
   unsigned long long* stamps;   // VX_CONV_STAMPS diagnostic builds only: per wave, cycles spent per phase
 };
 
@@ -52,9 +53,11 @@ struct ConvSArgs {
     st_last = t_;                                                                        \
   } while (0)
 #define VX_STAMP_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define S16_DBG ka.dbg
 #else
 #define VX_STAMP(i) do {} while (0)
 #define VX_STAMP_WAIT_LOADS() do {} while (0)
+#define S16_DBG 0
 #endif
 
 // XP (Cout == 8, CB == 8): x-pair packing as in conv3d_mfma.hip -- rows = (dx, cout), columns = voxel pairs
@@ -75,9 +78,8 @@ struct ConvSArgs {
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
-  constexpr bool SINGLE = DB == 1 || DB == 2 || DB == 4;   // double-buffered, every item a whole tile (one chunk)
+  constexpr bool SINGLE = DB == 1 || DB == 2;   // double-buffered, every item a whole tile (one chunk)
   constexpr bool STAG = DB == 2 || DB == 3;        // staggered waves (DB = 3: also for several chunks per tile)
-  constexpr bool PING = DB >= 4;                   // ping-pong halves (DB = 5: several chunks per tile), see below
   constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
   constexpr int NVT = TX * TY * TZ / 16;
   constexpr int R = NVT / NW;
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   // DB == 2: DB plus a stagger between the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup share
   // one): waves 4..7 run the epilogue of item k after the barrier of item k + 1, so their stores and statistics
   // overlap the MFMA loop of waves 0..3 and vice versa instead of every wave hitting the same phase together.
-  const bool late = (STAG || PING) && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+  const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
   int red_cur = 0, red_prev = 0, prev_tile = 0;
   bool have_prev = false;
   // DB: item 0 goes into image 0 before the loop, item 1's loads are in flight
@@ -617,17 +619,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     prefetch(db_ntile, db_nchunk, db_nhave, false);
   }
 
-  // PING (DB = 4 / 5): the two waves of a SIMD (w and w + 4) ALTERNATE between the matrix phase and everything else.
-  // Two phases per item, one barrier each:
-  //      phase A                                   | phase B
-  //   waves 0..3:  multiply(k)                     | epilogue(k), stage(k + 1) -> other image, loads(k + 2)
-  //   waves 4..7:  epilogue(k - 1), stage(k + 1),  | multiply(k)
-  //                loads(k + 2)                    |
-  // so on every SIMD one wave feeds the matrix pipe while its partner converts / stores / loads (the pairing of
-  // MI355X_MICROARCH.md "Two waves per SIMD": matrix beside memory, never matrix beside matrix).  In the staggered
-  // variant (DB = 2 / 3) both waves still ran their multiply phases at the same time -- the pipe was shared for the
-  // 108 MFMAs of an item and idle while both converted.  Image k + 1 is written by waves 4..7 in phase A and by waves
-  // 0..3 in phase B of item k, complete at the end of item k; image k is read in both phases.
+  // (A ping-pong schedule -- the two waves of a SIMD alternating between the matrix phase and everything else, one
+  // barrier per phase -- was measured at +20 % time in round 2 and is no longer built; tools/rejected/README.md.)
 #ifdef VX_CONV_STAMPS
   // phases: 0 barrier wait, 1 multiply, 2 epilogue, 3 wait for the prefetched loads, 4 convert + LDS write, 5 issue loads
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_iters = 0;
@@ -640,74 +633,6 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     }
   };
 #endif
-  if constexpr (PING) {
-    __syncthreads();           // image 0 (and resident weights) visible
-    int fl_n = -1, fl_tile = 0, fl_red = 0;   // tile whose statistics slots are complete after the next phase A
-    VX_STAMP(0);
-    while (have) {
-      const int ntile = db_ntile, nchunk = db_nchunk;
-      const bool nhave = db_nhave;
-      db_nchunk = nchunk + 1; db_ntile = ntile;
-      if (db_nchunk == ka.nchunks) { db_nchunk = 0; db_ntile = ntile + (int)gridDim.x; }
-      db_nhave = db_ntile < total;
-      const int cofs = db_cur * BUF_H;
-      db_cur ^= 1;
-      const bool last = chunk == ka.nchunks - 1;
-      // ---------------- phase A ----------------
-      if (!late) {
-        multiply(cofs, chunk);
-        VX_STAMP(1);
-      } else {
-        if (have_prev) { epilogue(prev_tile, red_prev); have_prev = false; }
-        VX_STAMP(2);
-        VX_STAMP_WAIT_LOADS();
-        VX_STAMP(3);
-        if (nhave) commit(false, db_cur * BUF_H);
-        VX_STAMP(4);
-        prefetch(db_ntile, db_nchunk, db_nhave, false);
-        VX_STAMP(5);
-      }
-      __syncthreads();
-      VX_STAMP(0);
-      // ---------------- phase B ----------------
-      if (!late) {
-        flush_one(fl_n, fl_tile, fl_red);     // waves 4..7 left their part of that tile in phase A
-        fl_n = -1;
-        if (last) {
-          pendB_n = -1;
-          epilogue(tile_lin, red_cur);
-          fl_n = pendB_n; fl_tile = pendB_tile; fl_red = red_cur;
-        }
-        VX_STAMP(2);
-        VX_STAMP_WAIT_LOADS();
-        VX_STAMP(3);
-        if (nhave) commit(false, db_cur * BUF_H);
-        VX_STAMP(4);
-        prefetch(db_ntile, db_nchunk, db_nhave, false);
-        VX_STAMP(5);
-      } else {
-        multiply(cofs, chunk);
-        VX_STAMP(1);
-        if (last) { prev_tile = tile_lin; have_prev = true; red_prev = red_cur; }
-      }
-      if (last) red_cur = red_cur == 2 * RED_F ? 0 : red_cur + RED_F;
-      __syncthreads();
-      VX_STAMP(0);
-#ifdef VX_CONV_STAMPS
-      ++st_iters;
-#endif
-      tile_lin = ntile; chunk = nchunk; have = nhave;
-    }
-    if (late && have_prev) epilogue(prev_tile, red_prev);
-    __syncthreads();
-    flush_one(fl_n, fl_tile, fl_red);
-    range_out();
-#ifdef VX_CONV_STAMPS
-    st_flush();
-#endif
-    return;
-  }
-
   while (have) {
     int ntile, nchunk;
     bool nhave;
@@ -735,15 +660,15 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         VX_STAMP(5);
       }
     } else {
-      if (ka.dbg < 3) __syncthreads();
+      if (S16_DBG < 3) __syncthreads();
       flush_stats();
-      if (ka.dbg < 2) commit(w_fresh);
-      if (ka.dbg < 3) __syncthreads();
+      if (S16_DBG < 2) commit(w_fresh);
+      if (S16_DBG < 3) __syncthreads();
       w_fresh = !w_resident;
       ntile = tile_lin; nchunk = chunk + 1;
       if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
       nhave = ntile < total;
-      if (ka.dbg < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+      if (S16_DBG < 2) prefetch(ntile, nchunk, nhave, !w_resident);
     }
     multiply(cofs, chunk);
     VX_STAMP(1);
@@ -757,7 +682,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         VX_STAMP(5);
       }
     }
-    if (ka.dbg >= 1) {
+    if (S16_DBG >= 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -859,7 +784,7 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   constexpr int TPS = 32 / CB, NSTEP = XP ? 9 : (27 + TPS - 1) / TPS;
   constexpr size_t img = (size_t)2 * (XP ? 2 : CB / 8) * PLANE * 8 * 2, wch = (size_t)NSTEP * NT * 2 * (XP ? 32 : 64) * 8 * 2;
   constexpr size_t red = (size_t)(DB >= 2 ? 3 : DB + 1) * NW * NT * 16 * 2 * 4;
-  static_assert((DB ? 2 : 1) * img + ((DB == 3 || DB == 5) ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
+  static_assert((DB ? 2 : 1) * img + (DB == 3 ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
   ka.w_all = DB ? (ka.nchunks > 1 ? 1 : 0)   // double-buffered variants: the dispatch made sure everything fits
                 : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0);
@@ -897,16 +822,6 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
     else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
   }
   if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
-    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db && vx_cfg().s16_ping) {
-      if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 0>(ka, s);
-      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 1>(ka, s);
-      if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 2>(ka, s);
-      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 4, 3>(ka, s);
-    }
-    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3 && vx_cfg().s16_ping) {
-      if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 1>(ka, s);
-      return launch_s16<CB, NT, 16, 8, 4, 8, XP, 5, 3>(ka, s);
-    }
     if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
@@ -969,9 +884,10 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
-  ka.dbg = vx_cfg().s16_dbg;
+  ka.dbg = 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS
+  if (const char* e = getenv("VX_S16_DBG")) ka.dbg = atoi(e);
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   ka.ty8 = ty8;

@@ -687,7 +687,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout);
+bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout) {
+  if (vx_cfg().conv_fp32 != 0 || vx_cfg().s16_no_xp || vx_cfg().s16_no_xp8) return false;
+  // D >= 8: a column has at least two items (the statistics hand-off between the wave halves needs the spacing)
+  return Cout == 8 && (Cin == 8 || Cin == 16) && W % 32 == 0 && H % 8 == 0 && D % 4 == 0 && W >= 32 && H >= 8 && D >= 8;
+}
 
 template <int NCH, int EPI, int PRE, int UP, int NPW>
 static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
@@ -712,8 +716,8 @@ static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
   return VX_OK;
 }
 
-// 1 = not taken (the caller falls back to conv3d_xp8.hip's kernel)
-int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
+// 1 = not taken (the caller uses the general tile kernel)
+int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   Xp8wArgs ka;
   ka.a = a;
   const int nch = a.Cin / 8, tz = 4 / nch;
@@ -731,13 +735,16 @@ int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("VX_XP_ABL")) ka.abl = atoi(e);
 #endif
+  if ((int64_t)a.N * cps >= (1ll << 31)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): too many columns");
+  if (a.stats_partial && (stat_tiles % cps || a.act != VX_ACT_NONE || (a.drop_mode != VX_DROP_NONE && !a.pool_out) || a.head_out))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): statistics go with a plain epilogue");
   const int pre = a.in_mean ? 1 : 0;
   int epi;
   if (a.stats_partial) epi = a.pool_out ? 4 : 0;
   else if (a.head_out) epi = 2;
   else if (a.drop_mode == VX_DROP_HASH) epi = 1;
   else epi = 3;
-  if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;
+  if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // head without dropout: general kernel
   if (epi == 1 && a.act != VX_ACT_LRELU) return 1;
   const int up = a.up_in ? 1 : 0;
   // producer waves: two per SIMD where the staging is heavy; the head epilogue (32 scattered 4-byte stores per lane and
@@ -753,5 +760,8 @@ int vx_conv3d_k3_xp8w(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   XP8W_CASE(2, 1, 0, 0); XP8W_CASE(2, 1, 1, 0); XP8W_CASE(2, 3, 0, 0); XP8W_CASE(2, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 1); XP8W_CASE(2, 1, 1, 1); XP8W_CASE(2, 3, 0, 1); XP8W_CASE(2, 3, 1, 1);
 #undef XP8W_CASE
+  if (up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): no fused up-convolution for this epilogue (act=%d, drop_mode=%d, statistics=%d)",
+                  a.act, a.drop_mode, a.stats_partial ? 1 : 0);
+  if (a.pool_out) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): no pooled output for this epilogue");
   return 1;
 }

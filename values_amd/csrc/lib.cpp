@@ -49,7 +49,6 @@ static void cfg_from_env() {
   memset(&g_cfg, 0, sizeof(g_cfg));
   g_cfg.conv_fp32 = env_int("VX_CONV_FP32", 0);
   g_cfg.conv_no_c8 = env_int("VX_CONV_NO_C8", 0);
-  g_cfg.conv_dma = env_int("VX_CONV_DMA", 0);
   g_cfg.conv_no_xcd = env_int("VX_CONV_NO_XCD", 0);
   g_cfg.conv_per_cu = env_int("VX_CONV_PER_CU", 0);
   g_cfg.s16_per_cu = env_int("VX_S16_PER_CU", 0);
@@ -62,20 +61,13 @@ static void cfg_from_env() {
   g_cfg.s16_no_ty8 = env_int("VX_S16_NO_TY8", 0);
   g_cfg.s16_no_wall = env_int("VX_S16_NO_WALL", 0);
   g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
-  g_cfg.s16_ping = env_int("VX_S16_PING", 0);
   g_cfg.s16_no_xp8 = env_int("VX_S16_NO_XP8", 0);
   g_cfg.s16_skip_raw = env_int("VX_S16_SKIP_RAW", 1);
   g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
   g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);
   g_cfg.no_head_fusion = env_int("VX_NO_HEAD_FUSION", 0);
-  g_cfg.s16_dbg = env_int("VX_S16_DBG", 0);
-  g_cfg.c8_dbg = env_int("VX_C8_DBG", 0);
-  g_cfg.dma_dbg = env_int("VX_DMA_DBG", 0);
-  g_cfg.dma_nw16 = env_int("VX_DMA_NW16", 0);
-  g_cfg.c8_tile16 = env_int("VX_C8_TILE16", 0);
   g_cfg.s16_range_check = env_int("VX_S16_RANGE_CHECK", 1);
   g_cfg.s16_no_upfuse = env_int("VX_S16_NO_UPFUSE", 0);
-  g_cfg.s16_no_wspec = env_int("VX_S16_NO_WSPEC", 0);
   g_cfg.s16_pw = env_int("VX_S16_PW", 0);
   g_cfg.s16_prio = env_int("VX_S16_PRIO", 0);
   g_cfg.s16_no_poolfuse = env_int("VX_S16_NO_POOLFUSE", 0);
@@ -101,5 +93,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 211; /* 0.2.1x: vx_conv3d_args.pool_out, vx_pool_finish; 0.2.1: vx_conv3d_args.up_*, vx_config.s16_no_upfuse / s16_no_wspec / s16_pw / s16_prio */ }
+extern "C" int vx_version(void) { return 300; /* 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

@@ -178,10 +178,13 @@ class MapGatherPipeline:
 # dealt round-robin over the ranks; a rank adds the sufficient statistics of its items into one buffer
 # [V][C+1][vox]; ONE sum-reduce to rank 0 (RCCL) combines members that ran on different ranks; rank 0 finalises.
 def ensemble_work_items(n_members: int, n_volumes: int, world: int):
-    """[(member, v_lo, v_hi)] per rank.  With fewer members than ranks the volumes are split into
-    ceil(world / n_members) blocks so every rank has work (5 members x 2 volume blocks = 10 items on 8 ranks)."""
-    blocks = max(1, -(-world // n_members))
-    blocks = min(blocks, max(1, n_volumes))
+    """[(member, v_lo, v_hi)] per rank, the same NUMBER of items on every rank whenever the volumes allow it: the
+    volumes are split into world / gcd(members, world) blocks, so members x blocks is a multiple of the rank count
+    (5 members on 8 ranks: 8 blocks = 40 items, 5 per rank; round 2 dealt 10 items over 8 ranks, two ranks carrying twice
+    the work of the other six).  Fewer volumes than that: as many blocks as there are volumes."""
+    import math
+    blocks = world // math.gcd(max(1, n_members), world)
+    blocks = max(1, min(blocks, max(1, n_volumes)))
     items = []
     for m in range(n_members):
         for b in range(blocks):

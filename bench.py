@@ -207,7 +207,7 @@ def roofline_leg(model, x, T, reps=3):
     return roof, detail
 
 
-def cpu_baseline_leg(T=10, budget_s=25.0):
+def cpu_baseline_leg(state_dict, T=10, budget_s=25.0):
     """The oracle (kind 'port': PyTorch-CPU restatement of test_3D.py:417-482) on a bounded sample of the same
     workload: the T float64 autograd-on forwards of one 64^3 volume as the reference runs them (fewer, stated, if they
     would not fit the time budget) + the T-sample calculate_uncertainty restatement -> volumes/s; and the same loop in
@@ -216,9 +216,9 @@ def cpu_baseline_leg(T=10, budget_s=25.0):
     import torch
     from oracle import uncertainty_oracle as uo
     from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
-    from values_amd.formula import formula_unet3d_state_dict
     ncpu = os.cpu_count() or 1
-    sd0 = {k: torch.from_numpy(v) for k, v in formula_unet3d_state_dict().items()}
+    # the weights the GPU leg ran with (torch default init, seed 123), as float64 like the reference's model.double()
+    sd0 = {k: v.detach().cpu().double() for k, v in state_dict.items()}
     # pick the thread count that is fastest on a 32^3 pass (oneDNN/ATen float64 conv3d slows down when
     # oversubscribed: 256 threads were 3x slower than 8 on the first GPU-box run)
     cand = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
@@ -234,7 +234,7 @@ def cpu_baseline_leg(T=10, budget_s=25.0):
         if best is None or dt < best:
             best, cores = dt, c
     torch.set_num_threads(cores)
-    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in formula_unet3d_state_dict().items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
     g = torch.Generator().manual_seed(123)
     x = torch.randn((1, 1, 64, 64, 64), generator=g, dtype=torch.float64)
     shapes = [(8, 64), (8, 64), (16, 32), (16, 32), (32, 16), (32, 16), (64, 8), (64, 8), (64, 8), (64, 8), (64, 8),
@@ -503,7 +503,7 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
     if rank == 0 and not args.no_latency:
         lat = latency_leg(model, x[:1], T)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(T)
+        cpu = cpu_baseline_leg(model.state_dict(), T)
     line = {"metric": "uncertainty-volumes/sec (64^3, T=10 MC-dropout)", "unit": "volumes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -634,7 +634,7 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     sharded over the ranks.  One step = B images per GPU = 8 B forwards (every view is its own batch, as test_2D.py:299-311
     runs them: training-mode BatchNorm sees one view at a time)."""
     import torch
-    from values_amd.formula import hrnet_w18_extra, hrnet_w48_extra
+    from values_amd.hrnet_configs import hrnet_w18_extra, hrnet_w48_extra
     from values_amd.hrnet import HighResolutionNet
     from values_amd.predict2d import GraphedPredictor2D, predict_logits_2d, process_output_2d, tta_views_8
     B = args.volumes or 4

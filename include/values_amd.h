@@ -262,6 +262,8 @@ typedef struct vx_norm_args {
                                  NULL: only the pooled tensor is produced (the consumer conv normalises the skip half
                                  itself, vx_conv3d_args.in_mean) */
   const uint32_t* seed_dev;   /* as in vx_conv3d_args */
+  uint32_t* range_flag;       /* nullable, as in vx_conv3d_args: set where this pass does NOT normalise (do_instancenorm=False:
+                                 the first layer's activation / dropout pass feeds a split-fp16 conv un-normalised) */
 } vx_norm_args;
 int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
 /* Same, but sample n of the OUTPUT reads sample n / x_repeat of x / mean / rstd: the T MC-dropout samples of a

@@ -6,9 +6,8 @@ integer-hash formulas, identically in tools/gen_golden.py (run once, in the
 container that has /root/reference) and in the tests (run anywhere).  All
 arithmetic is exact in uint64/float64, so the values do not depend on libm.
 
-Not part of the product path: nothing in values_amd imports this module; its users are tests/, tools/gen_golden.py,
-__graft_entry__.smoke() and bench.py (synthetic weights and inputs of the named shapes).  It lives in the package so that
-those four can share ONE definition on the GPU box, where /root/reference does not exist.
+Test infrastructure (round 3: moved out of the product package): users are tests/, tools/ (gen_golden.py, the fuzzers)
+and __graft_entry__.smoke().  Nothing in values_amd/ and nothing bench.py times imports it.
 """
 from __future__ import annotations
 
@@ -151,6 +150,7 @@ def formula_state_dict_from_shapes(shapes, seed_tag: int = 0):
     return sd
 
 
+# reduced HRNet layouts of the golden fixtures (tools/gen_golden.py); the shipped layouts live in values_amd.hrnet_configs
 HRNET_SMALL_EXTRA = {
     "DROPOUT_FINAL": True, "FINAL_CONV_KERNEL": 1,
     "STAGE1": {"NUM_MODULES": 1, "NUM_BRANCHES": 1, "BLOCK": "BOTTLENECK", "NUM_BLOCKS": [2], "NUM_CHANNELS": [32],
@@ -175,27 +175,3 @@ HRNET_W18S_EXTRA = {   # HRNet-W18 widths (BASELINE config 4) with fewer blocks 
     "STAGE4": {"NUM_MODULES": 1, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [1, 1, 1, 1],
                "NUM_CHANNELS": [18, 36, 72, 144], "FUSE_METHOD": "SUM"},
 }
-
-
-def hrnet_w48_extra(dropout_final=True):
-    """The shipped configs/model/hrnet_config*.yaml layout (W48)."""
-    return {
-        "DROPOUT_FINAL": dropout_final, "FINAL_CONV_KERNEL": 1,
-        "STAGE1": {"NUM_MODULES": 1, "NUM_BRANCHES": 1, "BLOCK": "BOTTLENECK", "NUM_BLOCKS": [4], "NUM_CHANNELS": [64],
-                   "FUSE_METHOD": "SUM"},
-        "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [48, 96],
-                   "FUSE_METHOD": "SUM"},
-        "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4],
-                   "NUM_CHANNELS": [48, 96, 192], "FUSE_METHOD": "SUM"},
-        "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4, 4],
-                   "NUM_CHANNELS": [48, 96, 192, 384], "FUSE_METHOD": "SUM"},
-    }
-
-
-def hrnet_w18_extra(dropout_final=True):
-    """The public HRNet-W18 layout (BASELINE config 4): widths 18/36/72/144, same blocks/modules as W48."""
-    e = hrnet_w48_extra(dropout_final)
-    e["STAGE2"]["NUM_CHANNELS"] = [18, 36]
-    e["STAGE3"]["NUM_CHANNELS"] = [18, 36, 72]
-    e["STAGE4"]["NUM_CHANNELS"] = [18, 36, 72, 144]
-    return e

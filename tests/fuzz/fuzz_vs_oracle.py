@@ -10,7 +10,7 @@ import torch
 torch.set_num_threads(16)
 from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
 from values_amd import UNet3D, predict_uncertainty
-from values_amd.formula import formula_unet3d_state_dict
+from tests.formula import formula_unet3d_state_dict
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from values_amd.formula import formula_unet3d_state_dict
+from tests.formula import formula_unet3d_state_dict
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -23,7 +23,7 @@ def _worker_sharded(rank, world, port, q):
         from tests.test_gpu_unet3d import KEYS, make_model
         from values_amd import predict_uncertainty
         from values_amd.dist import ensemble_uncertainty_sharded, gather_maps, shard_range
-        from values_amd.formula import formula_volume
+        from tests.formula import formula_volume
         models = [make_model(seed_tag=s, do_dropout=False) for s in range(3)]
         x = torch.from_numpy(np.concatenate([formula_volume((1, 1, 16, 16, 16), tag=70 + i) for i in range(3)], 0)).float().cuda()
         sh = ensemble_uncertainty_sharded(models, x, world=world, rank=rank, n_pred=1)
@@ -71,7 +71,7 @@ def _worker_nccl(rank, world, port, q):
         from tests.test_gpu_unet3d import KEYS, make_model
         from values_amd import predict_uncertainty
         from values_amd.dist import MapGatherPipeline, ensemble_uncertainty_sharded, shard_range
-        from values_amd.formula import formula_volume
+        from tests.formula import formula_volume
         assert dist.get_world_size() == world and str(dist.get_backend()).lower() == "nccl"
         models = [make_model(seed_tag=s, do_dropout=False) for s in range(3)]
         x = torch.from_numpy(np.concatenate([formula_volume((1, 1, 16, 16, 16), tag=70 + i) for i in range(4)], 0)).float().to(dev)

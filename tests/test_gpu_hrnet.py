@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from tests.helpers import load_npz
-from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes, formula_tensor
+from tests.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes, formula_tensor
 
 pytestmark = pytest.mark.gpu
 KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
@@ -163,7 +163,7 @@ def test_predict_2d_driver_mc_and_tta_vs_oracle():
 def test_hrnet_ssn_head_matches_reference_fixture():
     """HighResolutionNet with the SSN head (hrnet_config_ssn.yaml keys; hrnet_module.py:430-453, 559-595): state-dict
     names, mean, samples with the reference's captured normals (test_2D.py:285-299), and the generated diagonal noise"""
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     from values_amd.hrnet import HighResolutionNet
     g = load_npz("hrnet_ssn.npz")
     shapes = json.loads(bytes(g["shapes_json"]).decode())
@@ -195,7 +195,7 @@ def test_hrnet_ssn_head_matches_reference_fixture():
 def test_hrnet_w18_widths_match_reference_fixture():
     """HRNet-W18 widths (18/36/72/144, 270 concatenated, 5 classes): the zero-padded round16(C) layout of the HIP
     path gives the reference's logits, with DROPOUT_FINAL masks and without"""
-    from values_amd.formula import HRNET_W18S_EXTRA
+    from tests.formula import HRNET_W18S_EXTRA
     from values_amd.hrnet import HighResolutionNet
     g = load_npz("hrnet_w18s.npz")
     shapes = json.loads(bytes(g["shapes_json"]).decode())
@@ -221,10 +221,18 @@ def test_hrnet_w18_widths_match_reference_fixture():
         else:
             y = m(x).cpu().numpy()
             assert np.abs(y - g["logits_nodrop"]).max() < 5e-5
+            # the persistent zero-padded buffers: their tails are still zero after forwards, and a second geometry REPLACES
+            # a layer's buffer instead of adding one (the cache grew without bound)
+            assert m.zero_tails_intact()
+            n_buf = len(m._zcache)
+            y2 = m(torch.cat([x, x], 0)[:, :, :x.shape[2] // 2 * 2 - 32]).cpu().numpy()      # another batch size and height
+            assert np.isfinite(y2).all() and len(m._zcache) == n_buf and m.zero_tails_intact()
+            y3 = m(x).cpu().numpy()
+            assert np.array_equal(y3, y)
 
 
 def _w18_full(ncls=19):
-    from values_amd.formula import hrnet_w18_extra
+    from values_amd.hrnet_configs import hrnet_w18_extra
     from values_amd.hrnet import HighResolutionNet
     g = load_npz("hrnet_w18_256x478.npz")
     shapes = json.loads(bytes(g["shapes_json"]).decode())
@@ -314,7 +322,7 @@ def test_batched_tta_views_equal_one_forward_per_view():
     """predict_logits_2d(batch_views=True): the TTA views as ONE batch with BatchNorm statistics per view
     (vx_bn_finalize_groups, vx_affine_args.group_images) give the bits of one forward per view (test_2D.py:299-311) --
     W18 widths (zero-padded channels, persistent padded buffers) and the small W48-style net, 4 and 8 views, batch 2."""
-    from values_amd.formula import HRNET_W18S_EXTRA
+    from tests.formula import HRNET_W18S_EXTRA
     from values_amd.hrnet import HighResolutionNet
     from values_amd.predict2d import predict_logits_2d, tta_views_8
     g = load_npz("hrnet_w18s.npz")
@@ -344,7 +352,7 @@ def test_batched_tta_views_equal_one_forward_per_view():
 def test_graphed_predictor_2d_replays_the_eager_bits():
     """GraphedPredictor2D: predict_logits_2d + process_output_2d captured into one hipGraph (branches on side streams
     inside the capture) -- the replay gives the eager path's bits, for new inputs too; wrong shapes are refused."""
-    from values_amd.formula import HRNET_W18S_EXTRA
+    from tests.formula import HRNET_W18S_EXTRA
     from values_amd.hrnet import HighResolutionNet
     from values_amd.predict2d import GraphedPredictor2D, predict_logits_2d, process_output_2d, tta_views_8
     g = load_npz("hrnet_w18s.npz")

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from tests.helpers import load_npz
 from values_amd import _lib
-from values_amd.formula import formula_tensor
+from tests.formula import formula_tensor
 
 pytestmark = pytest.mark.gpu
 
@@ -120,28 +120,6 @@ def test_conv3d_k3_matches_oracle(cin, cout, shape, conv_mode):
     s = st.double().sum(1)
     np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
-
-
-@pytest.mark.parametrize("cin,cout,shape,xb", [
-    (8, 8, (2, 8, 8, 64), 0), (16, 8, (1, 5, 7, 38), 0), (16, 16, (1, 8, 8, 16), 0), (32, 16, (1, 6, 9, 20), 0),
-    (8, 16, (1, 16, 16, 16), 0), (16, 8, (2, 8, 8, 32), 4), (32, 16, (1, 4, 8, 16), 4),
-])
-def test_conv3d_k3_lds_dma_schedule_matches_oracle(cin, cout, shape, xb, vxcfg):
-    """the opt-in double-buffered LDS-DMA schedule (conv3d_dma.hip) gives the same result as the default kernel"""
-    vxcfg.setenv("VX_CONV_FP32", "1")     # the LDS-DMA schedule is a variant of the native-fp32 kernels
-    vxcfg.setenv("VX_CONV_DMA", "1")
-    n, d, h, w = shape
-    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 105))
-    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 106, scale=(1.0 / (27 * cin)) ** 0.5))
-    b = torch.from_numpy(formula_tensor((cout,), 107, scale=0.2))
-    ref = F.conv3d(x.float().double(), wt.float().double(), b.float().double(), padding=1)
-    got, st, _ = run_conv(x, wt, b, stats=True, xblk=xb)
-    assert (got.double() - ref).abs().max().item() < 2e-5
-    s = st.double().sum(1)
-    np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
-    vxcfg.delenv("VX_CONV_DMA")
-    got2, _, _ = run_conv(x, wt, b, stats=True, xblk=xb)
-    assert torch.equal(got, got2)   # same accumulation order in both schedules -> bit-identical
 
 
 @pytest.mark.parametrize("cin,shape,ncls,xb", [(8, (3, 8, 8, 32), 2, 0), (16, (2, 5, 7, 38), 4, 0), (16, (2, 4, 8, 16), 2, 4),

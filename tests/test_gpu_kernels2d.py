@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from values_amd import _lib
-from values_amd.formula import formula_tensor
+from tests.formula import formula_tensor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

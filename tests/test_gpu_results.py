@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from values_amd.formula import formula_volume
+from tests.formula import formula_volume
 
 pytestmark = pytest.mark.gpu
 
@@ -80,7 +80,7 @@ def test_softmax_model_gets_one_minus_msr_maps(tmp_path):
 def test_metrics_match_oracle(C, T, R, shape):
     """calculate_test_metrics / calculate_ged (test_3D.py:250-358) from the two device reductions vs the oracle"""
     from oracle import metrics_oracle as mo
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     from values_amd.metrics import calculate_ged, calculate_test_metrics, mask_agreement
     logits = formula_tensor((T, C) + shape, 8100 + C, scale=2.5)
     e = np.exp(logits - logits.max(1, keepdims=True))
@@ -104,6 +104,29 @@ def test_metrics_match_oracle(C, T, R, shape):
                 assert I[i, j, c] == int(((masks[i] == c) & (masks[j] == c)).sum())
 
 
+def test_hard_dice_and_ged_closed_forms_on_device():
+    """f2: values_amd.metrics (vx_mask_agreement counts -> ratios) against the hand-counted answers of tests/dice_kat.py --
+    the same table the oracle is held to on the CPU.  The row stays parity-unpinned (torchmetrics is absent); these pin the
+    documented definition, including its 0 / 0 -> 0 quirk."""
+    from tests import dice_kat
+    from values_amd.metrics import _micro_dice, calculate_ged, calculate_test_metrics, mask_agreement
+    for c in dice_kat.cases():
+        sm = torch.from_numpy(dice_kat.onehot(np.stack(c["preds"]), c["C"])).cuda()
+        gt = torch.from_numpy(np.stack(c["gts"])).cuda()
+        if c["dice"] is not None:
+            # calculate_test_metrics takes the MEAN prediction (1, C, ...): one prediction per case here
+            assert calculate_test_metrics(sm[:1], gt)["dice"] == pytest.approx(c["dice"], abs=1e-12), c["name"]
+        g = calculate_ged(sm, gt, ignore_index=0)
+        assert g["ged"] == pytest.approx(c["ged"], abs=1e-12), c["name"]
+        if "max_dice_rater" in c:
+            for r, v in enumerate(c["max_dice_rater"]):
+                assert g["max dice rater {}".format(r)] == pytest.approx(v, abs=1e-7), c["name"]
+            assert g["max dice pred"] == pytest.approx(c["max_dice_pred"], abs=1e-7), c["name"]
+    p, gl, acc = dice_kat.no_ignore_case()
+    I = mask_agreement(torch.from_numpy(np.concatenate([p, gl], 0)).cuda(), 3)
+    assert _micro_dice(I, [0], [1], [0, 1, 2]) == pytest.approx(acc, abs=1e-12)
+
+
 def test_metrics_edge_cases():
     from oracle import metrics_oracle as mo
     from values_amd.metrics import calculate_ged
@@ -123,7 +146,7 @@ def test_metrics_edge_cases():
                                   (3 * 64 ** 3, [0.9731, 0.5, 0.99999])])
 def test_quantile_is_bit_identical_to_numpy(n, qs):
     """np.quantile of find_threshold.py:61-66 via radix select: exact, including ties, negatives and interpolation"""
-    from values_amd.formula import hash_uniform
+    from tests.formula import hash_uniform
     from values_amd.thresholds import quantile
     x = (hash_uniform(n, 31) * 0.7).astype(np.float32)
     x[::7] = 0.0                      # many exact ties at 0 (uncertainty maps are mostly 0)
@@ -141,7 +164,7 @@ def test_find_threshold_files(tmp_path):
     threshold_aggregation (aggregate_uncertainties.py:59-60)"""
     from values_amd import nifti
     from values_amd.aggregation import threshold_aggregation
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     from values_amd.thresholds import (calculate_foreground_quantile_image, find_threshold, save_foreground_quantiles)
     segs = [(formula_tensor((8, 8, 8), 40 + i) > 0.6).astype(np.uint8) for i in range(3)]
     qs = [calculate_foreground_quantile_image(s) for s in segs]
@@ -175,7 +198,7 @@ def test_find_threshold_files(tmp_path):
 
 def test_2d_results_directory(tmp_path):
     """save_prediction / save_uncertainty (test_2D.py:116-159): names, colours, ignore map, float32 TIFF content"""
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     from values_amd.image_io import read_png, read_tiff_f32
     from values_amd.results2d import TRAINID2COLOR, create_save_dirs, save_prediction, save_uncertainty
     H, W, T = 12, 20, 3

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from tests.helpers import formula_sd_torch, load_npz
-from values_amd.formula import formula_tensor, formula_unet3d_state_dict, formula_volume
+from tests.formula import formula_tensor, formula_unet3d_state_dict, formula_volume
 
 pytestmark = pytest.mark.gpu
 KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from tests.helpers import formula_sd_torch, load_npz, unpack_masks
-from values_amd.formula import formula_unet3d_state_dict, formula_volume
+from tests.formula import formula_unet3d_state_dict, formula_volume
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ def stacked_masks(g, T):
 
 def test_state_dict_names_match_reference():
     from values_amd import UNet3D
-    from values_amd.formula import unet3d_param_shapes
+    from tests.formula import unet3d_param_shapes
     m = UNet3D(num_classes=2, do_dropout=True)
     ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert ours == dict(unet3d_param_shapes())
@@ -375,7 +375,7 @@ def test_aleatoric_head_sampling_matches_reference_formula():
     from oracle import uncertainty_oracle as uo
     from oracle.unet3d_oracle import unet3d_forward
     from values_amd import UNet3D, predict_uncertainty
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     sd = formula_unet3d_state_dict(seed_tag=4, aleatoric_loss=True)
     model = UNet3D(num_classes=2, aleatoric_loss=True)
     model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
@@ -403,7 +403,7 @@ def test_ssn_matches_reference_fixture_and_generated_noise_is_standard_normal():
     """SsnUNet3D (ssn_unet3D_module.py) + predict_cases_ssn sampling (test_3D.py:373-388): head, samples with the
     reference's captured normals, and the ssn=True maps; then the on-device generator's moments."""
     from values_amd import SsnUNet3D, predict_uncertainty
-    from values_amd.formula import formula_ssn_state_dict
+    from tests.formula import formula_ssn_state_dict
     from values_amd.io import instantiate
     g = load_npz("ssn_16.npz")
     NC, R, size = 2, 10, 16
@@ -606,6 +606,89 @@ def test_fp16_range_guard_never_returns_nan_maps():
     assert ok.range_max() == 0.0        # magnitudes below 32768 are not reported
 
 
+def _overflowing_model(do_dropout=False, **kw):
+    """a checkpoint whose center drives the decoder past the fp16 limit (see the test above)"""
+    from values_amd import UNet3D
+    sd = formula_unet3d_state_dict(seed_tag=2)
+    sd["center.4.weight"] = sd["center.4.weight"] * 3e7
+    model = UNet3D(num_classes=2, do_dropout=do_dropout, **kw)
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()})
+    return model.cuda(), sd
+
+
+def test_fp16_range_guard_covers_every_driver():
+    """the guard lived in predict_uncertainty only.  The same overflowing checkpoint through the sliding
+    window driver (the reference's main test_3D path), the member-sharded ensemble, the captured graph and the host
+    pipeline: each either raises or returns the native-fp32 result -- finite, equal to predict_uncertainty's fallback --
+    and the fallback replays the SAME dropout bits when the caller gave no seeds."""
+    from values_amd import GraphedPredictor, HostPipeline, _lib, predict_uncertainty
+    from values_amd.dist import ensemble_uncertainty_sharded
+    from values_amd.sliding import predict_image_sliding
+    model, _ = _overflowing_model()
+    x = torch.from_numpy(formula_volume((2, 1, 16, 16, 16), tag=95)).float().cuda()
+    want = predict_uncertainty([model], x, n_pred=1)                       # fallback result (checked against the oracle above)
+    assert torch.isfinite(want["logits"]).all()
+    # sliding window: one 16^3 patch per image
+    with pytest.raises(_lib.VxError):
+        predict_image_sliding([model], x[0, 0], patch_size=16, patch_overlap=1, n_pred=1, range_check="raise")
+    sl = predict_image_sliding([model], x[0, 0], patch_size=16, patch_overlap=1, n_pred=1)
+    assert torch.isfinite(sl["pred_entropy"]).all()
+    assert (sl["pred_entropy"] - want["pred_entropy"][0]).abs().max().item() < 2e-6
+    assert torch.equal(sl["pred_seg_mean"], want["pred_seg_mean"][0])
+    # member-sharded statistics path
+    with pytest.raises(_lib.VxError):
+        ensemble_uncertainty_sharded([model], x, world=1, rank=0, n_pred=1, range_check="raise")
+    sh = ensemble_uncertainty_sharded([model], x, world=1, rank=0, n_pred=1)
+    assert (sh["pred_entropy"] - want["pred_entropy"]).abs().max().item() < 2e-6
+    # captured graph: the weights of the split-fp16 family stay alive while the fallback packs the fp32 family
+    gp = GraphedPredictor([model], tuple(x.shape), n_pred=1)
+    g = gp(x, check=True)
+    assert (g["pred_entropy"] - want["pred_entropy"]).abs().max().item() < 2e-6
+    raw = gp(x)                                                            # unchecked replay still runs (pointers valid) ...
+    with pytest.raises(_lib.VxError):
+        gp.check_range()                                                   # ... and the word says what happened
+    # host pipeline: the word travels with the maps, no read on the submit path
+    hp = HostPipeline([model], n_pred=1)
+    outs = [hp.submit(x.cpu()) for _ in range(4)] + hp.flush()
+    outs = [o for o in outs if o is not None]
+    assert len(outs) == 4
+    for o in outs:
+        assert np.isfinite(o["pred_entropy"]).all()
+        assert np.abs(o["pred_entropy"] - want["pred_entropy"].cpu().numpy()).max() < 2e-6
+    hp = HostPipeline([model], n_pred=1, range_check="raise")
+    with pytest.raises(_lib.VxError):
+        [hp.submit(x.cpu()) for _ in range(4)], hp.flush()
+    # un-seeded MC-dropout: the second (fp32) run draws the bits the first one drew
+    drop, _ = _overflowing_model(do_dropout=True)
+    calls = drop._calls
+    a = predict_uncertainty([drop], x, n_pred=3)
+    seed = (drop.seed * 1000003 + calls) & 0xFFFFFFFF
+    with _lib.config(conv_fp32=1):
+        b = predict_uncertainty([drop], x, n_pred=3, seeds=[seed], range_check="off")
+    assert torch.equal(a["logits"], b["logits"])
+
+
+def test_fp16_range_guard_without_instancenorm_covers_the_first_block():
+    """do_instancenorm=False: nothing normalises the first layer's output on its way into contr_1_2 (a split-fp16 conv) --
+    the activation / dropout pass records the range there (vx_norm_args.range_flag)."""
+    from oracle.unet3d_oracle import unet3d_forward
+    from values_amd import UNet3D, _lib, predict_uncertainty
+    sd = formula_unet3d_state_dict(seed_tag=3)
+    model = UNet3D(num_classes=2, do_dropout=False, do_instancenorm=False)
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in sd.items()}, strict=False)
+    model = model.cuda()
+    x = torch.from_numpy(formula_volume((1, 1, 16, 16, 16), tag=96)) * 4e6        # raw intensities of any scale are legal input
+    with pytest.raises(_lib.VxError):
+        predict_uncertainty([model], x.float().cuda(), n_pred=1, range_check="raise")
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=1)
+    assert torch.isfinite(out["logits"]).all()
+    with torch.no_grad():
+        ref = unet3d_forward({k: torch.from_numpy(v).float().double() for k, v in sd.items()}, x.float().double(),
+                             instancenorm=False)
+    lg = out["logits"][:, 0].cpu().double()
+    assert ((lg - ref).abs().max() / ref.abs().max()).item() < 1e-5        # logits of magnitude 1e4: float32 arithmetic
+
+
 def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():
     """values_amd.GraphedPredictor: forward + reduction captured into one hipGraph; a replay with device seed word s gives
     the bits of the eager call with the same effective seed, another word other dropout samples, another input its maps"""
@@ -666,7 +749,7 @@ def test_ctor_variants_vs_oracle(in_channels, instancenorm, size):
     from oracle import uncertainty_oracle as uo
     from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
     from values_amd import UNet3D, predict_uncertainty
-    from values_amd.formula import unet3d_param_shapes
+    from tests.formula import unet3d_param_shapes
     sd = formula_unet3d_state_dict(seed_tag=6, in_channels=in_channels)
     model = UNet3D(num_classes=2, in_channels=in_channels, do_instancenorm=instancenorm, do_dropout=True)
     assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == dict(unet3d_param_shapes(in_channels=in_channels))

@@ -94,7 +94,7 @@ def test_experiment_version_and_dataloader_paths(tmp_path):
 
 def test_png_and_tiff_codecs_round_trip_and_decode_with_an_independent_reader(tmp_path):
     """2D result files (test_2D.py:145-158): our writers vs our readers, and vs PIL where it is installed"""
-    from values_amd.formula import formula_tensor
+    from tests.formula import formula_tensor
     from values_amd.image_io import read_png, read_tiff_f32, write_png, write_tiff_f32
     rgb = ((formula_tensor((37, 53, 3), 91) + 1) * 127.5).astype(np.uint8)
     grey = ((formula_tensor((5, 7), 92) + 1) * 127.5).astype(np.uint8)

@@ -3,7 +3,7 @@
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from values_amd.formula import hrnet_w18_extra, hrnet_w48_extra
+from values_amd.hrnet_configs import hrnet_w18_extra, hrnet_w48_extra
 from values_amd.hrnet import HighResolutionNet
 
 ap = argparse.ArgumentParser()

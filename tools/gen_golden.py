@@ -59,7 +59,7 @@ from uncertainty_modeling.toy_datamodule_3D import get_val_test_data_samples as 
 from uncertainty_modeling.lidc_idri_datamodule_3D import get_val_test_data_samples as ref_samples_lidc  # noqa: E402
 import evaluation.uncertainty_aggregation.aggregate_uncertainties as ref_agg  # noqa: E402
 
-from values_amd.formula import formula_tensor, formula_unet3d_state_dict, formula_volume, hash_uniform  # noqa: E402
+from tests.formula import formula_tensor, formula_unet3d_state_dict, formula_volume, hash_uniform  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -338,7 +338,7 @@ def gen_hrnet_ssn():
     import copy
     import torch.distributions.lowrank_multivariate_normal as lrm
     import uncertainty_modeling.models.hrnet_module as ref_hr
-    from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
+    from tests.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
     extra = copy.deepcopy(HRNET_SMALL_EXTRA)
     extra["DROPOUT_FINAL"] = False
     ncls, R, S = 4, 10, 2
@@ -384,7 +384,7 @@ def gen_hrnet_w18():
     BASELINE config 4), 5 classes, training-mode BN, two passes with DROPOUT_FINAL masks captured + one without."""
     import copy
     import uncertainty_modeling.models.hrnet_module as ref_hr
-    from values_amd.formula import HRNET_W18S_EXTRA, formula_state_dict_from_shapes
+    from tests.formula import HRNET_W18S_EXTRA, formula_state_dict_from_shapes
     extra = copy.deepcopy(HRNET_W18S_EXTRA)
     ncls = 5
     cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
@@ -438,7 +438,8 @@ def gen_hrnet_w18_full():
     the VerticalFlip / HorizontalFlip views' logits on the sub-grid for the 8-view TTA of config 4."""
     import copy
     import uncertainty_modeling.models.hrnet_module as ref_hr
-    from values_amd.formula import formula_state_dict_from_shapes, hrnet_w18_extra
+    from tests.formula import formula_state_dict_from_shapes
+    from values_amd.hrnet_configs import hrnet_w18_extra
     extra = copy.deepcopy(hrnet_w18_extra(False))
     ncls = 19
     cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},
@@ -547,7 +548,7 @@ def gen_ssn():
     formula tensors (captured), then softmax + calculate_uncertainty(ssn=True)."""
     import torch.distributions.lowrank_multivariate_normal as lrm
     from uncertainty_modeling.models.ssn_unet3D_module import SsnUNet3D as RefSsn
-    from values_amd.formula import formula_ssn_state_dict
+    from tests.formula import formula_ssn_state_dict
     NC, R, S, size = 2, 10, 3, 16
     model = RefSsn(num_classes=NC, rank=R)
     sd = formula_ssn_state_dict(NC, R)
@@ -621,7 +622,7 @@ def gen_metrics():
 def gen_hrnet():
     import copy
     import uncertainty_modeling.models.hrnet_module as ref_hr
-    from values_amd.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
+    from tests.formula import HRNET_SMALL_EXTRA, formula_state_dict_from_shapes
     extra = copy.deepcopy(HRNET_SMALL_EXTRA)
     ncls = 4
     cfg = _Cfg({"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3, "PRETRAINED": False},

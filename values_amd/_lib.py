@@ -41,7 +41,8 @@ class NormArgs(C.Structure):
                 ("pool_out", _p), ("pool_pitch", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("C", _i32),
                 ("act", _i32), ("drop_mode", _i32), ("drop_seed", _u32), ("drop_layer", _u32), ("drop_mask", _p),
-                ("out_xblk", _i32), ("out_half", _i32), ("x_xblk", _i32), ("x_half", _i32), ("seed_dev", _p)]
+                ("out_xblk", _i32), ("out_half", _i32), ("x_xblk", _i32), ("x_half", _i32), ("seed_dev", _p),
+                ("range_flag", _p)]
 
 
 class ConvTArgs(C.Structure):

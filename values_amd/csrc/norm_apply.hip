@@ -53,6 +53,13 @@ extern "C" int vx_instnorm_finalize(const float* stats_partial, int N, int ntile
 // original int64 % and / chain cost ~300 VALU instructions per piece and made the write-only fan-out kernel
 // instruction-bound at 2.7 TB/s.
 struct NormDecode { unsigned per_sample, mPW, mC4, mH; };   // magic 0 = divisor 1
+// fp16 range word (vx_conv3d_args.range_flag): one atomic per wave, and only for magnitudes within a factor two of the limit
+__device__ __forceinline__ void vx_range_report(uint32_t* flag, float rmax) {
+  if (!flag) return;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+  if ((threadIdx.x & 63) == 0 && !(rmax < 32768.f)) atomicMax(flag, __float_as_uint(rmax));
+}
 __device__ __forceinline__ unsigned vx_magic_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
 // WIDE (pooling with more than 128 channels): the x-neighbour's piece would sit in another wave, so a thread takes
 // BOTH voxels of an x-pair (a row then has W/2 * C/4 work items) and no shuffle is needed.
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
   const int PW = (WIDE ? a.W / 2 : a.W) * C4;  // work items per row
   const int n = blockIdx.y;
   const int RH = POOL ? a.H / 2 : a.H;   // rows (row bundles) per z
+  float rmax = 0.f;   // largest |value| stored: range guard of the split-fp16 consumers when nothing normalises (a.range_flag)
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < dc.per_sample; i += gridDim.x * 256u) {
     const unsigned row = vx_magic_div(i, dc.mPW);       // i / PW
     const int p = (int)(i - row * (unsigned)PW);
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * t[j] : 0.f;
       }
+      if (a.range_flag) rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
       if (!a.out) {
         // pooled tensor only
       } else if (a.out_xblk) {
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
       }
     }
   }
+  vx_range_report(a.range_flag, rmax);
 }
 
 // Fan-out variant (MC-dropout first layer: x_repeat = T samples share one source volume, no pooling): one thread
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args 
   const int ns = blockIdx.y;
   const size_t out_sample = (size_t)a.D * a.H * a.W * (a.out_xblk ? 2 * a.C : a.out_pitch);
   const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;
+  float rmax = 0.f;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < dc.per_sample; i += gridDim.x * 256u) {
     const unsigned row = vx_magic_div(i, dc.mPW);
     const int p = (int)(i - row * (unsigned)PW);
@@ -182,6 +193,8 @@ __global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args 
 #pragma unroll
       for (int j = 0; j < 4; ++j) t0[j] = fmaxf(t0[j], 0.f);
     }
+    // (the dropout's factor 2 included: what the T samples store is at most twice this)
+    if (a.range_flag) rmax = fmaxf(fmaxf(rmax, 2.f * fmaxf(fabsf(t0[0]), fabsf(t0[1]))), 2.f * fmaxf(fabsf(t0[2]), fabsf(t0[3])));
     const uint32_t e = (uint32_t)(((z * a.H + y) * a.W + x) * a.C + c);
     size_t off;   // float offset of the piece within a sample's output
     if (a.out_xblk)
@@ -203,6 +216,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args 
       *reinterpret_cast<f32x4*>(a.out + (size_t)n * out_sample + off) = t;
     }
   }
+  vx_range_report(a.range_flag, rmax);
 }
 
 extern "C" int vx_norm_act_drop_pool(const vx_norm_args* ap, vx_stream_t stream) {

@@ -191,6 +191,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.out_xblk = out_xblk; a.out_half = 1;
     a.x_xblk = x_xblk; a.x_half = 1;
     a.seed_dev = r->seed_dev;
+    a.range_flag = normalise ? nullptr : r->range_flag;   // an un-normalised tensor on its way to a split-fp16 conv
     a.x = x; a.x_pitch = C;
     a.mean = normalise ? (mean ? mean : p.mean) : nullptr;
     a.rstd = normalise ? (rstd ? rstd : p.rstd) : nullptr;

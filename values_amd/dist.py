@@ -206,13 +206,16 @@ def passes_per_member(model, n_pred: int = 1, tta: bool = False, n_aleatoric_sam
 
 def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int, n_pred: int = 1, dst: int = 0,
                                  seeds=None, group=None, tta: bool = False, x_noise=None,
-                                 n_aleatoric_samples: int = 10) -> Optional[Dict[str, torch.Tensor]]:
+                                 n_aleatoric_samples: int = 10, range_check: str = "fallback") -> Optional[Dict[str, torch.Tensor]]:
     """models: the FULL member list (every rank holds all checkpoints; only its items run).  x: (V,1,D,H,W), the
     same on every rank.  Returns the maps on `dst` (None elsewhere).  The number of passes of a member is taken from the
     logits it produced (and checked against passes_per_member); the total every rank finalises with is the sum over
-    ALL members, whichever rank ran them."""
+    ALL members, whichever rank ran them.
+    range_check: the fp16 range guard (values_amd.predict.guarded) around THIS rank's items, BEFORE the collective: a rank
+    whose forwards overflowed recomputes its own statistics on the native-fp32 kernels and then joins the one sum-reduce --
+    the ranks never disagree about which collective comes next."""
     from . import _lib
-    from .predict import predict_logits
+    from .predict import guarded, pin_seeds, predict_logits
     lib = _lib.load()
     dev = x.device
     V = x.shape[0]
@@ -223,18 +226,25 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
         nvox *= s_
     per_member = [passes_per_member(m, n_pred, tta, n_aleatoric_samples) for m in models]
     stats = torch.zeros((V, Cc + 1) + spatial, dtype=torch.float32, device=dev)
-    for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
-        kw = {"seeds": [seeds[m]]} if seeds is not None else {}
-        if tta:
-            kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
-        logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,
-                                **kw).contiguous()  # (hi-lo, T_m, C, ...)
-        T_m = int(logits.shape[1])
-        if T_m != per_member[m] or tuple(logits.shape[:3]) != (hi - lo, T_m, Cc):
-            raise _lib.VxError(f"ensemble_uncertainty_sharded: member {m} produced logits {tuple(logits.shape)}, "
-                               f"expected {per_member[m]} passes of {Cc} classes")
-        _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(logits), hi - lo, T_m, Cc, nvox, _lib.ptr(stats[lo:hi]),
-                                               _lib.stream_ptr()), "vx_unc_stats_accumulate")
+    if seeds is None and range_check != "off":
+        seeds = pin_seeds(models, {}).get("seeds")      # a second run of this rank's items replays the same dropout bits
+
+    def my_items():
+        stats.zero_()
+        for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
+            kw = {"seeds": [seeds[m]]} if seeds is not None else {}
+            if tta:
+                kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
+            logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,
+                                    **kw).contiguous()  # (hi-lo, T_m, C, ...)
+            T_m = int(logits.shape[1])
+            if T_m != per_member[m] or tuple(logits.shape[:3]) != (hi - lo, T_m, Cc):
+                raise _lib.VxError(f"ensemble_uncertainty_sharded: member {m} produced logits {tuple(logits.shape)}, "
+                                   f"expected {per_member[m]} passes of {Cc} classes")
+            _lib.check(lib.vx_unc_stats_accumulate(_lib.ptr(logits), hi - lo, T_m, Cc, nvox, _lib.ptr(stats[lo:hi]),
+                                                   _lib.stream_ptr()), "vx_unc_stats_accumulate")
+
+    guarded(models, my_items, range_check, "ensemble_uncertainty_sharded")
     if world > 1:
         import torch.distributed as dist
         dist.reduce(stats, dst=dst, op=dist.ReduceOp.SUM, group=group)

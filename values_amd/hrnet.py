@@ -257,9 +257,21 @@ class HighResolutionNet(nn.Module):
         # activation tensor has round16(C) channels whose tail is exactly 0 (zero weight rows, zero BN scale/shift)
         self._last_parts = list(pre)
         self._packed, self._packed_key = None, None
-        self._zcache = {}      # persistent zero-padded buffers (see _conv)
+        self._zcache = {}      # persistent zero-padded buffers (see _conv): (layer, device, stream) -> (geometry, tensor)
+        self._zreal = {}       # layer -> real channel count of its padded output (zero_tails_intact)
         self._groups = 1       # statistics groups of the forward in flight (forward_samples)
         self.seed, self._calls = 123, 0
+
+    def zero_tails_intact(self) -> bool:
+        """Debug check of the invariant the persistent zero-padded buffers rely on: no kernel ever wrote channels at or
+        beyond the real channel count of a padded tensor (reads them back: synchronises)."""
+        for key, (geo, t) in self._zcache.items():
+            if key[0] == "bn":
+                continue
+            real = self._zreal.get(key[0])
+            if real is not None and real < t.shape[-1] and bool((t[..., real:] != 0).any().item()):
+                return False
+        return True
 
     @staticmethod
     def _make_transition(pre, cur):
@@ -330,10 +342,15 @@ class HighResolutionNet(nn.Module):
             # the conv writes channels [0, round4(cout)) only, so the zero tail survives from forward to forward: one
             # buffer per layer and geometry, zero-filled once (a fill kernel per conv launch was the top entry of the
             # W18 profile)
-            key = (name, n, oh, ow, pitch, str(x.t.device), torch.cuda.current_stream().cuda_stream)
-            out = self._zcache.get(key)
-            if out is None:
-                out = self._zcache[key] = torch.zeros((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
+            # ONE geometry per (layer, stream): another batch size / image size replaces the entry instead of piling a
+            # second set of activation-sized buffers on top (a captured graph keeps its own references, _hold_last)
+            key = (name, str(x.t.device), torch.cuda.current_stream().cuda_stream)
+            geo = (n, oh, ow, pitch)
+            hit = self._zcache.get(key)
+            if hit is None or hit[0] != geo:
+                hit = self._zcache[key] = (geo, torch.zeros(geo, dtype=torch.float32, device=x.t.device))
+            self._zreal[name] = cout
+            out = hit[1]
         else:
             out = torch.empty((n, oh, ow, pitch), dtype=torch.float32, device=x.t.device)
         part = None
@@ -368,10 +385,12 @@ class HighResolutionNet(nn.Module):
         creal = raw.real_c
         G = self._groups
         if creal != raw.C:      # padded channels: scale = shift = 0 there, written once (the finalize kernel fills [0, creal))
-            key = ("bn", bn_name, G, raw.C, str(raw.t.device), torch.cuda.current_stream().cuda_stream)
-            ss = self._zcache.get(key)
-            if ss is None:
-                ss = self._zcache[key] = torch.zeros((2, G, raw.C), dtype=torch.float32, device=raw.t.device)
+            key = ("bn", bn_name, str(raw.t.device), torch.cuda.current_stream().cuda_stream)
+            geo = (2, G, raw.C)
+            hit = self._zcache.get(key)
+            if hit is None or hit[0] != geo:
+                hit = self._zcache[key] = (geo, torch.zeros(geo, dtype=torch.float32, device=raw.t.device))
+            ss = hit[1]
         else:
             ss = torch.empty((2, G, raw.C), dtype=torch.float32, device=raw.t.device)
         scale, shift = ss[0], ss[1]
@@ -419,8 +438,12 @@ class HighResolutionNet(nn.Module):
         return t
 
     def _streams(self, n):
-        if not hasattr(self, "_side") or len(self._side) < n:
-            self._side = [torch.cuda.Stream() for _ in range(n)]
+        # the pool only ever GROWS: stage 2's two streams are the first two of stage 4's four, so a layer sees the same
+        # stream in every forward (its persistent zero-padded buffer is keyed on it)
+        if not hasattr(self, "_side"):
+            self._side = []
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream())
         return self._side
 
     # ------------------------------------------------------------------ network walk

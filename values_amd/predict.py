@@ -58,6 +58,53 @@ def predict_logits_ssn(model, x: torch.Tensor, n_pred: int = 1, eps_w=None, eps_
     return dist.sample_volumes(n_pred, eps_w=eps_w, eps_d=eps_d, seed=seed)
 
 
+def range_watch_begin(models) -> None:
+    """Zero the fp16-range words of `models` in stream order -- no read, no synchronisation."""
+    for mdl in models:
+        if hasattr(mdl, "range_reset"):
+            mdl.range_reset()
+
+
+def range_watch_overflowed(models) -> float:
+    """The largest magnitude an un-normalised layer of `models` handed to a split-fp16 convolution since
+    range_watch_begin (reading synchronises the current stream), or 0.0 when everything stayed below the limit / the
+    native-fp32 kernels ran.  A value >= 65504 (or NaN) means the logits computed meanwhile are invalid."""
+    if _lib.get_config().conv_fp32 != 0:
+        return 0.0
+    worst = max([mdl.range_max(reset=True) for mdl in models if hasattr(mdl, "range_max")] or [0.0])
+    return worst if not worst < 65504.0 else 0.0
+
+
+def guarded(models, run, mode: str = "fallback", what: str = "values_amd"):
+    """THE fp16 range guard, shared by every driver that launches forwards (predict_uncertainty,
+    predict_image_sliding, ensemble_uncertainty_sharded, GraphedPredictor): run() under a zeroed range word; if a
+    magnitude >= 65504 reached a split-fp16 convolution, either raise (mode "raise") or compute again on the native-fp32
+    matrix kernels (mode "fallback": run() once more under vx_config.conv_fp32 = 1 -- the caller pins its dropout seeds so
+    that the second run draws the same bits).  mode "off": just run() (pipelined callers read the word themselves)."""
+    if mode not in ("fallback", "raise", "off"):
+        raise ValueError("range_check must be 'fallback', 'raise' or 'off'")
+    if mode == "off":
+        return run()
+    range_watch_begin(models)
+    out = run()
+    worst = range_watch_overflowed(models)
+    if worst:
+        if mode == "raise":
+            raise _lib.VxError(f"{what}: an activation of magnitude {worst:.4g} reached a split-fp16 convolution "
+                               "(limit 65504); re-run under values_amd._lib.config(conv_fp32=1)")
+        with _lib.config(conv_fp32=1):     # native-fp32 matrix kernels: no range limit; each family keeps its own packed weights
+            out = run()
+    return out
+
+
+def pin_seeds(models, kw: dict) -> dict:
+    """kw with explicit hash-dropout seeds: an un-seeded call draws them from the models' counters HERE, once, so that a
+    second run of the same batch (the range fallback) replays the same dropout bits."""
+    if kw.get("seeds") is None and kw.get("dropout_masks") is None and all(hasattr(m, "next_seed") for m in models):
+        kw = dict(kw, seeds=[m.next_seed() for m in models])
+    return kw
+
+
 _side_streams: Dict[int, list] = {}
 _index_cache: Dict[tuple, tuple] = {}
 
@@ -189,16 +236,18 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
     softmax_variance (V,D,H,W) f32 -- the north star's fourth map, from the same pass over the logits (no reference
     counterpart).
     range_check: the split-fp16 convolutions represent activations below 65504; every kernel that feeds them an
-    un-normalised tensor records the largest magnitude it stored (UNet3D.range_max).  "fallback" (default): read that
-    word after the batch (one synchronisation) and, if the limit was reached, compute the batch again on the native-fp32
-    kernels -- NaN maps never leave this function; "raise": VxError instead; "off": no read (pipelined callers check
-    model.check_range() themselves, the word keeps the running maximum)."""
+    un-normalised tensor records the largest magnitude it stored (UNet3D.range_max).  "fallback" (default): the word is
+    zeroed in stream order at entry (no read), read once after the batch (the ONE synchronisation of this call) and, if
+    the limit was reached, the batch is computed again on the native-fp32 kernels with the same dropout seeds -- NaN maps
+    never leave this function; "raise": VxError instead; "off": no read and no reset (pipelined callers -- HostPipeline,
+    bench.py -- read the word where they have waited anyway; it keeps the running maximum)."""
     if range_check not in ("fallback", "raise", "off"):
         raise ValueError("range_check must be 'fallback', 'raise' or 'off'")
     if range_check != "off":
-        for mdl in models:
-            if hasattr(mdl, "range_max"):
-                mdl.range_max(reset=True)
+        kw = pin_seeds(models, kw)
+        return guarded(models, lambda: predict_uncertainty(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, ssn=ssn,
+                                                           want_sample_argmax=want_sample_argmax, range_check="off", **kw),
+                       range_check, "predict_uncertainty")
     m = None
     one_batch = (hasattr(models[0], "rank") and hasattr(models[0], "cov_factor_conv")) or \
         (bool(getattr(models[0], "aleatoric_loss", False)) and not tta)      # SSN / aleatoric head: no volume chunks
@@ -228,15 +277,6 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
         out["epistemic_uncertainty"] = m["expected_entropy"]
     if want_sample_argmax:
         out["pred_seg"] = m["sample_argmax"]
-    if range_check != "off" and _lib.get_config().conv_fp32 == 0:
-        worst = max([mdl.range_max(reset=True) for mdl in models if hasattr(mdl, "range_max")] or [0.0])
-        if not worst < 65504.0:
-            if range_check == "raise":
-                raise _lib.VxError(f"predict_uncertainty: an activation of magnitude {worst:.4g} reached a split-fp16 "
-                                   "convolution (limit 65504)")
-            with _lib.config(conv_fp32=1):     # the native-fp32 matrix kernels: no range limit (weights re-pack per family)
-                return predict_uncertainty(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, ssn=ssn,
-                                           want_sample_argmax=want_sample_argmax, range_check="off", **kw)
     return out
 
 
@@ -245,8 +285,10 @@ class GraphedPredictor:
     reduction replay with one host call (single-volume latency: the eager path is bound by launch overhead there).
     `gp(x, seed=s)` copies x into the graph's input, sets the device seed word every dropout kernel adds to its seed
     (a graph replays with the arguments it was captured with), replays, and returns the graph's OUTPUT tensors -- valid
-    until the next call.  MC-dropout / deterministic UNet3D members with hash or no dropout; the fp16 range word is not
-    read here (model.check_range())."""
+    until the next call.  MC-dropout / deterministic UNet3D members with hash or no dropout.  The fp16 range word is
+    part of the captured work (every replay raises it if a split-fp16 conv saw >= 65504); `gp(x, check=True)` zeroes it
+    before the replay, reads it after (one synchronisation) and, on overflow, returns the eager result of the native-fp32
+    kernels instead -- without the flag the caller checks `gp.check_range()` where it synchronises anyway."""
 
     def __init__(self, models: Sequence, shape, n_pred: int = 1, device=None, **predict_kw):
         _lib.require_gpu()
@@ -256,6 +298,7 @@ class GraphedPredictor:
         self.seed_word = torch.zeros(1, dtype=torch.int32, device=self.dev)
         kw = dict(predict_kw, range_check="off", n_streams=1, seeds=[1000003 * (i + 1) for i in range(len(self.models))],
                   seed_dev=self.seed_word)
+        self._kw = dict(kw)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):          # warm-up on the capture stream: weights packed, workspaces and index tensors exist
@@ -268,13 +311,27 @@ class GraphedPredictor:
             self.out = predict_uncertainty(self.models, self.x, n_pred=n_pred, **kw)
         self._calls = 0
 
-    def __call__(self, x: torch.Tensor, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    def __call__(self, x: torch.Tensor, seed: Optional[int] = None, check: bool = False) -> Dict[str, torch.Tensor]:
         self.x.copy_(x, non_blocking=True)
         self._calls += 1
         s = (self._calls if seed is None else int(seed)) & 0x7FFFFFFF
         self.seed_word.fill_(s)
+        if check:
+            range_watch_begin(self.models)
         self.graph.replay()
+        if check and range_watch_overflowed(self.models):
+            # the graph holds the split-fp16 family's weight pointers (kept alive per family by the models); the fallback
+            # runs eagerly on the native-fp32 family with the seeds the replay used
+            with _lib.config(conv_fp32=1):
+                return predict_uncertainty(self.models, self.x, n_pred=self.n_pred,
+                                           **dict(self._kw, seed_dev=self.seed_word))
         return self.out
+
+    def check_range(self):
+        """raise VxError if any replay since the last check overflowed the fp16 range (synchronises)"""
+        for mdl in self.models:
+            if hasattr(mdl, "check_range"):
+                mdl.check_range()
 
 
 class HostPipeline:
@@ -290,14 +347,22 @@ class HostPipeline:
     upload, the next step's kernels -- starts only after that download, so every step pays it (measured: 17.6 ms per
     32-volume step instead of 13.5, or not, depending on the order the process happened to create its streams in).
     Here step i's download is enqueued in submit(i + 2), after the HOST has seen step i's completion event; step
-    i + 1 is queued on the GPU meanwhile, so the device never idles (tools/exp_hostpipe.py, exp_hostpipe2.py)."""
+    i + 1 is queued on the GPU meanwhile, so the device never idles (tools/exp_hostpipe.py, exp_hostpipe2.py).
+
+    fp16 range guard without a stall: every step runs with range_check="off" (no read on the submit path); a device copy
+    of the range word is taken right behind the step's kernels (the word is zeroed in stream order in front of them), and
+    travels to the host WITH the step's maps; _collect() -- where the host has waited for that download anyway -- looks at
+    it and, if the step overflowed, computes that step again on the native-fp32 kernels (same seeds) before handing its
+    maps out (range_check="raise": VxError there instead)."""
 
     KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "softmax_variance", "mean_softmax",
             "pred_seg_mean")
 
-    def __init__(self, models: Sequence, device=None, **predict_kw):
+    def __init__(self, models: Sequence, device=None, range_check: str = "fallback", **predict_kw):
         _lib.require_gpu()
-        self.models, self.kw = list(models), predict_kw
+        if range_check not in ("fallback", "raise", "off"):
+            raise ValueError("range_check must be 'fallback', 'raise' or 'off'")
+        self.models, self.kw, self.range_check = list(models), predict_kw, range_check
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._up = torch.cuda.Stream(device=self.dev)
         self._down = torch.cuda.Stream(device=self.dev)
@@ -307,25 +372,41 @@ class HostPipeline:
         self._next = 0
 
     def _start_download(self):
-        maps, xd, done = self._computing.pop(0)
+        maps, xd, done, rng, kw = self._computing.pop(0)
         done.synchronize()           # host-side: the step has finished, its download will not wait in any queue
         slot = self._next
         self._next = (self._next + 1) % len(self._slots)
         bufs = self._slots[slot]
         if bufs is None or any(tuple(bufs[k].shape) != tuple(maps[k].shape) for k in self.KEYS):
             bufs = {k: torch.empty(maps[k].shape, dtype=maps[k].dtype).pin_memory() for k in self.KEYS}
+            bufs["_range"] = torch.zeros(max(1, len(self.models)), dtype=torch.int32).pin_memory()
             self._slots[slot] = bufs
         with torch.cuda.stream(self._down):
             for k in self.KEYS:
                 bufs[k].copy_(maps[k], non_blocking=True)
+            if rng is not None:
+                bufs["_range"][:rng.numel()].copy_(rng, non_blocking=True)
+            else:
+                bufs["_range"].zero_()
         ev = torch.cuda.Event()
         ev.record(self._down)
-        self._copying.append((slot, ev, (maps, xd)))   # the device tensors stay referenced until the copies are done
+        self._copying.append((slot, ev, (maps, xd, kw)))   # the device tensors stay referenced until the copies are done
 
     def _collect(self):
-        slot, ev, _keep = self._copying.pop(0)
+        slot, ev, keep = self._copying.pop(0)
         ev.synchronize()
-        return {k: v.numpy() for k, v in self._slots[slot].items()}
+        bufs = self._slots[slot]
+        if self.range_check != "off" and _lib.get_config().conv_fp32 == 0:
+            worst = float(bufs["_range"].view(torch.float32).max().item())      # a pinned HOST tensor: no device work
+            if not worst < 65504.0:
+                if self.range_check == "raise":
+                    raise _lib.VxError(f"HostPipeline: an activation of magnitude {worst:.4g} reached a split-fp16 "
+                                       "convolution in this step (limit 65504)")
+                _maps, xd, kw = keep
+                with _lib.config(conv_fp32=1):     # rare: this step again on the native-fp32 kernels, synchronously
+                    out = predict_uncertainty(self.models, xd, **{**self.kw, **kw, "range_check": "off"})
+                return {k: out[k].cpu().numpy() for k in self.KEYS}
+        return {k: bufs[k].numpy() for k in self.KEYS}
 
     def submit(self, x_host: torch.Tensor, **kw):
         done = self._collect() if self._copying else None       # the download started one submit ago
@@ -336,10 +417,19 @@ class HostPipeline:
         if len(self._computing) == 2:
             self._start_download()                               # of the step submitted two calls ago
         main.wait_stream(self._up)
-        out = predict_uncertainty(self.models, xd, **{**self.kw, **kw})
+        rng = None
+        kw = pin_seeds(self.models, {**self.kw, **kw})
+        kw.pop("range_check", None)
+        if self.range_check != "off":
+            range_watch_begin(self.models)                       # zeroed in stream order, not read
+        out = predict_uncertainty(self.models, xd, range_check="off", **kw)
+        if self.range_check != "off":
+            flags = [f for m in self.models for d, f in getattr(m, "_range", {}).items() if d == str(self.dev)]
+            if flags:
+                rng = torch.cat(flags)                           # this step's word(s), copied on the device behind its kernels
         ev = torch.cuda.Event()
         ev.record(main)
-        self._computing.append(({k: out[k] for k in self.KEYS}, xd, ev))
+        self._computing.append(({k: out[k] for k in self.KEYS}, xd, ev, rng, kw))
         return done
 
     def flush(self):

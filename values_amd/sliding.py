@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from .predict import crop_indices, predict_logits
+from .predict import crop_indices, guarded, pin_seeds, predict_logits
 from .uncertainty import uncertainty_maps
 
 
@@ -21,15 +21,27 @@ from .uncertainty import uncertainty_maps
 def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int = 64, patch_overlap: float = 1,
                           n_pred: int = 1, tta: bool = False, patch_batch: int = 8, compat: bool = True,
                           seeds=None, noise_fn=None, n_aleatoric_samples: int = 10, ssn: bool = False,
-                          **predict_kw) -> Dict[str, torch.Tensor]:
+                          range_check: str = "fallback", **predict_kw) -> Dict[str, torch.Tensor]:
     """image: (X, Y, Z) float tensor (the preprocessed .npy of load_image).  Returns device tensors:
     softmax_sum (T, C, X,Y,Z), num_predictions (X,Y,Z), pred_entropy / aleatoric_uncertainty / epistemic_uncertainty
     (X,Y,Z) -- already divided by clip(count,1) like save_data --, mean_softmax (C, X,Y,Z), pred_seg_mean (X,Y,Z) u8.
     The number of passes T is whatever predict_logits produced for the model kind (n_pred, 16 TTA views, or
     n_aleatoric_samples for an aleatoric head: test_3D.py:458-469 sets n_pred := n_aleatoric_samples there), times the
     number of members.  ssn=True swaps the aleatoric / epistemic maps like calculate_uncertainty(ssn=True)
-    (test_3D.py:510-516)."""
+    (test_3D.py:510-516).
+    range_check: the fp16 range guard of values_amd.predict.guarded over the WHOLE image -- the range word is zeroed before
+    the first patch batch (no read), read once after the last accumulate, and on overflow the image is computed again on
+    the native-fp32 kernels with the same seeds ("raise": VxError; "off": the caller checks model.check_range())."""
     _lib.require_gpu()
+    if range_check != "off":
+        if seeds is None:
+            seeds = pin_seeds(models, {}).get("seeds")
+        return guarded(models, lambda: predict_image_sliding(models, image, patch_size=patch_size, patch_overlap=patch_overlap,
+                                                             n_pred=n_pred, tta=tta, patch_batch=patch_batch, compat=compat,
+                                                             seeds=seeds, noise_fn=noise_fn,
+                                                             n_aleatoric_samples=n_aleatoric_samples, ssn=ssn,
+                                                             range_check="off", **predict_kw),
+                       range_check, "predict_image_sliding")
     lib = _lib.load()
     dev = image.device if image.is_cuda else torch.device("cuda", torch.cuda.current_device())
     img = image.to(dev, torch.float32).contiguous()

@@ -84,6 +84,7 @@ class UNet3D(nn.Module):
         self.output_reconstruction_map = nn.Conv3d(f, out_channels=1, kernel_size=1)
         self._packed = None
         self._packed_key = None
+        self._packed_by_mode = {}   # (pack_mode(), device) -> (parameter key, (vx_unet3d_weights, tensors it points into))
         self._range = {}      # device -> int32 word: running maximum |activation| handed to a split-fp16 conv (bit pattern)
         self._ws = {}
         self._calls = 0
@@ -94,8 +95,15 @@ class UNet3D(nn.Module):
         return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in self.parameters()) + (_lib.pack_mode(),)
 
     def _ensure_packed(self, device):
+        """Packed weights of the CURRENT kernel family (vx_config's pack_mode()).  One entry per family stays alive: a
+        switch of the family (the fp16-range fallback runs a batch under conv_fp32 = 1) must not free the tensors of the
+        other one -- a captured hipGraph (GraphedPredictor) replays with the pointers it was captured with.  An entry is
+        replaced only when the parameters themselves changed."""
         key = self._param_key()
-        if self._packed is not None and self._packed_key == key:
+        mode = (key[-1], str(device))
+        hit = self._packed_by_mode.get(mode)
+        if hit is not None and hit[0] == key:
+            self._packed, self._packed_key = hit[1], key
             return self._packed
         lib = _lib.load()
         sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in self.state_dict().items()}
@@ -144,6 +152,7 @@ class UNet3D(nn.Module):
         w.no_instancenorm = 0 if self.do_instancenorm else 1
         self._packed = (w, keep)
         self._packed_key = key
+        self._packed_by_mode[mode] = (key, self._packed)
         return self._packed
 
     def _head_params(self, sd):
@@ -180,6 +189,18 @@ class UNet3D(nn.Module):
             if reset:
                 flag.zero_()
         return worst
+
+    def range_reset(self):
+        """zero the range word(s) in stream order, WITHOUT reading (no synchronisation: pipelined callers)"""
+        for flag in self._range.values():
+            flag.zero_()
+
+    def next_seed(self) -> int:
+        """the hash-dropout seed the next un-seeded forward would draw; drawing it here pins it (a re-run of the same
+        batch -- the fp16-range fallback -- then replays the same dropout bits)"""
+        seed = (self.seed * 1000003 + self._calls) & 0xFFFFFFFF
+        self._calls += 1
+        return seed
 
     def check_range(self, reset: bool = True):
         m = self.range_max(reset=reset)
@@ -265,8 +286,7 @@ class UNet3D(nn.Module):
         elif self.training and self.dropout_prob > 0:
             run.drop_mode = _lib.VX_DROP_HASH
             if seed is None:
-                seed = (self.seed * 1000003 + self._calls) & 0xFFFFFFFF
-                self._calls += 1
+                seed = self.next_seed()
             run.seed = int(seed) & 0xFFFFFFFF
             if seed_dev is not None:   # a device word added to the seed by every kernel (hipGraph replays, GraphedPredictor)
                 if seed_dev.dtype != torch.int32 or not seed_dev.is_cuda:

@@ -18,6 +18,8 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
     f = list(map(int, spec.split(":")))
     cin, cout, edge, act, drop, head = f[:6]
     up = f[6] if len(f) > 6 else 0
+    pre = f[7] if len(f) > 7 else 0        # 1: normalise-on-load prologue (hash dropout of the producing block), in_repeat = 10 for Cin = 8
+    pool = f[8] if len(f) > 8 else 0       # 1: pooled output (contr_1_2's epilogue)
     x = torch.randn((N, edge, edge, edge, 8 if up else cin), device=dev)
     w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05; b = torch.zeros(cout, device=dev)
     wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
@@ -36,7 +38,18 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
         _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(uw), _lib.ptr(uwp), 16, 8, _lib.stream_ptr()), "packT")
         a.up_in, a.up_w, a.up_b, a.up_pitch = coarse.data_ptr(), uwp.data_ptr(), ub.data_ptr(), 16
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout
+    if pre:
+        rep = 10 if (cin == 8 and N % 10 == 0) else 1
+        if rep > 1:
+            x = torch.randn((N // rep, edge, edge, edge, cin), device=dev); a.in_ = x.data_ptr()
+        mean = torch.zeros((N // rep, 8), device=dev); rstd = torch.ones((N // rep, 8), device=dev)
+        a.in_mean, a.in_rstd, a.in_drop_mode, a.in_drop_seed, a.in_drop_layer, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1, 7, 1, rep
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, 1, 2
+    if pool:
+        praw = torch.empty((N, edge // 2, edge // 2, edge // 2, 8), device=dev)
+        pfl = torch.empty((N, edge // 2, edge // 2, edge // 2, 2), dtype=torch.int32, device=dev)
+        a.pool_out, a.pool_flags = praw.data_ptr(), pfl.data_ptr()
+        a.drop_mode, a.drop_seed, a.drop_layer = 1, 1, 1
     st = None
     if not act:
         st = torch.zeros((N, lib.vx_conv3d_k3_tiles(edge, edge, edge), cout, 2), device=dev)

@@ -55,7 +55,7 @@ struct Xp8wArgs {
 template <int NCH, int EPI, int PRE, int UP, int NPW>
 __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka) {
   static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
-  constexpr int NW = 8, NTH = (NW + NPW) * 64, PT = NPW * 64;
+  constexpr int NW = 8, NTH = (NW + NPW) * 64;
   constexpr int TZ = 4 / NCH;
   constexpr int R = TZ;                       // column tiles (y-rows of one z-plane) per consumer wave
   constexpr int WPZ = 8 / R;                  // consumer waves per z-plane
@@ -66,12 +66,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
   constexpr int PREC_H = 2 * PP * 8;          // halves of one precision plane (both parities)
   constexpr int CHUNK_H = 2 * PREC_H;
   constexpr int W_H = 9 * 2 * 32 * 8;         // halves of one chunk's weights ([step 9][hi|lo][32 pieces][8])
-  constexpr int PPS = TZ * HX * HY * 2;       // 16-byte pieces per step and chunk
-  constexpr int IT_C = (PPS + PT - 1) / PT;
-  constexpr int IN_IT = NCH * IT_C;
   constexpr int GRP_H = TZ * ZP * 8;          // halves between two slot groups
   constexpr bool STATS = EPI == 0 || EPI == 4;
-  static_assert(IN_IT <= 16, "staging iterations");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16* s_img = reinterpret_cast<_Float16*>(smem_raw);
@@ -119,47 +115,106 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
   // S_{j+2}, the consumers compute the item that S_j completes (step s >= 1 of a column completes item s - 1)
   if (wave >= NW) {
     // =============================================== PRODUCER ===============================================
+    // Round 3: the staging works on whole ROWS.  The stamps of the round-2 kernel (tools/stamp_s16.py) showed the
+    // producers, not the consumers, on the critical path of the two largest layers (7 000 of 10 000 cycles per item in
+    // `convert`, the consumers parked 40 % at the barrier): ~65 vector instructions per 16-byte piece -- a hash per lane,
+    // LDS / element offsets recomputed from (plane, row, x) in every iteration, three instructions per dropout select.
+    // A wave-iteration now is one row of the step: its 32 interior voxels x 2 channel quads are exactly 64 pieces, so
+    //   * the global row offset, the LDS row offset and the row's validity (outside the volume in y / z) are SCALARS
+    //     (soffset / an immediate / a branch), the per-lane part of every address is a constant of the lane;
+    //   * ONE hash round per step serves eight rows: lane (i, j) computes keep-word j of row i, the row's lanes fetch
+    //     theirs with ds_bpermute (1 + 1 instructions per piece instead of 13);
+    //   * dropout = the keep bit ANDed into the piece's SCALE (2 instructions per element);
+    //   * rows outside the volume issue no load and commit zeros without touching the vector ALU.
+    // The 2 halo voxels per row (x = -1, x = 32) are gathered into one or two extra iterations of the old per-lane form.
     if (ka.prio == 1) __builtin_amdgcn_s_setprio(2);
-    const int ptid = tid - NW * 64;
     const int pw = wave - NW;
-    // ---- staging pattern of this thread (fixed for the kernel's life) ----
+    constexpr int NCS = UP ? 1 : NCH;             // chunks staged from memory (UP: chunk 0 is computed)
+    constexpr int RU = TZ * HY;                   // rows of a step, per chunk
+    constexpr int NU = NCS * RU;                  // row units of a step; unit u = pw + NPW * i belongs to this wave
+    constexpr int RPW = (NU + NPW - 1) / NPW;
+    constexpr int HR = (RPW + 7) / 8;             // hash rounds per step (eight rows each)
+    constexpr int NH = NU * 4;                    // halo pieces of a step: per row 2 sides x 2 channel quads
+    constexpr int HIT = (NH + 63) / 64;           // halo iterations, one each for waves NPW - 1, NPW - 2, ...
+    static_assert(HIT <= NPW && RPW <= 16, "producer row units");
     const int xb = a.in_xblk;
-    const int voxf = xb ? 16 : a.in_pitch;             // floats per voxel step along x (concat: two halves of 8)
+    const int voxf = xb ? 16 : a.in_pitch;              // floats per voxel step along x (concat: two halves of 8)
     const int rowf = a.W * voxf;
     const int biasf = ((TZ - 1) * a.H + 1) * rowf + 4 * voxf;
-    unsigned voff[IN_IT], erel[PRE ? IN_IT : 1];
-    int ldst[IN_IT];
-    unsigned ib_always = 0, ib_xlo = 0, ib_xhi = 0, ib_ylo = 0, ib_yhi = 0, ib_zfirst = 0, ib_zlast = 0;
-    int qq_thread = 0;
-#pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-      const int chunk = NCH == 2 ? (it & 1) : 0;
-      const int pidx = ptid + (NCH == 2 ? (it >> 1) : it) * PT;
-      const int vox = pidx >> 1, qq = pidx & 1;
-      qq_thread = qq;                                   // PT is even: the same channel quad in every iteration
-      const int pz = vox / (HX * HY), rem = vox % (HX * HY);
-      // within a row the even x come first, then the odd ones: 16 consecutive lanes (8 voxels x 2 quads) then write 128
-      // contiguous bytes of ONE parity plane (the two planes sit a multiple of 128 B apart: natural order = 2-way conflicts)
-      const int hy = rem / HX, hr = rem % HX;
-      const int hx = hr < HXP ? 2 * hr : 2 * (hr - HXP) + 1;
-      const int dx = hx - 1, dy = hy - 1, dz = pz - (TZ - 1);
-      int xf;
+    const int qq = lane & 1;                            // channel quad of this lane (interior and halo pieces alike)
+    auto xpart = [&](int dx, int lch) {                 // float offset of (voxel dx, quad qq) of chunk lch within its row
       if (xb) {
         const int blk = dx >= 0 ? dx / xb : -((-dx + xb - 1) / xb);
-        xf = (blk * 2 + chunk) * xb * 8 + (dx - blk * xb) * 8 + qq * 4;
-      } else {
-        xf = dx * a.in_pitch + (UP ? 0 : chunk * 8) + qq * 4;   // UP: `in` is the skip tensor alone
+        return (blk * 2 + lch) * xb * 8 + (dx - blk * xb) * 8 + qq * 4;
       }
-      voff[it] = (unsigned)(((dz * a.H + dy) * rowf + xf + biasf) * 4);
-      ldst[it] = chunk * CHUNK_H + (hx & 1) * PP * 8 + ((pz * HY + hy) * HXP + (hx >> 1)) * 8 + qq * 4;
-      if constexpr (PRE != 0) erel[it] = (unsigned)(((dz * a.H + dy) * a.W + dx) * 8 + qq * 4);
-      if (pidx >= PPS) ib_always |= 1u << it;
-      if (dx < 0) ib_xlo |= 1u << it;
-      if (dx >= 32) ib_xhi |= 1u << it;
-      if (dy < 0) ib_ylo |= 1u << it;
-      if (dy >= 8) ib_yhi |= 1u << it;
-      if (pz < TZ - 1) ib_zfirst |= 1u << it;           // step 0 of a column: planes -(TZ-1) .. -1 do not exist
-      if (pz >= TZ - 1) ib_zlast |= 1u << it;           // step KZ: plane D does not exist
+      return dx * a.in_pitch + (UP ? 0 : lch * 8) + qq * 4;   // UP: `in` is the skip tensor alone
+    };
+    // ---- interior pieces: lane = (x parity half, voxel pair, quad); within a row the even hx come first (lanes 0..31),
+    // then the odd ones: 16 consecutive lanes write 128 contiguous bytes of ONE parity plane (natural order: 2-way conflicts)
+    const int l_hx = (lane >> 5) ? 1 + (lane & 30) : 2 + (lane & 30);
+    const int l_dx = l_hx - 1;
+    const unsigned l_voff = (unsigned)((xpart(l_dx, 0) + biasf) * 4);      // chunk term rides in the row's scalar offset
+    const int l_lds = (l_hx & 1) * PP * 8 + (l_hx >> 1) * 8 + qq * 4;      // halves
+    const int l_bp = 4 * (l_dx >> 2);                                      // ds_bpermute address of this lane's keep-word within its row
+    const unsigned l_sh = (unsigned)((l_dx & 3) * 8 + qq * 4);             // first of its four bits in that word
+    // Row units of this wave.  LIN (all but the fused up-convolution at 8 producer waves): the wave owns RPW CONSECUTIVE
+    // rows of ONE z-plane of one chunk (RPW divides the plane's 10 rows), so row i is (first row) + i: a running scalar
+    // add on the global side, an immediate on the LDS side, no per-row tables in scalar registers.
+    constexpr bool LIN = NU % NPW == 0 && HY % RPW == 0;
+    auto unit_of = [&](int i) { return LIN ? pw * RPW + i : pw + NPW * i; };
+    auto unit_geo = [&](int u, int& lch, int& r, int& dzy, int& dy, int& pz) {
+      const int scn = u / RU;
+      r = u - scn * RU;
+      pz = r / HY;
+      const int hy = r - pz * HY;
+      dy = hy - 1;
+      dzy = (pz - (TZ - 1)) * a.H + dy;                // row offset in rows of the tensor
+      lch = UP ? 1 : scn;
+    };
+    int u_soff[LIN ? 1 : RPW], u_lds[LIN ? 1 : RPW];   // LIN: entry 0 = row 0 of the wave
+    unsigned um_valid = 0, um_ylo = 0, um_yhi = 0, um_zf = 0, um_zl = 0, um_pre = 0;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int lch, r, dzy, dy, pz;
+      unit_geo(unit_of(i), lch, r, dzy, dy, pz);
+      if (!LIN || i == 0) {
+        u_soff[LIN ? 0 : i] = (dzy * rowf + (xpart(0, lch) - xpart(0, 0))) * 4;
+        u_lds[LIN ? 0 : i] = lch * CHUNK_H + r * HXP * 8;
+      }
+      if (unit_of(i) < NU) um_valid |= 1u << i;
+      if (dy < 0) um_ylo |= 1u << i;
+      if (dy >= 8) um_yhi |= 1u << i;
+      if (pz < TZ - 1) um_zf |= 1u << i;               // step 0 of a column: planes -(TZ-1) .. -1 do not exist
+      else um_zl |= 1u << i;                           // step KZ: plane D does not exist
+      if (PRE != 0 && (NCH == 1 || lch == 1)) um_pre |= 1u << i;
+    }
+    const int row_soff_step = rowf * 4;
+    // keep-word this lane computes in hash round rd: word (lane & 7) of row slot 8 rd + (lane >> 3)
+    int l_hw[PRE ? HR : 1];
+    if constexpr (PRE != 0) {
+#pragma unroll
+      for (int rd = 0; rd < HR; ++rd) {
+        int lch, r, dzy, dy, pz;
+        unit_geo(unit_of(8 * rd + (lane >> 3)), lch, r, dzy, dy, pz);
+        l_hw[rd] = dzy * (a.W / 4) + (lane & 7);       // (row's first element) / 32 + word
+      }
+    }
+    // ---- halo pieces: iteration hk of the step (this wave's only one, if any): lane -> (chunk, row, side, quad)
+    const int hk = NPW - 1 - pw;
+    const bool has_halo = hk < HIT;
+    unsigned h_voff = 0, h_erel = 0, h_flags = 1u;     // flags: 1 never a piece, 2 / 4 side x = -1 / 32, 8 / 16 y = -1 / 8,
+    int h_lds = 0;                                     //        32 / 64 plane before the last / the last of the step, 128 prologue
+    if (has_halo) {
+      const int hp = lane + 64 * hk;
+      const int rem = hp % (RU * 4), side = (rem >> 1) & 1;
+      int lch, r, dzy, dy, pz;
+      unit_geo(hp >> 2, lch, r, dzy, dy, pz);
+      const int dx = side ? 32 : -1, hx = dx + 1;
+      h_voff = (unsigned)((dzy * rowf + xpart(dx, lch) + biasf) * 4);
+      h_lds = lch * CHUNK_H + (hx & 1) * PP * 8 + (r * HXP + (hx >> 1)) * 8 + qq * 4;
+      h_erel = (unsigned)((dzy * a.W + dx) * 8 + qq * 4);
+      h_flags = (hp >= NH ? 1u : 0u) | (side ? 4u : 2u) | (dy < 0 ? 8u : 0u) | (dy >= 8 ? 16u : 0u) | (pz < TZ - 1 ? 32u : 64u) |
+                ((PRE != 0 && (NCH == 1 || lch == 1)) ? 128u : 0u);
     }
     const size_t in_sample = (size_t)a.D * a.H * rowf;
     const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
@@ -209,35 +264,50 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const size_t up_sample = (size_t)(a.D >> 1) * Hc * urow;
 
     // ---- register staging: the loads of one step (and what its commit needs to know) ----
-    f32x4 ibuf[IN_IT];
+    f32x4 ibuf[RPW], hbuf = {0.f, 0.f, 0.f, 0.f};
     f32x4 ubuf[UP ? UT : 1];
     unsigned p_ubad = 0;
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
-    unsigned p_bad = 0, p_e0 = 0, p_key = 0;
+    unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;   // bit i: row unit i of the staged step lies outside the volume
+    bool p_hbad = true;                                      // this lane's halo piece of the staged step lies outside
 
     auto prefetch = [&](const Cur& c) {
       const bool have = c.ci < ncol_wg;
       int n = 0, ty = 0, tx = 0;
       if (have) col_of(c.ci, n, ty, tx);
-      unsigned bad = ib_always;
-      if (tx == 0) bad |= ib_xlo;
-      if (tx == ka.tiles_x - 1) bad |= ib_xhi;
-      if (ty == 0) bad |= ib_ylo;
-      if (ty == ka.tiles_y - 1) bad |= ib_yhi;
-      if (c.s == 0) bad |= ib_zfirst;
-      if (c.s == KZ) bad |= ib_zlast;
+      unsigned bad = ~um_valid;
+      if (ty == 0) bad |= um_ylo;
+      if (ty == ka.tiles_y - 1) bad |= um_yhi;
+      if (c.s == 0) bad |= um_zf;
+      if (c.s == KZ) bad |= um_zl;
       if (!have) bad = 0xFFFFFFFFu;
       const int nin = n / in_rep;
-      const unsigned soff = (unsigned)((((TZ * c.s) * a.H + ty * 8) * rowf + tx * 32 * voxf) * 4);
+      const int soff = (((TZ * c.s) * a.H + ty * 8) * rowf + tx * 32 * voxf) * 4;
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.in + (size_t)nin * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+      // NO branch may enclose a load: behind a join the compiler's wait-count bookkeeping gives up and waits for EVERY load
+      // in flight (s_waitcnt vmcnt(0) in the middle of this function: the whole memory latency, every step -- measured
+      // 2 400 cycles).  A row outside the volume reads through an out-of-range offset instead (zeros, no memory access).
 #pragma unroll
-      for (int it = 0; it < IN_IT; ++it) {
-        if (UP != 0 && !(it & 1)) continue;               // chunk 0 is computed, not loaded
-        const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
-        ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
+      for (int i = 0; i < RPW; ++i) {
+        const int so = soff + (LIN ? u_soff[0] + i * row_soff_step : u_soff[LIN ? 0 : i]);
+        const bool rb = (bad >> i) & 1u;
+        ibuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0));
       }
-      p_bad = bad;
+      p_rowbad = bad;
+      {
+        unsigned hb = 1u;
+        if (tx == 0) hb |= 2u;
+        if (tx == ka.tiles_x - 1) hb |= 4u;
+        if (ty == 0) hb |= 8u;
+        if (ty == ka.tiles_y - 1) hb |= 16u;
+        if (c.s == 0) hb |= 32u;
+        if (c.s == KZ) hb |= 64u;
+        if (!have) hb = 0x7Fu;
+        const bool lbad = (h_flags & hb) != 0u;      // waves without a halo iteration: flag 1 in every lane
+        hbuf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0));
+        p_hbad = lbad;
+      }
       if constexpr (UP != 0) {
         unsigned ub = ub_always;
         if (tx == 0) ub |= ub_xlo;
@@ -256,52 +326,104 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         p_ubad = ub;
       }
       if constexpr (PRE != 0) {
-        if (have) {
-          p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq_thread * 4);
-          p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq_thread * 4);
-        }
+        // (n = 0 when the workgroup has run out of columns: a valid address, no branch around the loads)
+        p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq * 4);
+        p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq * 4);
         p_e0 = (unsigned)(((TZ * c.s) * a.H + ty * 8) * a.W + tx * 32) * 8u;
         p_key = vx_drop_key(vx_seed_of(a, a.in_drop_seed), a.in_drop_layer, (uint32_t)n);
       }
     };
 
+    // the producing block's InstanceNorm + LeakyReLU + Dropout on one piece: (x - mean) * scale with the keep bit ANDed into
+    // the scale (dropout's factor 2 rides in it: 2 lrelu(t) = lrelu(2 t)); (x - mean) first: no cancellation against a
+    // rounded mean * rstd
+    auto pre_piece = [&](f32x4 v, const f32x4 sc, uint32_t bits) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int keep = __builtin_amdgcn_sbfe((int)bits, j, 1);          // all ones / all zeros
+        const float scj = __int_as_float(__float_as_int(sc[j]) & keep);
+        // plain single instructions (vx_*1): packed fp32 beside the consumers' MFMAs costs three times as much
+        const float t = vx_mul1(vx_sub1(v[j], p_mean[j]), scj);
+        v[j] = vx_max1(t, vx_mul1(t, 0.01f));
+      }
+      return v;
+    };
+
+    // plain-instruction split where the prologue runs (measured: -5 % on both prologue layers); the instances without a
+    // prologue keep the packed form (expand_1_2 + head lost 20 % with the plain one: its consumers are the critical path)
+    auto split4 = [&](const f32x4 v, f16x4& hi, f16x4& lo) {
+      if constexpr (PRE != 0) vx_split4_s(v, hi, lo);
+      else vx_split4(v, hi, lo);
+    };
     auto commit = [&](int grp) {
       const int gofs = grp * GRP_H;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+      const bool hashed = PRE != 0 && a.in_drop_mode == VX_DROP_HASH;
+      uint32_t hw[PRE ? HR : 1];
       if constexpr (PRE != 0) {
-        // dropout's factor 2 rides in the scale: 2 lrelu(t) = lrelu(2 t)
-        sc = p_rstd * (a.in_drop_mode == VX_DROP_HASH ? 2.f : 1.f);
+        const float two = hashed ? 2.f : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = vx_mul1(p_rstd[j], two);
+        if (hashed) {
+          // keep-words of this wave's rows, one hash round per eight rows
+#pragma unroll
+          for (int rd = 0; rd < HR; ++rd) hw[rd] = vx_mix32((uint32_t)((int)(p_e0 >> 5) + l_hw[rd]) ^ p_key);
+        }
+      }
+      // rows: straight-line code (the compiler interleaves the rows' dependent chains; a row outside the volume arrives as
+      // zeros and its keep bits are forced to zero, so it commits the zero padding of the NORMALISED tensor)
+      const bool wave_pre = PRE != 0 && ((NCH == 1 || UP != 0) ? true : (um_pre & 1u) != 0u);   // LIN: one chunk per wave
+      uint32_t wrow[PRE ? RPW : 1];
+      if constexpr (PRE != 0) {
+        if (hashed && wave_pre) {
+#pragma unroll
+          for (int i = 0; i < RPW; ++i)
+            wrow[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(l_bp + 32 * (i & 7), (int)hw[i >> 3]);
+        }
       }
 #pragma unroll
-      for (int it = 0; it < IN_IT; ++it) {
-        if (UP != 0 && !(it & 1)) continue;
-        if (ptid + (NCH == 2 ? (it >> 1) : it) * PT < PPS) {
-          f32x4 v = ibuf[it];
-          if constexpr (PRE != 0) if (NCH == 1 || (it & 1)) {
-            uint32_t bits = 0xFu;
-            if (a.in_drop_mode == VX_DROP_HASH) bits = vx_drop_bits4(p_key, p_e0 + erel[it]);
-            if ((p_bad >> it) & 1u) bits = 0u;           // zero padding belongs to the normalised tensor
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float t = (v[j] - p_mean[j]) * sc[j];      // (x - mean) first: no cancellation against a rounded mean * rstd
-              t = fmaxf(t, 0.01f * t);
-              // keep ? t : 0  -- an all-ones / all-zeros word from one signed bit-field extract
-              const int keep = __builtin_amdgcn_sbfe(bits, j, 1);
-              v[j] = __int_as_float(__float_as_int(t) & keep);
-            }
+      for (int i = 0; i < RPW; ++i) {
+        if (!LIN && !((um_valid >> i) & 1u)) continue;       // (only the last unit of a wave can be missing)
+        _Float16* dst = s_img + gofs + l_lds + (LIN ? u_lds[0] + i * (HXP * 8) : u_lds[LIN ? 0 : i]);
+        f32x4 v = ibuf[i];
+        if constexpr (PRE != 0) {
+          if (wave_pre && !(XP_ABL & 32)) {
+            uint32_t bits = hashed ? (wrow[i] >> l_sh) : 0xFu;                 // pre_piece looks at bits 0..3 only
+            bits &= ((p_rowbad >> i) & 1u) ? 0u : 0xFu;
+            v = pre_piece(v, sc, bits);
           }
-          f16x4 hi, lo;
-          vx_split4(v, hi, lo);
-          *reinterpret_cast<f16x4*>(s_img + gofs + ldst[it]) = hi;
-          *reinterpret_cast<f16x4*>(s_img + gofs + ldst[it] + PREC_H) = lo;
         }
+        f16x4 hi, lo;
+        if (XP_ABL & 32) { hi = __builtin_bit_cast(f16x4, (f32x2){v[0], v[1]}); lo = __builtin_bit_cast(f16x4, (f32x2){v[2], v[3]}); }
+        else split4(v, hi, lo);
+        if (!(XP_ABL & 16)) {
+          *reinterpret_cast<f16x4*>(dst) = hi;
+          *reinterpret_cast<f16x4*>(dst + PREC_H) = lo;
+        } else {
+          asm volatile("" :: "v"(hi), "v"(lo));
+        }
+      }
+      if (has_halo && !(h_flags & 1u)) {
+        f32x4 v = hbuf;                      // zeros where the piece lies outside the volume (out-of-range load)
+        if constexpr (PRE != 0) {
+          if (h_flags & 128u) {
+            uint32_t bits = 0xFu;
+            if (hashed) bits = vx_drop_bits4(p_key, p_e0 + h_erel);
+            if (p_hbad) bits = 0u;           // zero padding belongs to the normalised tensor
+            v = pre_piece(v, sc, bits);
+          }
+        }
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<f16x4*>(s_img + gofs + h_lds) = hi;
+        *reinterpret_cast<f16x4*>(s_img + gofs + h_lds + PREC_H) = lo;
       }
       if constexpr (UP != 0) {
         // the up half of the step: ConvTranspose3d(k = 2, s = 2) of the coarse voxels just loaded, three split products
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f16x4 ubh[UT], ubl[UT];
 #pragma unroll
-        for (int i = 0; i < UT; ++i) vx_split4(ubuf[i], ubh[i], ubl[i]);
+        for (int i = 0; i < UT; ++i) split4(ubuf[i], ubh[i], ubl[i]);
         // vx_split4 writes the lo halves from inline assembly: the compiler does not know a VALU result is about to be a
         // matrix operand and inserts no wait states for it (measured: stale lo operands without this)
         __builtin_amdgcn_sched_barrier(0);
@@ -313,11 +435,14 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16f16(u_ah, bh, ubias4, 0, 0, 0);
           f32x4 dx = __builtin_amdgcn_mfma_f32_16x16x16f16(u_ah, bl, zero, 0, 0, 0);
           dx = __builtin_amdgcn_mfma_f32_16x16x16f16(u_al, bh, dx, 0, 0, 0);
-          f32x4 v = d + dx * (1.0f / 2048.f);
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaf(dx[j], 1.0f / 2048.f, d[j]);   // NOT inline asm: the first reader of a matrix
+                                                                                 // result needs the compiler's wait states
           if ((p_ubad >> i) & 1u) v = zero;               // outside the volume: the conv's zero padding, not the bias
           rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           f16x4 hi, lo;
-          vx_split4(v, hi, lo);
+          split4(v, hi, lo);
           if (!((u_nowrite >> i) & 1u)) {
             *reinterpret_cast<f16x4*>(s_img + gofs + u_ldst[i]) = hi;
             *reinterpret_cast<f16x4*>(s_img + gofs + u_ldst[i] + PREC_H) = lo;

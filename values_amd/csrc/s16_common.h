@@ -40,6 +40,40 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
   }
 }
 
+// Single-instruction fp32 helpers.  hipcc packs neighbouring fp32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32
+// (explicit f32x2 arithmetic and the SLP vectoriser alike); beside another wave's MFMA stream a packed fp32 instruction
+// costs 11-13 cycles against ~4 for a plain one (MI355X_MICROARCH.md, cycle constants, "price of one filler beside
+// MFMAs") -- measured here: the staging waves of conv3d_xp8w.hip spent ~12 cycles per vector instruction.  Inline
+// assembly keeps these single instructions whatever the flags.
+__device__ __forceinline__ float vx_sub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vx_mul1(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vx_add1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vx_fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vx_max1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// vx_split4 with the 2048 x products as plain multiplies (staging waves that run beside MFMA waves)
+__device__ __forceinline__ void vx_split4_s(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {
+    const f32x2 x = {v[j], v[j + 1]};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+#ifdef VX_SPLIT_S_PLAIN
+    const float r0 = vx_mul1(vx_sub1(v[j], (float)h[0]), 2048.f), r1 = vx_mul1(vx_sub1(v[j + 1], (float)h[1]), 2048.f);
+    const f16x2 l = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+#else
+    const float xs0 = vx_mul1(v[j], 2048.f), xs1 = vx_mul1(v[j + 1], 2048.f);
+    const float m2048 = -2048.f;
+    const uint32_t hv = __builtin_bit_cast(uint32_t, h);
+    uint32_t lv = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs1));
+    const f16x2 l = __builtin_bit_cast(f16x2, lv);
+#endif
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
+
 // x + (x of lane ^ 16): two copies, v_permlane16_swap_b32 exchanges row 1 of the first with row 0 of the second (and
 // row 3 with row 2), so a = [r0, r0, r2, r2], b = [r1, r1, r3, r3] -- no LDS-queue ds_bpermute as __shfl_xor(x, 16) takes
 // (tools/micro/permlane_swap.hip); the same bits as x + __shfl_xor(x, 16)

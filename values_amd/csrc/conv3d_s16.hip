@@ -79,6 +79,7 @@ template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, in
 __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   constexpr int NTH = 64 * NW;
   constexpr bool SINGLE = DB == 1 || DB == 2;   // double-buffered, every item a whole tile (one chunk)
+  constexpr bool DEFER = DB == 0 && XP == 0;     // two-barrier schedule, plain layers: next item's loads issued inside the multiply loop
   constexpr bool STAG = DB == 2 || DB == 3;        // staggered waves (DB = 3: also for several chunks per tile)
   constexpr int TXV = XP ? 2 * TX : TX;            // voxels per tile along x
   constexpr int NVT = TX * TY * TZ / 16;
@@ -227,7 +228,21 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
 
-  auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w) {
+  // the prologue's dropout seed: read ONCE (a device word under hipGraph replay: a load inside the item loop would make
+  // every item wait for all the loads in flight -- s_waitcnt vmcnt(0) -- before it can use the word)
+  const uint32_t seed_in = pre ? vx_seed_of(a, a.in_drop_seed) : 0u;
+  const uint32_t seed_out = vx_seed_of(a, a.drop_seed);
+  // the loads of the next item: addressing set up by prefetch(); issued either right there or, for the two-barrier
+  // schedule of the plain layers, one per K-step INSIDE the multiply loop (pf_issue(s) behind step s): issuing all of
+  // them at once after the barrier kept every wave of the workgroup in the load queue for 2 000 - 3 400 cycles per item
+  // (72 KB through the CU's one address path) with the matrix pipe idle -- 15-25 % of the item (tools/stamp_s16.py)
+  __amdgpu_buffer_rsrc_t pf_srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
+  unsigned pf_bad = 0xFFFFFFFFu, pf_soff = 0;
+  auto pf_issue = [&](int it) {
+    const unsigned vo = ((pf_bad >> it) & 1u) ? VX_OOB : voff[it];
+    ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pf_srd, (int)vo, (int)pf_soff, 0));
+  };
+  auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w, bool deferred = false) {
     int n, tx, ty, tz;
     decode(tile_lin, n, tx, ty, tz);
     unsigned bad = ibad_always;
@@ -244,22 +259,22 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     else coff = 0;
     const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TXV * voxf + coff) * 4);
     const int n_in = have ? n / in_rep : 0;
-    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.in + (size_t)n_in * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+    pf_srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n_in * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+    pf_bad = bad;
+    pf_soff = soff;
+    if (!deferred) {
 #pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-      const unsigned vo = ((bad >> it) & 1u) ? VX_OOB : voff[it];
-      ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
+      for (int it = 0; it < IN_IT; ++it) pf_issue(it);
     }
     if (pre) {
       p_bad = bad;
       p_e0 = (soff >> 2) - (unsigned)biasf;
-      p_key = vx_drop_key(vx_seed_of(a, a.in_drop_seed), a.in_drop_layer, (uint32_t)n);
-      if (have) {
-        const size_t mo = (size_t)n_in * a.Cin + chunk * CB + (tid % Q) * 4;
-        p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + mo);
-        p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + mo);
-      }
+      p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
+      // (n_in = 0 when the workgroup has run out of tiles: a valid address -- no branch around the loads, a join behind
+      // one makes the compiler wait for every load in flight)
+      const size_t mo = (size_t)n_in * a.Cin + chunk * CB + (tid % Q) * 4;
+      p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + mo);
+      p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + mo);
     }
     const f32x4* src = w_cg + (size_t)chunk * (W_H / 8);
 #pragma unroll
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     const unsigned e0 = vox0 * (unsigned)a.Cout;
     const __amdgpu_buffer_rsrc_t osrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
-    const uint32_t dkey = f_dhash ? vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n) : 0u;
+    const uint32_t dkey = f_dhash ? vx_drop_key(seed_out, a.drop_layer, (uint32_t)n) : 0u;
     const size_t hnvox = (size_t)a.D * a.H * a.W;
     int hflip = 0;
     float* hbase = nullptr;
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   };
 
   // ---- the multiply phase of one item: image at halves offset cofs, weights of chunk ck ----
-  auto multiply = [&](int cofs, int ck) {
+  auto multiply = [&](int cofs, int ck, bool issue_loads = false) {
     const _Float16* s_wc = s_w + (ka.w_all ? ck * W_H : 0);   // this item's weights
 
     if constexpr (XP == 1 && TX == 16 && TY % R == 0) {
@@ -588,6 +603,15 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       for (int s = 0; s < NSTEP; ++s) {
         if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
         const int cur = s & 1;
+        if (issue_loads) {
+          // the next item's loads, spread over the steps (IN_IT <= NSTEP for every tile this path takes; else the rest
+          // goes out with the last step)
+          if (s < IN_IT) pf_issue(s);
+          if (s == NSTEP - 1) {
+#pragma unroll
+            for (int it = NSTEP; it < IN_IT; ++it) pf_issue(it);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -596,6 +620,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bl[cur][r], accx[r][nt], 0, 0, 0);
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][nt], bh[cur][r], accx[r][nt], 0, 0, 0);
           }
+        if (issue_loads && s < IN_IT) {
+          // pin the load behind this step's matrix instructions (left alone the scheduler sinks all of them to the end
+          // of the loop, where they queue up exactly as before)
+          __builtin_amdgcn_sched_group_barrier(0x008, R * NT * 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
       }
     }
 
@@ -661,16 +691,22 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       }
     } else {
       if (S16_DBG < 3) __syncthreads();
+      VX_STAMP(0);
       flush_stats();
+      VX_STAMP_WAIT_LOADS();
+      VX_STAMP(3);
       if (S16_DBG < 2) commit(w_fresh);
+      VX_STAMP(4);
       if (S16_DBG < 3) __syncthreads();
+      VX_STAMP(0);
       w_fresh = !w_resident;
       ntile = tile_lin; nchunk = chunk + 1;
       if (nchunk == ka.nchunks) { nchunk = 0; ntile = tile_lin + (int)gridDim.x; }
       nhave = ntile < total;
-      if (S16_DBG < 2) prefetch(ntile, nchunk, nhave, !w_resident);
+      if (S16_DBG < 2) prefetch(ntile, nchunk, nhave, !w_resident, DEFER);
+      VX_STAMP(5);
     }
-    multiply(cofs, chunk);
+    multiply(cofs, chunk, DB == 0 && DEFER && S16_DBG < 2);
     VX_STAMP(1);
     if constexpr (STAG) {   // waves 4..7 stage the next item after their MFMA loop: E M C against C M E of waves 0..3
       if (late) {

@@ -105,6 +105,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     tx = (int)(rem - q2 * (unsigned)ka.tiles_x);
   };
 
+  // dropout seeds: the by-value seed + the optional device word (hipGraph replay), read ONCE -- a load inside the item
+  // loops would wait for every load / store in flight (s_waitcnt vmcnt(0)) before the word can be used
+  const uint32_t seed_in = PRE != 0 ? vx_seed_of(a, a.in_drop_seed) : 0u;
+  const uint32_t seed_out = (EPI == 1 || EPI == 2 || EPI == 4) ? vx_seed_of(a, a.drop_seed) : 0u;
   float rmax = 0.f;   // largest |value| this wave stored or produced (range guard of the split-fp16 consumers)
 #ifdef VX_CONV_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_iters = 0;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq * 4);
         p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq * 4);
         p_e0 = (unsigned)(((TZ * c.s) * a.H + ty * 8) * a.W + tx * 32) * 8u;
-        p_key = vx_drop_key(vx_seed_of(a, a.in_drop_seed), a.in_drop_layer, (uint32_t)n);
+        p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
       }
     };
 
@@ -440,7 +444,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           for (int j = 0; j < 4; ++j) v[j] = fmaf(dx[j], 1.0f / 2048.f, d[j]);   // NOT inline asm: the first reader of a matrix
                                                                                  // result needs the compiler's wait states
           if ((p_ubad >> i) & 1u) v = zero;               // outside the volume: the conv's zero padding, not the bias
-          rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          rmax = vx_max3abs(vx_max3abs(rmax, v[0], v[1]), v[2], v[3]);
           f16x4 hi, lo;
           split4(v, hi, lo);
           if (!((u_nowrite >> i) & 1u)) {
@@ -619,7 +623,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (ci != e_ci) {   // a new column: sample, tile row / column, dropout key, head pointers
         e_ci = ci;
         col_of(ci, e_n, e_ty, e_tx);
-        if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)e_n);
+        if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(seed_out, a.drop_layer, (uint32_t)e_n);
         if (EPI == 2) {
           e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
           const int slot = a.head_dst ? a.head_dst[e_n] : e_n;

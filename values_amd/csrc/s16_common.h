@@ -51,6 +51,12 @@ __device__ __forceinline__ float vx_add1(float a, float b) { float r; asm("v_add
 __device__ __forceinline__ float vx_fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vx_max1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// r = max(r, |a|, |b|) as ONE instruction (fmaxf(fabsf()) chains compile to a canonicalising v_max per operand first)
+__device__ __forceinline__ float vx_max3abs(float r, float a, float b) {
+  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // vx_split4 with the 2048 x products as plain multiplies (staging waves that run beside MFMA waves)
 __device__ __forceinline__ void vx_split4_s(const f32x4 v, f16x4& hi, f16x4& lo) {
 #pragma unroll

@@ -4,21 +4,24 @@
 // resolves the pass scheduling of predict_cases (test_3D.py:417-482): sample n reads volume src[n]
 // (MC-dropout: n / repeat, all T samples of a volume read the same input) through the flip code of
 // its TTA view.
-#include "common.h"
+#include "s16_common.h"
 
+// Round 3: a thread computes a column of FOUR voxels along z and walks the nine (ky, kx) offsets: per offset the three
+// kz weight vectors come out of LDS once (broadcast 16-byte reads) and serve the column's six input planes, so a voxel
+// costs 27 LDS reads instead of 243 (the round-2 kernel read one weight per FMA: 0.16 of the HBM roof); the InstanceNorm
+// sums are accumulated over the column before the cross-lane reduction (a quarter of the shuffles per voxel).
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3d_k3_c1_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           int out_pitch, int N, int D, int H, int W, int repeat,
-                                                           const int32_t* __restrict__ src,
-                                                           const int32_t* __restrict__ flip,
-                                                           float* __restrict__ stats_partial, int tiles_x, int tiles_y,
-                                                           int tiles_z) {
-  constexpr int TX = 32, TY = 4, TZ = 2;  // 256 voxels, one per thread
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ out, int out_pitch, int N, int D, int H, int W,
+                                                           int repeat, const int32_t* __restrict__ src,
+                                                           const int32_t* __restrict__ flip, float* __restrict__ stats_partial,
+                                                           int tiles_x, int tiles_y, int tiles_z) {
+  constexpr int TX = 64, TY = 4, TZ = 4;  // 1024 voxels, a z-column of four per thread
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
   __shared__ float s_in[HZ * HY * HX];
-  __shared__ float s_w[27 * COUT];
-  __shared__ float s_red[4][COUT][2];
+  __shared__ __attribute__((aligned(16))) float s_w[27 * COUT];
+  __shared__ float s_red[16][COUT][2];
 
   const int tid = threadIdx.x;
   int t = blockIdx.x;
@@ -50,48 +53,72 @@ __global__ __launch_bounds__(256) void conv3d_k3_c1_kernel(const float* __restri
   }
   __syncthreads();
 
-  const int lx = tid % TX, ly = (tid / TX) % TY, lz = tid / (TX * TY);
-  float acc[COUT];
+  const int lx = tid % TX, ly = tid / TX;
+  float acc[TZ][COUT];
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+  for (int z = 0; z < TZ; ++z)
 #pragma unroll
-  for (int kz = 0; kz < 3; ++kz)
+    for (int c = 0; c < COUT; ++c) acc[z][c] = bias[c];
+  // (a run-time loop on purpose: fully unrolled, hipcc hoists all 27 x Cout weights into registers -- 360 VGPRs)
+#pragma unroll 1
+  for (int kk = 0; kk < 9; ++kk) {
+    const int ky = kk / 3, kx = kk - 3 * ky;
+    float wk[3][COUT];                 // the three kz taps of this (ky, kx), all output channels
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const float xv = s_in[((lz + kz) * HY + ly + ky) * HX + lx + kx];
-        const int tap = (kz * 3 + ky) * 3 + kx;
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(s_w[tap * COUT + c], xv, acc[c]);
+      for (int c = 0; c < COUT; c += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[(kz * 9 + kk) * COUT + c]);
+        wk[kz][c] = w4[0]; wk[kz][c + 1] = w4[1]; wk[kz][c + 2] = w4[2]; wk[kz][c + 3] = w4[3];
       }
-
-  const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-  const bool valid = gx < W && gy < H && gz < D;
-  if (valid) {
-    float* o = out + (((size_t)(n * D + gz) * H + gy) * W + gx) * out_pitch;
+    const float* sp = s_in + (ly + ky) * HX + lx + kx;
+    // input plane p (0 .. TZ + 1) feeds output plane z through tap kz = p - z
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4)
-      *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    for (int p = 0; p < HZ; ++p) {
+      const float xv = sp[p * HY * HX];
+#pragma unroll
+      for (int z = 0; z < TZ; ++z) {
+        const int kz = p - z;
+        if (kz < 0 || kz > 2) continue;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[z][c] = fmaf(wk[kz][c], xv, acc[z][c]);
+      }
+    }
+  }
+
+  const int gx = x0 + lx, gy = y0 + ly;
+  float ssum[COUT], ssq[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+#pragma unroll
+  for (int z = 0; z < TZ; ++z) {
+    const int gz = z0 + z;
+    const bool valid = gx < W && gy < H && gz < D;
+    if (valid) {
+      float* o = out + (((size_t)(n * D + gz) * H + gy) * W + gx) * out_pitch;
+#pragma unroll
+      for (int c = 0; c < COUT; c += 4)
+        *reinterpret_cast<f32x4*>(o + c) = (f32x4){acc[z][c], acc[z][c + 1], acc[z][c + 2], acc[z][c + 3]};
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) { ssum[c] += acc[z][c]; ssq[c] = fmaf(acc[z][c], acc[z][c], ssq[c]); }
+    }
   }
   if (stats_partial) {
+    // sums over the workgroup: DPP row rotations inside each 16-lane row (vector ALU, no trip through the LDS queue as
+    // __shfl_xor takes), then the 16 row sums of the four waves through LDS
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
-      float s = valid ? acc[c] : 0.f;
-      float q = s * s;
+      float s = ssum[c], q = ssq[c];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        s += __shfl_xor(s, off, 64);
-        q += __shfl_xor(q, off, 64);
-      }
-      if (lane == 0) { s_red[wave][c][0] = s; s_red[wave][c][1] = q; }
+      for (int rot = 8; rot >= 1; rot >>= 1) { s += vx_row_ror(s, rot); q += vx_row_ror(q, rot); }
+      if ((lane & 15) == 0) { s_red[wave * 4 + (lane >> 4)][c][0] = s; s_red[wave * 4 + (lane >> 4)][c][1] = q; }
     }
     __syncthreads();
     if (tid < COUT) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) { s += s_red[wv][tid][0]; q += s_red[wv][tid][1]; }
+      for (int wv = 0; wv < 16; ++wv) { s += s_red[wv][tid][0]; q += s_red[wv][tid][1]; }
       const int ntiles = tiles_x * tiles_y * tiles_z;
       const int tile = blockIdx.x % ntiles;
       float* dst = stats_partial + (((size_t)n * ntiles + tile) * COUT + tid) * 2;
@@ -101,7 +128,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_c1_kernel(const float* __restri
   }
 }
 
-extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W) { return ((W + 31) / 32) * ((H + 3) / 4) * ((D + 1) / 2); }
+extern "C" int vx_conv3d_k3_c1_tiles(int D, int H, int W) { return ((W + 63) / 64) * ((H + 3) / 4) * ((D + 3) / 4); }
 
 extern "C" int vx_conv3d_k3_c1(const float* in, const float* w_torch, const float* bias, float* out, int out_pitch,
                                int N, int D, int H, int W, int Cout, int repeat, const int32_t* src,
@@ -110,7 +137,7 @@ extern "C" int vx_conv3d_k3_c1(const float* in, const float* w_torch, const floa
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3_c1: empty tensor");
   if (repeat <= 0) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3_c1: repeat must be >= 1");
   if (out_pitch < Cout || out_pitch % 4 || !vx_aligned16(out)) VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3_c1: out pitch/alignment");
-  const int tiles_x = (W + 31) / 32, tiles_y = (H + 3) / 4, tiles_z = (D + 1) / 2;
+  const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4, tiles_z = (D + 3) / 4;
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z * N));
   hipStream_t s = (hipStream_t)stream;
 #define VX_C1(CO)                                                                                                  \

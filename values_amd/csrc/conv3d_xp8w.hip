@@ -680,7 +680,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
               part = vx_add_xor16(part);
               // (measured alternative: the g-odd lane finishing and storing class c + 1 -- one exchange and one store per
               // class pair with all 64 lanes active -- 1.282 instead of 1.249 ms per 320 samples, same box)
-              if (!(g & 1)) o[(size_t)c * hnvox] = part;
+              if (XP_ABL & 64) asm volatile("" :: "v"(part));      // diagnostic build: head stores off
+              else if (!(g & 1)) o[(size_t)c * hnvox] = part;
             }
           }
         } else {

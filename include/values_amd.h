@@ -79,6 +79,8 @@ typedef struct vx_config {
   int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
   int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
   int32_t s16_no_poolfuse; /* separate pooling pass over contr_1_2's output instead of the window maxima from its epilogue */
+  int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
+                              instead of reading the once-per-volume output of vx_prenorm_split */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);
@@ -209,6 +211,10 @@ typedef struct vx_conv3d_args {
    * statistics exist -- the full-resolution tensor is not read again. */
   float* pool_out;      /* nullable: [N][D/2][H/2][W/2][8] raw window maxima */
   uint32_t* pool_flags; /* [N][D/2][H/2][W/2][2]: bit j of word q = a dropped element of channel 4 q + j in the window */
+  /* PRE-SPLIT input (only with in_repeat > 1 where vx_conv3d_k3_prologue_ok): `in` is the output of vx_prenorm_split --
+   * the shared raw tensor already normalised, activated and split into fp16 (hi, lo) pairs, ONCE per volume; the prologue
+   * then only applies sample n's dropout bits (in_drop_*) while the tile is staged.  in_mean / in_rstd are not read. */
+  int32_t in_split;
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
@@ -216,6 +222,12 @@ int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx
 /* pooled[c] = any_dropped ? max(s f(m), 0) : s f(m) with f(m) = LeakyReLU((m - mean[n][c]) * rstd[n][c]), s = 2 with
  * dropout (drop_scale2 != 0) else 1: the MaxPool3d(2, 2) of Dropout(LeakyReLU(InstanceNorm(x))) from the window maxima and
  * flags vx_conv3d_k3 left in pool_out / pool_flags (bit-identical to pooling the normalised tensor: f is monotone). */
+/* In place: x [N][nvox][8] fp32 -> per 16-byte piece (4 channels) [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] fp16 with
+ * y = scale * LeakyReLU((x - mean[n][c]) * rstd[n][c]) = hi + lo * 2^-11 (the split the fp16 matrix kernels consume; scale = 2
+ * folds a following p = 0.5 dropout's factor).  For the MC-dropout batch of test_3D.py:462-472: the T samples of a volume
+ * share the first block's conv output (InstanceNorm + LeakyReLU of unet3D_module.py:231-237 are the same for all of them,
+ * only the dropout bits differ), so this runs once per VOLUME and contr_1_2 (vx_conv3d_args.in_split) masks per sample. */
+int vx_prenorm_split(float* x, const float* mean, const float* rstd, int N, int64_t nvox, float scale, vx_stream_t stream);
 int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd, float* out,
                    int out_pitch, int N, int64_t voxels_per_sample, int drop_scale2, vx_stream_t stream);
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an

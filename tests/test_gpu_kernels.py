@@ -615,7 +615,7 @@ def _hash_mask(seed, layer, n, c, d, h, w):
 
 
 def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, stats=False, xblk=0, head=None,
-              pre=None, out_xblk=0, up=None, in_pitch=None):
+              pre=None, out_xblk=0, up=None, in_pitch=None, presplit=False):
     """one vx_conv3d_k3 launch on a channels-last (or x-blocked) device input; returns (out NCDHW cpu, stats, head)"""
     lib = _lib.load()
     assert lib.vx_conv3d_k3_prologue_ok(d, h, wd, cin, 8) == 1
@@ -654,6 +654,14 @@ def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, s
         a.in_mean, a.in_rstd, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), rep
         a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = pmode, pseed, player
         keep += [mean, rstd]
+        if presplit:   # the shared raw tensor goes through vx_prenorm_split first (in place, on a copy), the conv then only masks
+            x_cl = x_cl.clone()
+            n_in, nvox = x_cl.shape[0], d * h * wd
+            _lib.check(lib.vx_prenorm_split(_lib.ptr(x_cl), _lib.ptr(mean), _lib.ptr(rstd), n_in, nvox,
+                                            2.0 if pmode == _lib.VX_DROP_HASH else 1.0, _lib.stream_ptr()), "vx_prenorm_split")
+            a.in_ = x_cl.data_ptr()
+            a.in_split = 1
+            keep.append(x_cl)
     flag = torch.zeros(1, dtype=torch.int32, device=dev())
     a.range_flag = flag.data_ptr()
     _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
@@ -745,6 +753,13 @@ def test_conv3d_xp8_prologue_matches_oracle(cin, shape, rep, xblk, pmode):
     if st is not None:
         s = st.double().sum(1)
         np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=2e-3)
+    if cin == 8:
+        # the same conv on the PRE-SPLIT tensor (vx_prenorm_split once per input sample, the staging waves only apply each
+        # output sample's dropout bits): the same normalised values, the same fp16 pairs, the same products -> the same bits
+        got2, st2, _, _ = _xp8_conv(xd, cin, wt, b, n, d, h, w, stats=True, act=_lib.VX_ACT_NONE, presplit=True,
+                                    pre=(meand, rstdd, rep, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 55, 1))
+        assert _lib.load().vx_last_kernel_name().decode().startswith("conv3d_xp8w_kernel<1,0,2,0,")
+        assert torch.equal(got2, got) and torch.equal(st2, st)
 
 
 @pytest.mark.parametrize("shape,xblk,pitch,pmode", [((2, 8, 16, 64), 4, 16, None), ((3, 12, 8, 32), 0, 16, None),

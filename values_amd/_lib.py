@@ -32,7 +32,8 @@ class ConvArgs(C.Structure):
                 ("head_C", _i32),
                 ("in_mean", _p), ("in_rstd", _p), ("in_drop_mode", _i32), ("in_drop_seed", _u32), ("in_drop_layer", _u32),
                 ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p),
-                ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p)]
+                ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
+                ("in_split", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -74,7 +75,7 @@ class Config(C.Structure):
         "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
         "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
-        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse")]
+        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "s16_no_presplit")]
 
 
 class UncOutputs(C.Structure):
@@ -122,6 +123,7 @@ SIGNATURES = {
     "vx_conv3d_k3_upfuse_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_poolfuse_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -329,10 +329,12 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         }
         p_ubad = ub;
       }
-      if constexpr (PRE != 0) {
+      if constexpr (PRE == 1) {
         // (n = 0 when the workgroup has run out of columns: a valid address, no branch around the loads)
         p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq * 4);
         p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq * 4);
+      }
+      if constexpr (PRE != 0) {
         p_e0 = (unsigned)(((TZ * c.s) * a.H + ty * 8) * a.W + tx * 32) * 8u;
         p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
       }
@@ -359,15 +361,28 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if constexpr (PRE != 0) vx_split4_s(v, hi, lo);
       else vx_split4(v, hi, lo);
     };
+    // PRE == 2: the piece is [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3] already; keep bit j -> a 16-bit mask on element j
+    auto masked_piece = [&](const f32x4 v, uint32_t bits, f16x4& hi, f16x4& lo) {
+      const u32x4 d = __builtin_bit_cast(u32x4, v);
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 0, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+      const uint32_t k2 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2, 1), k3 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+      const uint32_t m01 = __builtin_amdgcn_perm(k1, k0, 0x05040100u), m23 = __builtin_amdgcn_perm(k3, k2, 0x05040100u);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      hi = __builtin_bit_cast(f16x4, (u32x2){d[0] & m01, d[1] & m23});
+      lo = __builtin_bit_cast(f16x4, (u32x2){d[2] & m01, d[3] & m23});
+    };
+
     auto commit = [&](int grp) {
       const int gofs = grp * GRP_H;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f};
       const bool hashed = PRE != 0 && a.in_drop_mode == VX_DROP_HASH;
       uint32_t hw[PRE ? HR : 1];
-      if constexpr (PRE != 0) {
+      if constexpr (PRE == 1) {
         const float two = hashed ? 2.f : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sc[j] = vx_mul1(p_rstd[j], two);
+      }
+      if constexpr (PRE != 0) {
         if (hashed) {
           // keep-words of this wave's rows, one hash round per eight rows
 #pragma unroll
@@ -390,16 +405,22 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if (!LIN && !((um_valid >> i) & 1u)) continue;       // (only the last unit of a wave can be missing)
         _Float16* dst = s_img + gofs + l_lds + (LIN ? u_lds[0] + i * (HXP * 8) : u_lds[LIN ? 0 : i]);
         f32x4 v = ibuf[i];
-        if constexpr (PRE != 0) {
-          if (wave_pre && !(XP_ABL & 32)) {
-            uint32_t bits = hashed ? (wrow[i] >> l_sh) : 0xFu;                 // pre_piece looks at bits 0..3 only
-            bits &= ((p_rowbad >> i) & 1u) ? 0u : 0xFu;
-            v = pre_piece(v, sc, bits);
-          }
-        }
         f16x4 hi, lo;
-        if (XP_ABL & 32) { hi = __builtin_bit_cast(f16x4, (f32x2){v[0], v[1]}); lo = __builtin_bit_cast(f16x4, (f32x2){v[2], v[3]}); }
-        else split4(v, hi, lo);
+        if constexpr (PRE == 2) {
+          // pre-split input (vx_prenorm_split): only this sample's keep bits are left to apply (a row outside the volume
+          // arrives as zeros)
+          masked_piece(v, hashed ? (wrow[i] >> l_sh) : 0xFu, hi, lo);
+        } else {
+          if constexpr (PRE == 1) {
+            if (wave_pre && !(XP_ABL & 32)) {
+              uint32_t bits = hashed ? (wrow[i] >> l_sh) : 0xFu;                 // pre_piece looks at bits 0..3 only
+              bits &= ((p_rowbad >> i) & 1u) ? 0u : 0xFu;
+              v = pre_piece(v, sc, bits);
+            }
+          }
+          if (XP_ABL & 32) { hi = __builtin_bit_cast(f16x4, (f32x2){v[0], v[1]}); lo = __builtin_bit_cast(f16x4, (f32x2){v[2], v[3]}); }
+          else split4(v, hi, lo);
+        }
         if (!(XP_ABL & 16)) {
           *reinterpret_cast<f16x4*>(dst) = hi;
           *reinterpret_cast<f16x4*>(dst + PREC_H) = lo;
@@ -409,16 +430,20 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       }
       if (has_halo && !(h_flags & 1u)) {
         f32x4 v = hbuf;                      // zeros where the piece lies outside the volume (out-of-range load)
-        if constexpr (PRE != 0) {
-          if (h_flags & 128u) {
-            uint32_t bits = 0xFu;
-            if (hashed) bits = vx_drop_bits4(p_key, p_e0 + h_erel);
-            if (p_hbad) bits = 0u;           // zero padding belongs to the normalised tensor
-            v = pre_piece(v, sc, bits);
-          }
-        }
         f16x4 hi, lo;
-        split4(v, hi, lo);
+        if constexpr (PRE == 2) {
+          masked_piece(v, hashed ? vx_drop_bits4(p_key, p_e0 + h_erel) : 0xFu, hi, lo);
+        } else {
+          if constexpr (PRE == 1) {
+            if (h_flags & 128u) {
+              uint32_t bits = 0xFu;
+              if (hashed) bits = vx_drop_bits4(p_key, p_e0 + h_erel);
+              if (p_hbad) bits = 0u;           // zero padding belongs to the normalised tensor
+              v = pre_piece(v, sc, bits);
+            }
+          }
+          split4(v, hi, lo);
+        }
         *reinterpret_cast<f16x4*>(s_img + gofs + h_lds) = hi;
         *reinterpret_cast<f16x4*>(s_img + gofs + h_lds + PREC_H) = lo;
       }
@@ -868,7 +893,10 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if ((int64_t)a.N * cps >= (1ll << 31)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): too many columns");
   if (a.stats_partial && (stat_tiles % cps || a.act != VX_ACT_NONE || (a.drop_mode != VX_DROP_NONE && !a.pool_out) || a.head_out))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): statistics go with a plain epilogue");
-  const int pre = a.in_mean ? 1 : 0;
+  const int pre = a.in_split ? 2 : (a.in_mean ? 1 : 0);
+  if (a.in_split && (a.Cin != 8 || a.in_xblk || a.in_pitch != 8 || a.up_in || !a.stats_partial))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): a pre-split input (vx_prenorm_split) goes with a dense 8-channel tensor and the "
+            "statistics epilogue (contr_1_2)");
   int epi;
   if (a.stats_partial) epi = a.pool_out ? 4 : 0;
   else if (a.head_out) epi = 2;
@@ -885,7 +913,7 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
 #define XP8W_CASE(N_, E_, P_, U_)                                                         \
   if (nch == N_ && epi == E_ && pre == P_ && up == U_)                                    \
     return npw == 8 ? launch_xp8w<N_, E_, P_, U_, 8>(ka, s) : launch_xp8w<N_, E_, P_, U_, 4>(ka, s)
-  XP8W_CASE(1, 4, 0, 0); XP8W_CASE(1, 4, 1, 0);
+  XP8W_CASE(1, 4, 0, 0); XP8W_CASE(1, 4, 1, 0); XP8W_CASE(1, 4, 2, 0); XP8W_CASE(1, 0, 2, 0);
   XP8W_CASE(1, 0, 0, 0); XP8W_CASE(1, 0, 1, 0); XP8W_CASE(1, 1, 0, 0); XP8W_CASE(1, 2, 0, 0); XP8W_CASE(1, 3, 0, 0); XP8W_CASE(1, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 0); XP8W_CASE(2, 1, 1, 0); XP8W_CASE(2, 3, 0, 0); XP8W_CASE(2, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 1); XP8W_CASE(2, 1, 1, 1); XP8W_CASE(2, 3, 0, 1); XP8W_CASE(2, 3, 1, 1);

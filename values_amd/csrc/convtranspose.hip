@@ -183,14 +183,35 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
   const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;   // x-block size is 1, 2 or 4
   const int wstride = (int)gridDim.x * 4;
   float rmax = 0.f;   // range guard of the split-fp16 consumer (vx_convT_args.range_flag)
+  // the next column tile's input is in flight while this one is multiplied and stored (round 3: at 2 waves per SIMD --
+  // 184 registers with 8 row tiles -- the load latency of every iteration was exposed: 0.34 of the HBM roof)
+  auto load_x = [&](int ct, f32x4* dst) {
+    int v = ct * 16 + m;
+    if (v >= nvox_in) v = nvox_in - 1;
+    const float* __restrict__ xin = a.in + (size_t)v * a.in_pitch + 4 * g;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xin + 16 * q);
+  };
+  // (only where the registers allow it: with 64 / 128 input channels the extra fragments spill -- measured +40 %)
+  constexpr bool PF = CIN <= 32;
+  f32x4 xnext[Q];
+  if constexpr (PF) {
+    const int ct0 = blockIdx.x * 4 + wave;
+    load_x(ct0 < ncoltiles ? ct0 : ncoltiles - 1, xnext);
+  }
   for (int ct = blockIdx.x * 4 + wave; ct < ncoltiles; ct += wstride) {
     const int v = ct * 16 + m;                 // flattened input voxel of this lane's column
     const bool ok = v < nvox_in;
     const int vc = ok ? v : nvox_in - 1;
     f32x4 xv[Q];
-    const float* __restrict__ xin = a.in + (size_t)vc * a.in_pitch + 4 * g;
+    if constexpr (PF) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xin + 16 * q);
+      for (int q = 0; q < Q; ++q) xv[q] = xnext[q];
+      const int ctn = ct + wstride;
+      load_x(ctn < ncoltiles ? ctn : ncoltiles - 1, xnext);
+    } else {
+      load_x(ct, xv);
+    }
     unsigned r = (unsigned)vc, q;
     q = ct_div(r, dc.mW); const int x = (int)(r - q * (unsigned)a.W); r = q;
     q = ct_div(r, dc.mH); const int y = (int)(r - q * (unsigned)a.H); r = q;

@@ -71,6 +71,7 @@ static void cfg_from_env() {
   g_cfg.s16_pw = env_int("VX_S16_PW", 0);
   g_cfg.s16_prio = env_int("VX_S16_PRIO", 0);
   g_cfg.s16_no_poolfuse = env_int("VX_S16_NO_POOLFUSE", 0);
+  g_cfg.s16_no_presplit = env_int("VX_S16_NO_PRESPLIT", 0);
 }
 
 const vx_config& vx_cfg() {
@@ -93,5 +94,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 300; /* 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
+extern "C" int vx_version(void) { return 301; /* 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

@@ -4,7 +4,7 @@
 //   vx_norm_act_drop_pool: y = Dropout(LeakyReLU((x - mean) * rstd)); writes y with an arbitrary
 //                          channel pitch/offset (the skip half of the decoder concat buffer) and the
 //                          2x2x2 max-pool of y.  Pure streaming: 16-byte vectors, HBM-bound.
-#include "common.h"
+#include "s16_common.h"
 
 __global__ __launch_bounds__(64) void instnorm_finalize_kernel(const float* __restrict__ partial, int ntiles, int C,
                                                                double inv_count, float eps, float* __restrict__ mean,
@@ -345,6 +345,46 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
     }
     *reinterpret_cast<f32x4*>(out + pv * out_pitch + q * 4) = t;
   }
+}
+
+// vx_prenorm_split: one thread = one 16-byte piece, in place (values_amd.h)
+__global__ __launch_bounds__(256) void prenorm_split_kernel(float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, unsigned pieces, float scale) {
+  const int n = blockIdx.y;
+  f32x4* xs = reinterpret_cast<f32x4*>(x) + (size_t)n * pieces;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
+    const int c = (i & 1u) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * 8 + c);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * 8 + c);
+    f32x4 v = xs[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = (v[j] - mu[j]) * (sc[j] * scale);     // the z-column kernel's prologue arithmetic, bit for bit
+      v[j] = fmaxf(t, 0.01f * t);
+    }
+    f16x4 hi, lo;
+    vx_split4(v, hi, lo);
+    f32x4 o;
+    o[0] = __builtin_bit_cast(float, (f16x2){hi[0], hi[1]});
+    o[1] = __builtin_bit_cast(float, (f16x2){hi[2], hi[3]});
+    o[2] = __builtin_bit_cast(float, (f16x2){lo[0], lo[1]});
+    o[3] = __builtin_bit_cast(float, (f16x2){lo[2], lo[3]});
+    xs[i] = o;
+  }
+}
+
+extern "C" int vx_prenorm_split(float* x, const float* mean, const float* rstd, int N, int64_t nvox, float scale,
+                                vx_stream_t stream) {
+  if (!x || !mean || !rstd) VX_FAIL(VX_E_NULL, "vx_prenorm_split: null pointer");
+  if (N <= 0 || N >= 65536 || nvox <= 0 || nvox >= (1ll << 30)) VX_FAIL(VX_E_SHAPE, "vx_prenorm_split: empty / too large");
+  if (!vx_aligned16(x) || !vx_aligned16(mean) || !vx_aligned16(rstd)) VX_FAIL(VX_E_ALIGN, "vx_prenorm_split: alignment");
+  const unsigned pieces = (unsigned)(nvox * 2);
+  unsigned bx = (pieces + 255u) / 256u;
+  if (bx > 512u) bx = 512u;
+  vx_note_kernel("prenorm_split_kernel");
+  hipLaunchKernelGGL(prenorm_split_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, pieces, scale);
+  VX_CHECK_LAUNCH("vx_prenorm_split");
+  return VX_OK;
 }
 
 extern "C" int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd,

@@ -146,6 +146,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   const bool fuse_head = NC <= 4 && vx_conv3d_k3_head_fusable(F, F) && !vx_cfg().no_head_fusion;
   // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
+  bool pre_split_ = false;           // set around the contr_1_2 launch when its input went through vx_prenorm_split
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
@@ -175,6 +176,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       a.in_mean = pre_mean ? pre_mean : p.mean; a.in_rstd = pre_rstd ? pre_rstd : p.rstd;
       a.in_drop_mode = dm; a.in_drop_seed = r->seed; a.in_drop_layer = (uint32_t)pre_layer;
       a.in_repeat = pre_rep;
+      a.in_split = pre_split_ ? 1 : 0;
     }
     a.seed_dev = r->seed_dev;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
@@ -274,7 +276,16 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
         float* scratch = fuse0 ? p.A[0] : p.CAT[0];
         VX_STEP(kConv[0], first_conv(scratch, V, 1, nullptr, nullptr, inorm ? p.stats : nullptr));
         if (inorm) VX_STEP(kFin[0], vx_instnorm_finalize(p.stats, V, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
-        if (fuse_norm) { in2 = scratch; pre_layer = 0; pre_rep = rep; }
+        if (fuse_norm) {
+          in2 = scratch; pre_layer = 0; pre_rep = rep;
+          // InstanceNorm + LeakyReLU + the fp16 split of the shared tensor ONCE per volume (in place); contr_1_2's staging
+          // waves then only AND sample n's dropout bits in -- a third of their vector work (they are that layer's critical
+          // path: tools/stamp_s16.py)
+          if (dm != VX_DROP_MASK && !vx_cfg().s16_no_presplit) {
+            VX_STEP("presplit:contr_1_1", vx_prenorm_split(scratch, p.mean, p.rstd, V, L.nvox, dm == VX_DROP_HASH ? 2.f : 1.f, stream));
+            pre_split_ = true;
+          }
+        }
         else VX_STEP(kNorm[0], norm(p.CAT[0], C, p.A[0], C, 0, nullptr, L, 0, rep, 0, 0, nullptr, nullptr, inorm));
       } else {
         VX_STEP(kConv[0], first_conv(p.A[0], N, rep, r->src, r->flip, inorm ? p.stats : nullptr));
@@ -294,6 +305,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_LRELU, 2 * l, nullptr, 0));
     }
     ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+    struct ClearSplit { bool& f; ~ClearSplit() { f = false; } } clear_split_{pre_split_};   // the flag covers this level's second conv only
     if (!inorm) {
       // second conv of the block with its activation / dropout fused; one streaming pass copies it into the skip half of
       // the concat buffer and pools it (no normalisation, no activation)

@@ -364,6 +364,13 @@ typedef struct vx_conv2d_args {
   int32_t N, H, W, Cin, Cout, KS, S;        /* KS in {1,3}; S in {1,2} (1x1: S = 1) */
   float* stats_partial;                     /* nullable */
   int32_t w_family;                         /* vx_conv2d_family(Cin, Cout, KS) at the time w_packed was packed */
+  /* Optional PROLOGUE (split-fp16 kernels only): `in` is the RAW output of the previous conv; y = x * in_scale[g][c] +
+   * in_shift[g][c] (the training-mode BatchNorm folded by vx_bn_finalize[_groups]), then ReLU if in_relu, are applied
+   * while the tile is staged -- conv2(relu(bn1(conv1(x)))) of BasicBlock / Bottleneck (hrnet_module.py:59-77, 99-119)
+   * without the pass that would write the activated tensor.  g = n / in_group_images (0: one group), rows in_cpitch
+   * floats apart.  Zero padding is that of the ACTIVATED tensor. */
+  const float* in_scale; const float* in_shift;   /* nullable together */
+  int32_t in_cpitch, in_group_images, in_relu;
 } vx_conv2d_args;
 int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS);
 int vx_pack_conv2d(const float* w_torch /* (Cout,Cin,KS,KS) */, float* w_packed, int Cin, int Cout, int KS, vx_stream_t stream);

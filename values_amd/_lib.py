@@ -58,7 +58,8 @@ class Conv2dArgs(C.Structure):
     _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
                 ("N", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Cout", _i32), ("KS", _i32), ("S", _i32),
-                ("stats_partial", _p), ("w_family", _i32)]
+                ("stats_partial", _p), ("w_family", _i32),
+                ("in_scale", _p), ("in_shift", _p), ("in_cpitch", _i32), ("in_group_images", _i32), ("in_relu", _i32)]
 
 
 class AffineArgs(C.Structure):

@@ -415,6 +415,10 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
   ka.OW = (a.W + 2 * (a.KS / 2) - a.KS) / a.S + 1;
   if ((int64_t)(a.H + 2) * a.W * a.in_pitch * 4 >= (1ll << 31) || (int64_t)ka.OH * ka.OW * a.out_pitch * 4 >= (1ll << 31))
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: one image must stay below 2 GiB");
+  if ((a.in_scale == nullptr) != (a.in_shift == nullptr)) VX_FAIL(VX_E_NULL, "vx_conv2d: in_scale / in_shift must come together");
+  if (a.in_scale && (a.in_cpitch < a.Cin - 15 || a.in_group_images < 0 || !c2_split16()))
+    VX_FAIL(VX_E_SHAPE, "vx_conv2d: the input prologue needs rows of in_cpitch >= the real channel count and the split-fp16 "
+            "kernels (vx_config.conv_fp32 = 0)");
   if (c2_split16()) return vx_conv2d_s16(a, (hipStream_t)stream);
   C2Cfg c = c2_config(a.KS, a.S, a.Cout);
   ka.tiles_x = (ka.OW + 15) / 16;

@@ -157,6 +157,12 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 
   const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
   f32x4 ibuf[IN_IT], wbuf[W_IT];
+  // prologue (vx_conv2d_args.in_scale): the folded BatchNorm of the PRODUCING conv (+ ReLU) applied on the way into LDS.
+  // The scale / shift rows of the item's image group are staged into a small LDS table by prefetch() (after the second
+  // barrier of the previous item: commit() of this item reads them behind the next barrier).
+  const bool pre = a.in_scale != nullptr;
+  float* s_ss = smem + IN_FLOATS + W_FLOATS + NW * NT * 16 * 2;    // [scale | shift][NSUB * 16] of the item's chunk
+  unsigned p_bad = 0;
   const bool w_resident = ka.nchunks == 1;
   bool w_fresh = true;
 
@@ -179,6 +185,19 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
       const unsigned vo = b ? K_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
+    if (pre) {
+      p_bad = bad;
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it)
+        if (NSUB > 1 && (int)isub[it] >= nsub) p_bad |= 1u << it;
+      // this chunk's channels of the image's statistics group (channels beyond Cin: scale = shift = 0 -> zeros)
+      if (tid < 2 * NSUB * 16) {
+        const int which = tid / (NSUB * 16), c = tid % (NSUB * 16), ch = chunk * NSUB * 16 + c;
+        const int grp = a.in_group_images > 0 ? (have ? n : 0) / a.in_group_images : 0;
+        const float* row = (which ? a.in_shift : a.in_scale) + (size_t)grp * a.in_cpitch;
+        s_ss[tid] = ch < a.Cin ? row[ch] : 0.f;
+      }
+    }
     const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * W_FLOATS);
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
@@ -193,6 +212,20 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     for (int it = 0; it < IN_IT; ++it)
       if (tid + it * NTH < NPIECE) {
         f16x4 hi, lo;
+        if (pre) {
+          const int c = (int)isub[it] * 16 + (tid & 3) * 4;           // NTH % 4 == 0: the lane's quad is idx % 4 in every iteration
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_ss + c);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(s_ss + NSUB * 16 + c);
+          f32x4 v = ibuf[it];
+          const bool zero = (p_bad >> it) & 1u;                        // zero padding belongs to the activated tensor
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = v[j] * sc[j] + sh[j];                            // vx_affine_gather's arithmetic (two roundings: -ffp-contract=off)
+            if (a.in_relu) t = fmaxf(t, 0.f);
+            v[j] = zero ? 0.f : t;
+          }
+          ibuf[it] = v;
+        }
         split4(ibuf[it], hi, lo);
         *reinterpret_cast<f16x4*>(s_hi + ldst[it]) = hi;
         *reinterpret_cast<f16x4*>(s_lo + ldst[it]) = lo;
@@ -432,7 +465,8 @@ static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
   constexpr int PLANE = ((S * S * NPP + 15) / 16) * 16;
   constexpr int IMG_H = NSUB * 2 * PLANE * 8;
   constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;
-  constexpr size_t lds = (size_t)IMG_H * 4 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)8 * NT * 16 * 2 * 4;
+  constexpr size_t lds = (size_t)IMG_H * 4 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)8 * NT * 16 * 2 * 4 +
+                         (size_t)2 * NSUB * 16 * 4;   // + the prologue's scale / shift table
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY>;

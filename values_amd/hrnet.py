@@ -328,7 +328,10 @@ class HighResolutionNet(nn.Module):
         return packed
 
     # ------------------------------------------------------------------ kernel wrappers
-    def _conv(self, x: _Act, name, stats=True):
+    def _conv(self, x: _Act, name, stats=True, pre=None):
+        """pre = (scale, shift): `x` is the RAW output of the previous conv and relu(x * scale + shift) -- its training-mode
+        BatchNorm + ReLU -- is applied while this conv stages its tiles (vx_conv2d_args.in_scale): the affine pass that
+        would write the activated tensor (and the read of it) disappear."""
         lib = _lib.load()
         wp, b, cin, cout, ks, stride, _w, fam = self._pk[name]
         cin_pad = (cin + 15) // 16 * 16
@@ -364,6 +367,11 @@ class HighResolutionNet(nn.Module):
         if stats:
             part = torch.empty((ntiles, cout, 2), dtype=torch.float32, device=x.t.device)
             a.stats_partial = part.data_ptr()
+        if pre is not None:
+            scale, shift = pre
+            a.in_scale, a.in_shift, a.in_relu = scale.data_ptr(), shift.data_ptr(), 1
+            a.in_cpitch = x.C                                   # rows of scale / shift [G][C] (C = the padded channel count)
+            a.in_group_images = (n // self._groups) if self._groups > 1 else 0
         prof = getattr(self, "_prof", None)
         if prof is not None:       # diagnostic (profile_forward): a HIP event pair around the launch, on its stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -378,9 +386,9 @@ class HighResolutionNet(nn.Module):
         act.real_c = cout
         return act, part, ntiles
 
-    def _conv_bn(self, x: _Act, conv_name, bn_name):
+    def _conv_bn(self, x: _Act, conv_name, bn_name, pre=None):
         lib = _lib.load()
-        raw, part, ntiles = self._conv(x, conv_name)
+        raw, part, ntiles = self._conv(x, conv_name, pre=pre)
         gamma, beta = self._pk[bn_name]
         creal = raw.real_c
         G = self._groups
@@ -400,6 +408,16 @@ class HighResolutionNet(nn.Module):
                    "vx_bn_finalize " + bn_name)
         self._hold += [ss]
         return raw, scale, shift
+
+    def _fold(self) -> bool:
+        import os
+        return _lib.get_config().conv_fp32 == 0 and not os.environ.get("VX_HRNET_NO_FOLD")
+
+    def _conv_bn_after(self, r, conv_name, bn_name):
+        """conv + BatchNorm statistics of relu(bn(r)): r = (raw, scale, shift) of the previous conv"""
+        if self._fold():
+            return self._conv_bn(r[0], conv_name, bn_name, pre=(r[1], r[2]))
+        return self._conv_bn(self._aff(r[0], r[1], r[2], relu=True), conv_name, bn_name)
 
     def _aff(self, x: _Act, scale=None, shift=None, relu=False, add: Optional[_Act] = None, out: Optional[_Act] = None,
                out_coff=0, size=None, drop=None):
@@ -448,16 +466,15 @@ class HighResolutionNet(nn.Module):
 
     # ------------------------------------------------------------------ network walk
     def _block(self, x: _Act, p: str, blk: _Block) -> _Act:
+        # relu(bn(conv)) feeding the next conv of the block is never written: that conv applies it on load (FOLD; the
+        # separate affine pass remains behind VX_HRNET_NO_FOLD=1 for A/B and for the native-fp32 kernels)
         if blk.kind == "BASIC":
             r1 = self._conv_bn(x, p + ".conv1", p + ".bn1")
-            a1 = self._aff(r1[0], r1[1], r1[2], relu=True)
-            r2 = self._conv_bn(a1, p + ".conv2", p + ".bn2")
+            r2 = self._conv_bn_after(r1, p + ".conv2", p + ".bn2")
         else:
             r1 = self._conv_bn(x, p + ".conv1", p + ".bn1")
-            a1 = self._aff(r1[0], r1[1], r1[2], relu=True)
-            rm = self._conv_bn(a1, p + ".conv2", p + ".bn2")
-            a2 = self._aff(rm[0], rm[1], rm[2], relu=True)
-            r2 = self._conv_bn(a2, p + ".conv3", p + ".bn3")
+            rm = self._conv_bn_after(r1, p + ".conv2", p + ".bn2")
+            r2 = self._conv_bn_after(rm, p + ".conv3", p + ".bn3")
         res = x
         if blk.downsample is not None:
             rd = self._conv_bn(x, p + ".downsample.0", p + ".downsample.1")
@@ -505,11 +522,10 @@ class HighResolutionNet(nn.Module):
                     term = (r[0], r[1], r[2], (xs[i].H, xs[i].W))
                 else:
                     t = xs[j]
+                    r = None
                     for k in range(i - j):
                         q = f"{p}.fuse_layers.{i}.{j}.{k}"
-                        r = self._conv_bn(t, q + ".0", q + ".1")
-                        if k != i - j - 1:
-                            t = self._aff(r[0], r[1], r[2], relu=True)
+                        r = self._conv_bn(t, q + ".0", q + ".1") if r is None else self._conv_bn_after(r, q + ".0", q + ".1")
                     term = (r[0], r[1], r[2], None)
                 if y is None:
                     y = self._aff(term[0], term[1], term[2], relu=last, size=term[3])
@@ -530,11 +546,11 @@ class HighResolutionNet(nn.Module):
                     r = self._conv_bn(ys[i], f"{tname}.{i}.0", f"{tname}.{i}.1")
                     out.append(self._aff(r[0], r[1], r[2], relu=True))
             else:
-                t = ys[-1]
+                r = None
                 for j in range(len(tl)):
-                    r = self._conv_bn(t, f"{tname}.{i}.{j}.0", f"{tname}.{i}.{j}.1")
-                    t = self._aff(r[0], r[1], r[2], relu=True)
-                out.append(t)
+                    nm = f"{tname}.{i}.{j}"
+                    r = self._conv_bn(ys[-1], nm + ".0", nm + ".1") if r is None else self._conv_bn_after(r, nm + ".0", nm + ".1")
+                out.append(self._aff(r[0], r[1], r[2], relu=True))
         return out
 
     def _backbone(self, x: torch.Tensor) -> List[_Act]:
@@ -546,8 +562,7 @@ class HighResolutionNet(nn.Module):
         self._hold.append(xin)
         a = _Act(xin, 16)
         r = self._conv_bn(a, "conv1", "bn1")
-        a = self._aff(r[0], r[1], r[2], relu=True)
-        r = self._conv_bn(a, "conv2", "bn2")
+        r = self._conv_bn_after(r, "conv2", "bn2")
         a = self._aff(r[0], r[1], r[2], relu=True)
         for b, blk in enumerate(self.layer1):
             a = self._block(a, f"layer1.{b}", blk)
@@ -574,8 +589,10 @@ class HighResolutionNet(nn.Module):
         outs = []
         for head in (("last_layer",) + (("cov_factor_conv",) if self.ssn else ())):
             r = self._conv_bn(cat, head + ".0", head + ".1")
-            y = self._aff(r[0], r[1], r[2], relu=True)
-            raw, _, _ = self._conv(y, head + ".3", stats=False)
+            if self._fold():
+                raw, _, _ = self._conv(r[0], head + ".3", stats=False, pre=(r[1], r[2]))
+            else:
+                raw, _, _ = self._conv(self._aff(r[0], r[1], r[2], relu=True), head + ".3", stats=False)
             outs.append(raw)
         return outs
 
@@ -592,8 +609,10 @@ class HighResolutionNet(nn.Module):
             self._aff(f, out=cat, out_coff=off, size=(h0, w0), drop=drop)   # dropout -> bilinear -> concat slot
             off += f.C
         r = self._conv_bn(cat, "last_layer.0", "last_layer.1")
-        y = self._aff(r[0], r[1], r[2], relu=True)
-        raw, _, _ = self._conv(y, "last_layer.3", stats=False)
+        if self._fold():
+            raw, _, _ = self._conv(r[0], "last_layer.3", stats=False, pre=(r[1], r[2]))
+        else:
+            raw, _, _ = self._conv(self._aff(r[0], r[1], r[2], relu=True), "last_layer.3", stats=False)
         _lib.check(lib.vx_bilinear_nchw(_lib.ptr(raw.t), raw.pitch, n, h0, w0, self.num_classes, size[0], size[1],
                                         _lib.ptr(out), _lib.ptr(dst), _lib.ptr(flip), self._st), "vx_bilinear_nchw")
 

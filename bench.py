@@ -360,6 +360,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
                     help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
+    ap.add_argument("--storage16", action="store_true",
+                    help="C2: ALSO time the opt-in reduced-storage mode (vx_config.storage16: expand_1_1's tensor stored as fp16) and "
+                         "print it as a side object with its measured deviation from the default path; `value` stays the default path")
     ap.add_argument("--graph", action="store_true", help="C2: replay the step as one captured hipGraph (GraphedPredictor)")
     ap.add_argument("--no-gather", action="store_true", help="C2, N > 1: leave the maps on the ranks that computed them (default: "
                     "every step's maps are gathered on rank 0 inside the timed region, the metric SURVEY 8d defines)")
@@ -472,6 +475,26 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
         side = timed_regions(step_local, local.flush, barrier, args.steps, 1, min(3, max(1, args.repeats)), reduce_max)
     model.check_range()      # the fp16-range word keeps the running maximum over every step above
 
+    st16 = None
+    if args.storage16:
+        # opt-in reduced-storage throughput mode: never `value` (it cannot meet the 1e-4 parity of the maps); what it buys and
+        # what it costs, measured on the same volumes and dropout seeds as the default path
+        from values_amd import _lib
+        ref_out = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+        ref_maps = {k: ref_out[k].clone() for k in ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax")}
+        ref_seg = ref_out["pred_seg_mean"].clone()
+        with _lib.config(storage16=1):
+            red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+            dev_maps = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
+            flips = int((red["pred_seg_mean"] != ref_seg).sum().item())
+            t16 = timed_regions(step, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+        s16 = summarise(t16, V * world * args.steps, args.steps)
+        st16 = {"value": s16["value"], "ms_per_step": s16["ms_per_step"], "unit": "volumes/s",
+                "max_abs_diff_vs_default_path": dev_maps, "argmax_flips": flips, "voxels": int(ref_seg.numel()),
+                "note": "vx_config.storage16 = 1: expand_1_1 -> expand_1_2 tensor stored as fp16 (2 instead of 3 matrix products "
+                        "in expand_1_2); NOT the default, NOT within the 1e-4 parity bar -- the deviation from the float64 "
+                        "oracle is asserted in tests/test_gpu_unet3d.py::test_storage16_mode_reports_its_deviation..."}
+
     pcie = None
     if args.pcie and world == 1:
         # host-inclusive variant: volumes start in pinned host memory, the maps end there; never reported as `value`.
@@ -522,6 +545,8 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
         ss = summarise(side, V * world * args.steps, args.steps)
         line["no_gather"] = {"value": ss["value"], "ms_per_step": ss["ms_per_step"],
                              "note": "same steps, maps left on the ranks that computed them"}
+    if st16 is not None:
+        line["storage16"] = st16
     if lat is not None:
         line["latency_single_volume"] = lat
     if detail is not None:

@@ -79,6 +79,9 @@ typedef struct vx_config {
   int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
   int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
   int32_t s16_no_poolfuse; /* separate pooling pass over contr_1_2's output instead of the window maxima from its epilogue */
+  int32_t storage16;       /* OPT-IN reduced-storage throughput mode (default 0): expand_1_1's full-resolution output is stored
+                              as fp16 and expand_1_2 consumes it unsplit (2 instead of 3 matrix products).  Maps then differ from
+                              the float64 reference by ~1e-3: bench.py --storage16 reports the measured differences */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
 } vx_config;
@@ -215,6 +218,10 @@ typedef struct vx_conv3d_args {
    * the shared raw tensor already normalised, activated and split into fp16 (hi, lo) pairs, ONCE per volume; the prologue
    * then only applies sample n's dropout bits (in_drop_*) while the tile is staged.  in_mean / in_rstd are not read. */
   int32_t in_split;
+  /* Reduced-storage mode (vx_config.storage16; opt-in, NOT the default: an activation rounded to fp16 cannot meet the 1e-4
+   * parity of the maps): out_f16 -- the LeakyReLU + dropout epilogue stores fp16 (out_pitch counts halves); in_f16 -- the
+   * dense 8-channel input is such a tensor: it is copied into the hi plane unsplit and the lo-activation product is skipped. */
+  int32_t out_f16, in_f16;
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */

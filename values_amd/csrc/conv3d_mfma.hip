@@ -736,7 +736,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   }
   const bool tile_pre = a.in_mean && c.S16 && vx_conv3d_s16_prologue_ok(a.Cin, a.Cout) && !a.in_xblk && a.in_pitch == a.Cin &&
                         a.in_drop_mode != VX_DROP_MASK;
-  if ((a.in_mean && !tile_pre) || a.out_xblk || a.up_in || a.pool_out || a.in_split)
+  if ((a.in_mean && !tile_pre) || a.out_xblk || a.up_in || a.pool_out || a.in_split || a.in_f16 || a.out_f16)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);

@@ -52,8 +52,13 @@ struct Xp8wArgs {
 // max(2 f(max over the KEPT x), 0 if any element was dropped): the epilogue writes the maximum of the kept RAW values and
 // an any-dropped bit per channel; vx_pool_finish applies the statistics to 1/8 of the voxels later.  For this a consumer
 // wave owns 2 rows x 2 planes (whole windows in one lane pair) instead of 4 rows of one plane.
-template <int NCH, int EPI, int PRE, int UP, int NPW>
+// IN16 (opt-in reduced-storage mode, vx_config.storage16): the input tensor is stored as fp16 -- every value IS its own hi
+// part, the lo plane is zero: the staging waves copy 8 bytes per piece without a split, the multiplying waves skip the
+// lo-activation product (2 matrix instructions per product instead of 3).  Not the default: a tensor rounded to fp16
+// (2^-11 relative) cannot meet the 1e-4 parity of the maps.
+template <int NCH, int EPI, int PRE, int UP, int NPW, int IN16 = 0>
 __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka) {
+  static_assert(IN16 == 0 || (NCH == 1 && PRE == 0 && UP == 0), "fp16 input: one-chunk layers without a prologue");
   static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
   constexpr int NW = 8, NTH = (NW + NPW) * 64;
   constexpr int TZ = 4 / NCH;
@@ -157,7 +162,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // then the odd ones: 16 consecutive lanes write 128 contiguous bytes of ONE parity plane (natural order: 2-way conflicts)
     const int l_hx = (lane >> 5) ? 1 + (lane & 30) : 2 + (lane & 30);
     const int l_dx = l_hx - 1;
-    const unsigned l_voff = (unsigned)((xpart(l_dx, 0) + biasf) * 4);      // chunk term rides in the row's scalar offset
+    constexpr int ISZ = IN16 ? 2 : 4;                                      // bytes per input element
+    const unsigned l_voff = (unsigned)((xpart(l_dx, 0) + biasf) * ISZ);    // chunk term rides in the row's scalar offset
     const int l_lds = (l_hx & 1) * PP * 8 + (l_hx >> 1) * 8 + qq * 4;      // halves
     const int l_bp = 4 * (l_dx >> 2);                                      // ds_bpermute address of this lane's keep-word within its row
     const unsigned l_sh = (unsigned)((l_dx & 3) * 8 + qq * 4);             // first of its four bits in that word
@@ -182,7 +188,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       int lch, r, dzy, dy, pz;
       unit_geo(unit_of(i), lch, r, dzy, dy, pz);
       if (!LIN || i == 0) {
-        u_soff[LIN ? 0 : i] = (dzy * rowf + (xpart(0, lch) - xpart(0, 0))) * 4;
+        u_soff[LIN ? 0 : i] = (dzy * rowf + (xpart(0, lch) - xpart(0, 0))) * ISZ;
         u_lds[LIN ? 0 : i] = lch * CHUNK_H + r * HXP * 8;
       }
       if (unit_of(i) < NU) um_valid |= 1u << i;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       else um_zl |= 1u << i;                           // step KZ: plane D does not exist
       if (PRE != 0 && (NCH == 1 || lch == 1)) um_pre |= 1u << i;
     }
-    const int row_soff_step = rowf * 4;
+    const int row_soff_step = rowf * ISZ;
     // keep-word this lane computes in hash round rd: word (lane & 7) of row slot 8 rd + (lane >> 3)
     int l_hw[PRE ? HR : 1];
     if constexpr (PRE != 0) {
@@ -214,7 +220,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       int lch, r, dzy, dy, pz;
       unit_geo(hp >> 2, lch, r, dzy, dy, pz);
       const int dx = side ? 32 : -1, hx = dx + 1;
-      h_voff = (unsigned)((dzy * rowf + xpart(dx, lch) + biasf) * 4);
+      h_voff = (unsigned)((dzy * rowf + xpart(dx, lch) + biasf) * ISZ);
       h_lds = lch * CHUNK_H + (hx & 1) * PP * 8 + (r * HXP + (hx >> 1)) * 8 + qq * 4;
       h_erel = (unsigned)((dzy * a.W + dx) * 8 + qq * 4);
       h_flags = (hp >= NH ? 1u : 0u) | (side ? 4u : 2u) | (dy < 0 ? 8u : 0u) | (dy >= 8 ? 16u : 0u) | (pz < TZ - 1 ? 32u : 64u) |
@@ -268,7 +274,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const size_t up_sample = (size_t)(a.D >> 1) * Hc * urow;
 
     // ---- register staging: the loads of one step (and what its commit needs to know) ----
-    f32x4 ibuf[RPW], hbuf = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ibuf[IN16 ? 1 : RPW], hbuf = {0.f, 0.f, 0.f, 0.f};
+    // fp16 input: 8 bytes per piece, kept as integer pairs (hipcc 7.2 narrows a 64-bit buffer load to ONE dword when its
+    // halves travel through float lanes of a wider vector -- the second dword was garbage; tools/micro/load_b64_narrow.hip)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 ibuf16[IN16 ? RPW : 1], hbuf16 = {0u, 0u};
     f32x4 ubuf[UP ? UT : 1];
     unsigned p_ubad = 0;
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
@@ -286,9 +296,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (c.s == KZ) bad |= um_zl;
       if (!have) bad = 0xFFFFFFFFu;
       const int nin = n / in_rep;
-      const int soff = (((TZ * c.s) * a.H + ty * 8) * rowf + tx * 32 * voxf) * 4;
+      const int soff = (((TZ * c.s) * a.H + ty * 8) * rowf + tx * 32 * voxf) * ISZ;
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.in + (size_t)nin * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+          (void*)(reinterpret_cast<const char*>(a.in) + ((size_t)nin * in_sample - biasf) * ISZ), 0, VX_NUMREC, 0x00020000);
       // NO branch may enclose a load: behind a join the compiler's wait-count bookkeeping gives up and waits for EVERY load
       // in flight (s_waitcnt vmcnt(0) in the middle of this function: the whole memory latency, every step -- measured
       // 2 400 cycles).  A row outside the volume reads through an out-of-range offset instead (zeros, no memory access).
@@ -296,7 +306,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int i = 0; i < RPW; ++i) {
         const int so = soff + (LIN ? u_soff[0] + i * row_soff_step : u_soff[LIN ? 0 : i]);
         const bool rb = (bad >> i) & 1u;
-        ibuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0));
+        if constexpr (IN16 != 0) {
+          ibuf16[i] = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0);
+        } else {
+          ibuf[IN16 ? 0 : i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0));
+        }
       }
       p_rowbad = bad;
       {
@@ -309,7 +323,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if (c.s == KZ) hb |= 64u;
         if (!have) hb = 0x7Fu;
         const bool lbad = (h_flags & hb) != 0u;      // waves without a halo iteration: flag 1 in every lane
-        hbuf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0));
+        if constexpr (IN16 != 0) {
+          hbuf16 = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0);
+        } else {
+          hbuf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0));
+        }
         p_hbad = lbad;
       }
       if constexpr (UP != 0) {
@@ -404,7 +422,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int i = 0; i < RPW; ++i) {
         if (!LIN && !((um_valid >> i) & 1u)) continue;       // (only the last unit of a wave can be missing)
         _Float16* dst = s_img + gofs + l_lds + (LIN ? u_lds[0] + i * (HXP * 8) : u_lds[LIN ? 0 : i]);
-        f32x4 v = ibuf[i];
+        if constexpr (IN16 != 0) {     // the stored halves ARE the hi plane; nobody reads a lo plane in this mode
+          *reinterpret_cast<f16x4*>(dst) = __builtin_bit_cast(f16x4, ibuf16[i]);
+          continue;
+        }
+        f32x4 v = ibuf[IN16 ? 0 : i];
         f16x4 hi, lo;
         if constexpr (PRE == 2) {
           // pre-split input (vx_prenorm_split): only this sample's keep bits are left to apply (a row outside the volume
@@ -431,7 +453,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (has_halo && !(h_flags & 1u)) {
         f32x4 v = hbuf;                      // zeros where the piece lies outside the volume (out-of-range load)
         f16x4 hi, lo;
-        if constexpr (PRE == 2) {
+        if constexpr (IN16 != 0) {
+          hi = __builtin_bit_cast(f16x4, hbuf16);
+          lo = (f16x4){0, 0, 0, 0};
+        } else if constexpr (PRE == 2) {
           masked_piece(v, hashed ? vx_drop_bits4(p_key, p_e0 + h_erel) : 0xFu, hi, lo);
         } else {
           if constexpr (PRE == 1) {
@@ -526,7 +551,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         const int oxb = a.out_xblk;
         ovoff[r] = (unsigned)((((tz_ * a.H + ty_) * (2 * a.W * 8)) + ((lx / oxb) * 2 + a.out_half) * oxb * 8 + (lx % oxb) * 8 + oc) * 4);
       } else {
-        ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * 4);
+        ovoff[r] = (unsigned)((ovox * a.out_pitch + a.out_coff + oc) * (a.out_f16 ? 2 : 4));
       }
       eoff[r] = (unsigned)(ovox * 8 + oc);
     }
@@ -614,11 +639,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           int slot = rb + lz + kz;
           if (slot >= NZ) slot -= NZ;
           const _Float16* row0 = img + slot * (ZP * 8);
-          f16x8 bh[R + 2], bl[R + 2];
+          f16x8 bh[R + 2], bl[IN16 ? 1 : R + 2];
 #pragma unroll
           for (int jr = 0; jr < R + 2; ++jr) {
             bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8);
-            bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
+            if constexpr (IN16 == 0) bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
@@ -630,8 +655,12 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
               const bool fresh = chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
               const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
+              if constexpr (IN16 == 0) {
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
+              } else {                                                   // fp16 input: its lo part is zero
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], fresh ? zero : accx[r], 0, 0, 0);
+              }
             }
           }
         }
@@ -665,8 +694,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       const unsigned osoff = a.out_xblk ? (unsigned)((((k * TZ) * a.H + e_ty * 8) * (2 * a.W * 8) + e_tx * 32 * 16) * 4)
                                         : vox0 * (unsigned)a.out_pitch * 4u;
       const unsigned e0 = vox0 * 8u;
-      const __amdgpu_buffer_rsrc_t osrd =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)e_n * out_sample), 0, VX_NUMREC, 0x00020000);
+      const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(reinterpret_cast<char*>(a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v = acc[r] + accx[r] * (1.0f / 2048.f);
@@ -711,7 +740,13 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           }
         } else {
           rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)ovoff[r], (int)osoff, 0);
+          if (EPI == 1 && a.out_f16) {     // reduced-storage mode: the tensor leaves as fp16 (out_pitch in halves)
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const f16x4 h4 = __builtin_convertvector(v, f16x4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), osrd, (int)ovoff[r], (int)(osoff >> 1), 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)ovoff[r], (int)osoff, 0);
+          }
           // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_nop 3" ::: "memory");
@@ -848,13 +883,13 @@ bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout) {
   return Cout == 8 && (Cin == 8 || Cin == 16) && W % 32 == 0 && H % 8 == 0 && D % 4 == 0 && W >= 32 && H >= 8 && D >= 8;
 }
 
-template <int NCH, int EPI, int PRE, int UP, int NPW>
+template <int NCH, int EPI, int PRE, int UP, int NPW, int IN16 = 0>
 static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
   constexpr int TZ = 4 / NCH, NZ = 3 * TZ, ZP = 170;
   constexpr int PP = ((NZ * ZP + 15) / 16) * 16;
   constexpr size_t lds = (size_t)NCH * 2 * 2 * PP * 8 * 2 + (size_t)NCH * (9 * 2 * 32 * 8) * 2 + 8 * 16 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3d_xp8w_kernel<NCH, EPI, PRE, UP, NPW>;
+  auto kern = conv3d_xp8w_kernel<NCH, EPI, PRE, UP, NPW, IN16>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -864,7 +899,8 @@ static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
   int gx = 256;
   if (vx_cfg().s16_per_cu > 0) gx = 256 * vx_cfg().s16_per_cu;
   if (gx > ka.ncols) gx = ka.ncols;
-  static const char* kname = vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW);
+  static const char* kname = IN16 ? vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW, IN16)
+                                  : vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW);
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3((8 + NPW) * 64), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(xp8w)");
@@ -910,6 +946,13 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   // (the pooling epilogue holds 8 image rows + the window state: 128 VGPRs at 16 waves would spill 28 dwords)
   const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 4 ? 4 : 8);
   if (a.pool_out && nch != 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): the pooled output goes with Cin = 8");
+  if (a.out_f16 && (epi != 1 || a.out_xblk || a.out_coff))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): fp16 output goes with the LeakyReLU + dropout epilogue and a dense output tensor");
+  if (a.in_f16) {
+    if (!(nch == 1 && epi == 2 && pre == 0 && !up && !a.in_xblk))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): fp16 input goes with the dense 8-channel layer that carries the fused head");
+    return npw == 8 ? launch_xp8w<1, 2, 0, 0, 8, 1>(ka, s) : launch_xp8w<1, 2, 0, 0, 4, 1>(ka, s);
+  }
 #define XP8W_CASE(N_, E_, P_, U_)                                                         \
   if (nch == N_ && epi == E_ && pre == P_ && up == U_)                                    \
     return npw == 8 ? launch_xp8w<N_, E_, P_, U_, 8>(ka, s) : launch_xp8w<N_, E_, P_, U_, 4>(ka, s)

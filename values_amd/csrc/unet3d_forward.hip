@@ -147,6 +147,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   bool pre_split_ = false;           // set around the contr_1_2 launch when its input went through vx_prenorm_split
+  int st16_ = 0;                     // reduced-storage mode: 1 around expand_1_1's launch (fp16 output), 2 around expand_1_2's (fp16 input)
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
@@ -179,6 +180,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       a.in_split = pre_split_ ? 1 : 0;
     }
     a.seed_dev = r->seed_dev;
+    a.out_f16 = st16_ == 1 ? 1 : 0;
+    a.in_f16 = st16_ == 2 ? 1 : 0;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     if (pool_raw_ && wi == 1) {   // contr_1_2 also leaves the window maxima of its block's MaxPool (dropout layer 1)
       a.pool_out = pool_raw_; a.pool_flags = pool_flags_;
@@ -246,6 +249,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // vx_pool_finish on 1/8 of the voxels) instead of a pass that re-reads the full-resolution tensor
   const bool fuse_pool = dm != VX_DROP_MASK && vx_conv3d_k3_poolfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F);
   const bool fuse0 = pre0 && vx_cfg().s16_skip_raw && vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
+  // opt-in reduced-storage mode (vx_config.storage16, never the default): expand_1_1 -> expand_1_2 hand their tensor over as
+  // fp16; needs the z-column kernels on both and the fused head
+  const bool st16 = vx_cfg().storage16 && dm != VX_DROP_MASK && F == 8 && fuse_head && vx_cfg().conv_fp32 == 0 &&
+                    vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F) && dm == VX_DROP_HASH;
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
   const int ICH = w->in_channels > 1 ? w->in_channels : 1;
@@ -353,6 +360,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int wi = 10 + 2 * (3 - l);
     const int dl = 9 + 2 * (3 - l);
     const float* up_in = l == 0 && fuse_up ? p.B[1] : nullptr;
+    st16_ = (l == 0 && st16) ? 1 : 0;     // expand_1_1 leaves A_0 as fp16 (same buffer, half of it used)
     if (l == 0 && fuse0)   // the skip half of CAT_0 is contr_1_2's raw output: normalise + LeakyReLU + dropout layer 1 on load
       VX_STEP(up_in ? "upscale2+expand_1_1" : kConv[wi],
               conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 1, 1,
@@ -362,7 +370,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
                                           xblk_of(L.W), -1, 1, nullptr, nullptr, 0, 0, up_in, 3, 2 * C));
     else
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
+    st16_ = (l == 0 && st16) ? 2 : 0;
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
+    st16_ = 0;
     if (l > 1 || (l == 1 && !fuse_up)) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------

@@ -82,6 +82,8 @@ typedef struct vx_config {
   int32_t storage16;       /* OPT-IN reduced-storage throughput mode (default 0): expand_1_1's full-resolution output is stored
                               as fp16 and expand_1_2 consumes it unsplit (2 instead of 3 matrix products).  Maps then differ from
                               the float64 reference by ~1e-3: bench.py --storage16 reports the measured differences */
+  int32_t s16_no_dbplain;  /* plain (not x-pair) tile layers: two barriers per item on ONE LDS image and the large tile instead of the
+                              staggered double-buffered schedule on the 16 x 4 x 4 tile */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
 } vx_config;

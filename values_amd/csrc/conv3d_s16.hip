@@ -594,10 +594,16 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int p = (vbase[r] + toff[s]) * 8;
-          bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
-          bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
+          bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + cofs + p);
+          bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + cofs + p);
         }
       };
+      if constexpr (SINGLE) {   // one item = one tile: the epilogue does not clear the accumulators
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      }
       load_step(0, 0);
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
@@ -847,6 +853,8 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   return VX_OK;
 }
 
+static inline bool s16_dbplain() { return !vx_cfg().s16_no_dbplain && !vx_cfg().s16_no_db; }
+
 template <int CB, int NT, int XP>
 static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
   // epilogue specialisation of the large-tile instances (EPI in the kernel's header)
@@ -867,6 +875,19 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
     if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3) {   // 16 -> 8 channels
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 1>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 3>(ka, s);
+    }
+  }
+  if constexpr (XP == 0) {
+    // Round 3: single-chunk plain layers on two LDS images with staggered SIMD partners (DB = 2) WHERE THE LAYER'S TILE FITS
+    // TWICE: -11 % on 16 -> 32 at 16^3.  Shrinking the tile to make room loses more than the stagger wins: the 16-channel
+    // chunks at 32^3 on 16 x 4 x 4 instead of 16 x 8 x 4 were 14-15 % SLOWER double-buffered, and 8 -> 16 at 32^3 (whose large
+    // tile does fit twice) measured neutral (same-process A/B)
+    if (tx == 16 && ka.nchunks == 1 && s16_dbplain()) {
+      if (!ka.ty8) {                             // 16 x 4 x 4 tile (two row tiles, or H < 32)
+        if (epi == 0) return launch_s16<CB, NT, 16, 4, 4, 8, XP, 2, 0>(ka, s);
+        if (epi == 1) return launch_s16<CB, NT, 16, 4, 4, 8, XP, 2, 1>(ka, s);
+        return launch_s16<CB, NT, 16, 4, 4, 8, XP, 2, 3>(ka, s);
+      }
     }
   }
   if constexpr (NT == 1) {   // large layers: 4 column tiles per wave (vx_conv3d_s16_tile: never with two row tiles)

@@ -899,8 +899,7 @@ static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
   int gx = 256;
   if (vx_cfg().s16_per_cu > 0) gx = 256 * vx_cfg().s16_per_cu;
   if (gx > ka.ncols) gx = ka.ncols;
-  static const char* kname = IN16 ? vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW, IN16)
-                                  : vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW);
+  static const char* kname = vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW, IN16);   // as rocprofv3 prints it
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3((8 + NPW) * 64), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(xp8w)");

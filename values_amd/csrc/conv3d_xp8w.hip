@@ -285,20 +285,64 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;   // bit i: row unit i of the staged step lies outside the volume
     bool p_hbad = true;                                      // this lane's halo piece of the staged step lies outside
 
-    auto prefetch = [&](const Cur& c) {
-      const bool have = c.ci < ncol_wg;
+    // per-COLUMN state of the staging (recomputed at step 0 of a column, KZ + 1 steps apart): sample, tile position, the
+    // x / y parts of the validity masks and offsets, the buffer descriptors, the prologue's statistics and dropout key --
+    // per step only the z terms are left (round 3: ~100 scalar instructions and two loads per step gone)
+    bool cs_have = false;
+    unsigned cs_bad = 0xFFFFFFFFu, cs_hb = 0x7Fu, cs_ub = 0xFFFFFFFFu, cs_e0 = 0;
+    int cs_soff = 0;
+    unsigned cs_usoff = 0;
+    __amdgpu_buffer_rsrc_t cs_srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t cs_usrd = cs_srd;
+    auto column_state = [&](int ci) {
+      const bool have = ci < ncol_wg;
       int n = 0, ty = 0, tx = 0;
-      if (have) col_of(c.ci, n, ty, tx);
+      if (have) col_of(ci, n, ty, tx);
+      cs_have = have;
       unsigned bad = ~um_valid;
       if (ty == 0) bad |= um_ylo;
       if (ty == ka.tiles_y - 1) bad |= um_yhi;
+      cs_bad = bad;
+      unsigned hb = 1u;
+      if (tx == 0) hb |= 2u;
+      if (tx == ka.tiles_x - 1) hb |= 4u;
+      if (ty == 0) hb |= 8u;
+      if (ty == ka.tiles_y - 1) hb |= 16u;
+      cs_hb = hb;
+      const int nin = n / in_rep;
+      cs_soff = ((ty * 8) * rowf + tx * 32 * voxf) * ISZ;
+      cs_srd = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(reinterpret_cast<const char*>(a.in) + ((size_t)nin * in_sample - biasf) * ISZ), 0, VX_NUMREC, 0x00020000);
+      if constexpr (UP != 0) {
+        unsigned ub = ub_always;
+        if (tx == 0) ub |= ub_xlo;
+        if (tx == ka.tiles_x - 1) ub |= ub_xhi;
+        if (ty == 0) ub |= ub_ylo;
+        if (ty == ka.tiles_y - 1) ub |= ub_yhi;
+        cs_ub = ub;
+        cs_usoff = (unsigned)(((ty * 4) * urow + tx * 16 * a.up_pitch) * 4);
+        cs_usrd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.up_in + (size_t)n * up_sample - ubiasf), 0, VX_NUMREC, 0x00020000);
+      }
+      if constexpr (PRE == 1) {
+        // (n = 0 when the workgroup has run out of columns: a valid address, no branch around the loads)
+        p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq * 4);
+        p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq * 4);
+      }
+      if constexpr (PRE != 0) {
+        cs_e0 = (unsigned)((ty * 8) * a.W + tx * 32) * 8u;
+        p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
+      }
+    };
+
+    auto prefetch = [&](const Cur& c) {
+      if (c.s == 0) column_state(c.ci);            // (a wave-uniform branch BEFORE the loads, nothing in flight at the join)
+      const bool have = cs_have;
+      unsigned bad = cs_bad;
       if (c.s == 0) bad |= um_zf;
       if (c.s == KZ) bad |= um_zl;
       if (!have) bad = 0xFFFFFFFFu;
-      const int nin = n / in_rep;
-      const int soff = (((TZ * c.s) * a.H + ty * 8) * rowf + tx * 32 * voxf) * ISZ;
-      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<const char*>(a.in) + ((size_t)nin * in_sample - biasf) * ISZ), 0, VX_NUMREC, 0x00020000);
+      const int soff = cs_soff + ((TZ * c.s) * a.H) * rowf * ISZ;
+      const __amdgpu_buffer_rsrc_t srd = cs_srd;
       // NO branch may enclose a load: behind a join the compiler's wait-count bookkeeping gives up and waits for EVERY load
       // in flight (s_waitcnt vmcnt(0) in the middle of this function: the whole memory latency, every step -- measured
       // 2 400 cycles).  A row outside the volume reads through an out-of-range offset instead (zeros, no memory access).
@@ -314,11 +358,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       }
       p_rowbad = bad;
       {
-        unsigned hb = 1u;
-        if (tx == 0) hb |= 2u;
-        if (tx == ka.tiles_x - 1) hb |= 4u;
-        if (ty == 0) hb |= 8u;
-        if (ty == ka.tiles_y - 1) hb |= 16u;
+        unsigned hb = cs_hb;
         if (c.s == 0) hb |= 32u;
         if (c.s == KZ) hb |= 64u;
         if (!have) hb = 0x7Fu;
@@ -331,31 +371,17 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         p_hbad = lbad;
       }
       if constexpr (UP != 0) {
-        unsigned ub = ub_always;
-        if (tx == 0) ub |= ub_xlo;
-        if (tx == ka.tiles_x - 1) ub |= ub_xhi;
-        if (ty == 0) ub |= ub_ylo;
-        if (ty == ka.tiles_y - 1) ub |= ub_yhi;
+        unsigned ub = cs_ub;
         if (!have || (c.s == 0 && u_pz == 0) || (c.s == KZ && u_pz == 1)) ub = 0xFFFFFFFFu;
-        const unsigned usoff = (unsigned)(((c.s * Hc + ty * 4) * urow + tx * 16 * a.up_pitch) * 4);
-        const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.up_in + (size_t)n * up_sample - ubiasf), 0, VX_NUMREC, 0x00020000);
+        const unsigned usoff = cs_usoff + (unsigned)((c.s * Hc) * urow * 4);
 #pragma unroll
         for (int i = 0; i < UT; ++i) {
           const unsigned vo = ((ub >> i) & 1u) ? VX_OOB : u_voff[i];
-          ubuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(usrd, (int)vo, (int)usoff, 0));
+          ubuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)vo, (int)usoff, 0));
         }
         p_ubad = ub;
       }
-      if constexpr (PRE == 1) {
-        // (n = 0 when the workgroup has run out of columns: a valid address, no branch around the loads)
-        p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)nin * 8 + qq * 4);
-        p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)nin * 8 + qq * 4);
-      }
-      if constexpr (PRE != 0) {
-        p_e0 = (unsigned)(((TZ * c.s) * a.H + ty * 8) * a.W + tx * 32) * 8u;
-        p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
-      }
+      if constexpr (PRE != 0) p_e0 = cs_e0 + (unsigned)(((TZ * c.s) * a.H) * a.W) * 8u;
     };
 
     // the producing block's InstanceNorm + LeakyReLU + Dropout on one piece: (x - mean) * scale with the keep bit ANDed into

@@ -84,6 +84,7 @@ typedef struct vx_config {
                               the float64 reference by ~1e-3: bench.py --storage16 reports the measured differences */
   int32_t s16_no_dbplain;  /* plain (not x-pair) tile layers: two barriers per item on ONE LDS image and the large tile instead of the
                               staggered double-buffered schedule on the 16 x 4 x 4 tile */
+  int32_t s16_no_upsplit;  /* expand_2_2 stores plain floats and the fused up-convolution splits them per step (round 2) */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
 } vx_config;
@@ -224,6 +225,11 @@ typedef struct vx_conv3d_args {
    * parity of the maps): out_f16 -- the LeakyReLU + dropout epilogue stores fp16 (out_pitch counts halves); in_f16 -- the
    * dense 8-channel input is such a tensor: it is copied into the hi plane unsplit and the lo-activation product is skipped. */
   int32_t out_f16, in_f16;
+  /* PRE-SPLIT hand-over of the coarse tensor of the fused up-convolution: out_split -- the (tile-kernel) epilogue stores
+   * every 16-byte piece as [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] fp16 (the layout of vx_prenorm_split) instead of four floats;
+   * up_split -- up_in is such a tensor: the staging waves take the matrix operands as they are (each coarse voxel was split
+   * by four waves per step before).  Same values, same bits. */
+  int32_t out_split, up_split;
 } vx_conv3d_args;
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */

@@ -33,7 +33,8 @@ class ConvArgs(C.Structure):
                 ("in_mean", _p), ("in_rstd", _p), ("in_drop_mode", _i32), ("in_drop_seed", _u32), ("in_drop_layer", _u32),
                 ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p),
                 ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
-                ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32)]
+                ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32),
+                ("out_split", _i32), ("up_split", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -76,7 +77,7 @@ class Config(C.Structure):
         "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
         "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
-        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_presplit")]
+        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit")]
 
 
 class UncOutputs(C.Structure):

@@ -739,7 +739,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if ((a.in_mean && !tile_pre) || a.out_xblk || a.up_in || a.pool_out || a.in_split || a.in_f16 || a.out_f16)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
+  if (a.up_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: up_split goes with the fused up-convolution (up_in)");
   if (c.S16) return vx_conv3d_k3_s16(a, s);
+  if (a.out_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: out_split is an epilogue of the split-fp16 tile kernel");
   if (c.XP) return dispatch_tile_xp<8>(ka, t, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_tile<16, 1>(ka, t, s);
   if (c.CB == 16 && c.NT == 2) return dispatch_tile<16, 2>(ka, t, s);

@@ -506,8 +506,18 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         }
         if (f_store) {
           if (f_range && !bad) rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          u32x4 sv = __builtin_bit_cast(u32x4, v);
+          if (a.out_split) {   // the consumer is the fused up-convolution: hand the piece over as the fp16 pairs it multiplies
+            // (integer lanes all the way: hipcc 7.2 mishandles bit patterns that travel through float lanes of a wider
+            // vector -- tools/micro/load_b64_narrow.hip)
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            f16x4 hi, lo;
+            vx_split4(v, hi, lo);
+            const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+            sv = (u32x4){h2[0], h2[1], l2[0], l2[1]};
+          }
           const unsigned vo = bad ? VX_OOB : ovoff[r] + cshift * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(sv, osrd, (int)vo, (int)osoff, 0);
           // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_nop 3" ::: "memory");

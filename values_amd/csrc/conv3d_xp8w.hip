@@ -502,8 +502,18 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         // the up half of the step: ConvTranspose3d(k = 2, s = 2) of the coarse voxels just loaded, three split products
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f16x4 ubh[UT], ubl[UT];
+        if (a.up_split) {          // the producer of the coarse tensor stored the pairs (vx_conv3d_args.out_split)
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < UT; ++i) split4(ubuf[i], ubh[i], ubl[i]);
+          for (int i = 0; i < UT; ++i) {
+            const u32x4 d = __builtin_bit_cast(u32x4, ubuf[i]);
+            ubh[i] = __builtin_bit_cast(f16x4, (u32x2){d[0], d[1]});
+            ubl[i] = __builtin_bit_cast(f16x4, (u32x2){d[2], d[3]});
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < UT; ++i) split4(ubuf[i], ubh[i], ubl[i]);
+        }
         // vx_split4 writes the lo halves from inline assembly: the compiler does not know a VALU result is about to be a
         // matrix operand and inserts no wait states for it (measured: stale lo operands without this)
         __builtin_amdgcn_sched_barrier(0);
@@ -971,6 +981,8 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   // (the pooling epilogue holds 8 image rows + the window state: 128 VGPRs at 16 waves would spill 28 dwords)
   const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 4 ? 4 : 8);
   if (a.pool_out && nch != 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): the pooled output goes with Cin = 8");
+  if (a.out_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): out_split is an epilogue of the tile kernel");
+  if (a.up_split && !up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): up_split without up_in");
   if (a.out_f16 && (epi != 1 || a.out_xblk || a.out_coff))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): fp16 output goes with the LeakyReLU + dropout epilogue and a dense output tensor");
   if (a.in_f16) {

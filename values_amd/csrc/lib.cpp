@@ -74,6 +74,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_presplit = env_int("VX_S16_NO_PRESPLIT", 0);
   g_cfg.storage16 = env_int("VX_STORAGE16", 0);
   g_cfg.s16_no_dbplain = env_int("VX_S16_NO_DBPLAIN", 0);
+  g_cfg.s16_no_upsplit = env_int("VX_S16_NO_UPSPLIT", 0);
 }
 
 const vx_config& vx_cfg() {

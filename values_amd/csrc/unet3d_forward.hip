@@ -147,6 +147,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // pre: the input is a contract block's RAW conv output; its InstanceNorm (p.mean / p.rstd), LeakyReLU and dropout
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   bool pre_split_ = false;           // set around the contr_1_2 launch when its input went through vx_prenorm_split
+  bool osplit_ = false, usplit_ = false;   // pre-split hand-over of B_1 (expand_2_2 -> upscale2 inside expand_1_1)
   int st16_ = 0;                     // reduced-storage mode: 1 around expand_1_1's launch (fp16 output), 2 around expand_1_2's (fp16 input)
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
@@ -182,6 +183,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.seed_dev = r->seed_dev;
     a.out_f16 = st16_ == 1 ? 1 : 0;
     a.in_f16 = st16_ == 2 ? 1 : 0;
+    a.out_split = osplit_ ? 1 : 0;       // expand_2_2 hands B_1 to the fused up-convolution as fp16 pairs
+    a.up_split = (up_in && usplit_) ? 1 : 0;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     if (pool_raw_ && wi == 1) {   // contr_1_2 also leaves the window maxima of its block's MaxPool (dropout layer 1)
       a.pool_out = pool_raw_; a.pool_flags = pool_flags_;
@@ -371,8 +374,12 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     else
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
     st16_ = (l == 0 && st16) ? 2 : 0;
+    // expand_2_2's output has ONE reader when upscale2 is fused into expand_1_1: hand it over pre-split
+    osplit_ = l == 1 && fuse_up && dm != VX_DROP_MASK && !vx_cfg().s16_no_upsplit;   // (level 1 runs on the tile kernel)
+    if (osplit_) usplit_ = true;
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     st16_ = 0;
+    osplit_ = false;
     if (l > 1 || (l == 1 && !fuse_up)) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
   }
   // ---------------- head ----------------

@@ -12,4 +12,4 @@ run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 run b SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
 run c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run d GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR
-for n in a b c d; do python3 tools/pmc_summary.py "gpurun_out/pmcx_${tag}_$n/**/*counter_collection.csv" xp8; tail -1 gpurun_out/pmcx_${tag}_$n.log | cut -c1-150; done
+for n in a b c d; do python3 tools/pmc_summary.py "gpurun_out/pmcx_${tag}_$n/**/*counter_collection.csv" ${PMC_FILTER:-xp8}; tail -1 gpurun_out/pmcx_${tag}_$n.log | cut -c1-150; done

@@ -603,7 +603,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int p = (vbase[r] + toff[s]) * 8;
+          // column tile r of a wave sits a lane-independent distance from its tile 0 (16 r voxels further in the tile's
+          // x-fastest order, never across the wave's z-plane): ONE address register per step, the rest is the
+          // instruction's immediate offset
+          constexpr int ROWS16 = 16 / TX;                                  // y-rows one column tile covers
+          static_assert(TX == 16 || TX == 8 || TX == 4, "tile width");
+          static_assert((R * ROWS16) % TY == 0 || TY % (R * ROWS16) == 0, "a wave's tiles do not straddle z-planes unevenly");
+          const int dr = (((r * ROWS16) / TY) * HY + (r * ROWS16) % TY) * HXP;
+          const int p = (vbase[0] + toff[s]) * 8 + dr * 8;
           bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + cofs + p);
           bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + cofs + p);
         }
@@ -636,12 +643,58 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bl[cur][r], accx[r][nt], 0, 0, 0);
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][nt], bh[cur][r], accx[r][nt], 0, 0, 0);
           }
+#ifndef VX_S16_NO_PIN
+        // The schedule, pinned: left alone hipcc sinks every fragment read to just before the matrix instruction that
+        // consumes it (ds_read_b128, s_waitcnt lgkmcnt(0), v_mfma ... -- the LDS latency exposed a dozen times per step).
+        //   mode 1: one read of step s + 1 behind each of this step's first matrix instructions (a whole step of cover;
+        //           two sets of fragments live);
+        //   mode 2: the reads of column tile r of step s + 1 behind the matrix instructions of tile r of step s, whose
+        //           fragment registers they can take over (three quarters of a step of cover, no extra registers).
+        // Same-process A/B against the unpinned loop: mode 1 -7..-9 % on every 16-channel-chunk instance (-3 % on the 8 -> 16
+        // layer), mode 2 -5.5..-7 % on the four-tile instances; mode 1 everywhere (no instance spills since the fragment
+        // addresses share one register per step).
+        {
+#ifdef VX_S16_PINMODE
+          constexpr int PINMODE = VX_S16_PINMODE;
+#else
+          constexpr int PINMODE = 1;
+#endif
+          constexpr int NRD = 2 * NT + 2 * R, NMF = 3 * R * NT;
+          constexpr int PAIRS = NRD < NMF ? NRD : NMF;
+          if (s == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);    // step 0's own fragments
+          if (s + 1 < NSTEP) {
+            if constexpr (PINMODE == 1) {
+#pragma unroll
+              for (int i = 0; i < PAIRS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              if (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
+              if (NMF > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);             // the next step's weights
+              __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT - 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+              for (int r = 1; r < R; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              }
+            }
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+          }
+          if (issue_loads && s < IN_IT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#else
         if (issue_loads && s < IN_IT) {
           // pin the load behind this step's matrix instructions (left alone the scheduler sinks all of them to the end
           // of the loop, where they queue up exactly as before)
           __builtin_amdgcn_sched_group_barrier(0x008, R * NT * 3, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+#endif
       }
     }
 

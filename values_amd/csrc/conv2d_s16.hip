@@ -306,7 +306,9 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int p = (vbase[r] + toff[s]) * 8;
+          // output row r of the wave = PXW positions further: one address register per step, the rest is the
+          // instruction's immediate offset (conv3d_s16.hip)
+          const int p = (vbase[0] + toff[s]) * 8 + r * PXW * 8;
           bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
           bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
         }
@@ -324,6 +326,27 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][nt], bl[cur][r], accx[r][nt], 0, 0, 0);
             accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][nt], bh[cur][r], accx[r][nt], 0, 0, 0);
           }
+#ifndef VX_S16_NO_PIN
+        // the schedule, pinned (conv3d_s16.hip): one fragment read of step s + 1 behind each of this step's first matrix
+        // instructions -- left alone hipcc sinks every read to just before its consumer and the LDS latency is exposed
+        // (not the five-row-tile 1x1 instance: it spills as it is, and ten times more with two sets of fragments live)
+        if constexpr (!(KS == 1 && NT >= 5)) {
+          constexpr int NRD = 2 * NT + 2 * R, NMF = 3 * R * NT;
+          constexpr int PAIRS = NRD < NMF ? NRD : NMF;
+          if (s == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+          if (s + 1 < NSTEP) {
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
+            if (NMF > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+          }
+        }
+#endif
       }
     }
 
@@ -347,10 +370,12 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
-          const f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
+          f32x4 v;     // main + cross * 2^-11: one fma per element (exact scaling: the bits of multiply-then-add)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaf(accx[r][nt][j], 1.0f / 2048.f, acc[r][nt][j]) + bias4[nt][j];
           if (a.stats_partial && !bad) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
+            for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] = fmaf(v[j], v[j], ssq[nt][j]); }
           }
           const unsigned vo = bad ? K_OOB : ovoff[r] + cshift * 4u;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), osrd, (int)vo, (int)osoff, 0);

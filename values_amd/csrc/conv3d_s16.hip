@@ -453,10 +453,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const bool bad = ((obad >> r) & 1u) || !cvalid[nt];
-        f32x4 v = (acc[r][nt] + accx[r][nt] * (1.0f / 2048.f)) + bias4[nt];
+        // main + cross * 2^-11 as ONE fma per element (the scaling is exact, so the same bits as multiply-then-add, which
+        // -ffp-contract=off would otherwise keep as two instructions -- packed ones, at twice the issue cost here)
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(accx[r][nt][j], 1.0f / 2048.f, acc[r][nt][j]) + bias4[nt][j];
         if (a.stats_partial && !bad) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] += v[j] * v[j]; }
+          for (int j = 0; j < 4; ++j) { ssum[nt][j] += v[j]; ssq[nt][j] = fmaf(v[j], v[j], ssq[nt][j]); }
         }
         if (f_lrelu) {
 #pragma unroll

@@ -734,7 +734,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           (void*)(reinterpret_cast<char*>(a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        f32x4 v = acc[r] + accx[r] * (1.0f / 2048.f);
+        f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling: the bits of multiply-then-add)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(accx[r][j], 1.0f / 2048.f, acc[r][j]);
         if (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }

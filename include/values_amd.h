@@ -87,6 +87,8 @@ typedef struct vx_config {
   int32_t s16_no_upsplit;  /* expand_2_2 stores plain floats and the fused up-convolution splits them per step (round 2) */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
+  int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
+                              one per tile with all sub-blocks staged together; same bits */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);
@@ -371,7 +373,10 @@ int vx_unet3d_forward_profiled(const vx_unet3d_weights* w, const vx_unet3d_run* 
  * K15: 3x3 stride 1 / 3x3 stride 2 / 1x1 convolution, padding k/2 (hrnet_module.py:37-41, 85-93, 349-358, 411-428;
  * bias only on last_layer), raw output + per-tile (sum, sumsq) partials [ntiles_total][Cout][2] for the
  * TRAINING-mode BatchNorm that follows (batch statistics over N,H,W; the reference never calls .eval()).
- * Cin must be a multiple of 16 (pad image channels with zeros), weights packed by vx_pack_conv2d. */
+ * Cin must be a multiple of 16, weights packed by vx_pack_conv2d (real channel count: it pads).  The input of C real
+ * channels needs NO padding to Cin: in_pitch may be any multiple of 4 in (Cin - 16, ...); channels at and beyond
+ * min(Cin, in_pitch) read as zeros, channels [C, in_pitch) must hold zeros (an 18-channel tensor travels at 20 floats
+ * per pixel, the 3-channel image at 4). */
 typedef struct vx_conv2d_args {
   const float* in; int32_t in_pitch;
   const float* w_packed; const float* bias; /* bias nullable, [Cout] */

@@ -21,12 +21,15 @@ def nchw(x):
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0):
+def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0, narrow=False):
+    """narrow: the input arrives with pitch round4(cin) < Cin = round16(cin) -- the next pixel's channels follow directly,
+    so a kernel that read "its" 16-channel block would multiply them in (vx_conv2d_args.in_pitch)"""
     lib = _lib.load()
     n, cin, h, wd = x.shape
     cout = w.shape[0]
     cin_pad = (cin + 15) // 16 * 16
-    xd = torch.zeros((n, h, wd, cin_pad), dtype=torch.float32, device=DEV)
+    in_pitch = (cin + 3) // 4 * 4 if narrow else cin_pad
+    xd = torch.zeros((n, h, wd, in_pitch), dtype=torch.float32, device=DEV)
     xd[..., :cin] = nhwc(x.float()).to(DEV)
     wdv = w.float().contiguous().to(DEV)
     wp = torch.empty(lib.vx_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=DEV)
@@ -40,7 +43,7 @@ def run_conv2d(x, w, b, ks, s, stats=True, out_pitch=None, out_coff=0):
     bd = b.float().to(DEV) if b is not None else None
     a = _lib.Conv2dArgs()
     a.w_family = lib.vx_conv2d_family(cin, cout, ks)
-    a.in_ = xd.data_ptr(); a.in_pitch = cin_pad; a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr() if bd is not None else None
+    a.in_ = xd.data_ptr(); a.in_pitch = in_pitch; a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr() if bd is not None else None
     a.out = out.data_ptr(); a.out_pitch = out_pitch; a.out_coff = out_coff
     a.N, a.H, a.W, a.Cin, a.Cout, a.KS, a.S = n, h, wd, cin_pad, cout, ks, s
     if stats:
@@ -74,6 +77,38 @@ def test_conv2d_matches_oracle(cin, cout, ks, s, shape, mode, vxcfg):
     ssum = st.double().sum(0)
     np.testing.assert_allclose(ssum[:, 0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(ssum[:, 1].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("cin,cout,ks,s,shape", [
+    (18, 18, 3, 1, (2, 20, 33)), (36, 36, 3, 1, (1, 16, 30)), (18, 36, 3, 2, (2, 17, 31)), (3, 64, 3, 2, (1, 32, 48)),
+    (36, 72, 3, 2, (1, 16, 30)), (270, 19, 1, 1, (1, 9, 14)), (40, 48, 3, 1, (1, 8, 15)),
+])
+@pytest.mark.parametrize("mode", ["split16", "fp32"])
+def test_conv2d_narrow_input_pitch_and_whole_cin_items(cin, cout, ks, s, shape, mode, vxcfg):
+    """Round 3: (1) an input of C channels may arrive with pitch round4(C) -- channels at and beyond the pitch read as
+    zeros (HRNet-W18's 18-channel branch at 20 floats per pixel); (2) 3x3 layers of <= 48 input channels run one work item
+    per tile with all 16-channel sub-blocks staged together -- the same bits as one item per sub-block (c2s_no_wide)."""
+    if mode == "fp32":
+        vxcfg.setenv("VX_CONV_FP32", "1")
+    else:
+        vxcfg.delenv("VX_CONV_FP32", raising=False)
+    n, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, h, w), 221))
+    wt = torch.from_numpy(formula_tensor((cout, cin, ks, ks), 222, scale=(1.0 / (ks * ks * cin)) ** 0.5))
+    ref = F.conv2d(x.float().double(), wt.float().double(), None, stride=s, padding=ks // 2)
+    got, st, _ = run_conv2d(x, wt, None, ks, s, narrow=True)
+    assert (got.double() - ref).abs().max().item() < 3e-5
+    ssum = st.double().sum(0)
+    np.testing.assert_allclose(ssum[:, 0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=2e-3)
+    wide, _, _ = run_conv2d(x, wt, None, ks, s, narrow=False)
+    assert torch.equal(got, wide)                     # the pitch changes the addressing, not a bit of the result
+    if mode == "split16":
+        vxcfg.set(c2s_no_wide=1)
+        try:
+            per_sub, st2, _ = run_conv2d(x, wt, None, ks, s, narrow=True)
+        finally:
+            vxcfg.set(c2s_no_wide=0)
+        assert torch.equal(got, per_sub) and torch.equal(st, st2)
 
 
 def test_conv2d_pitch_offset_into_concat():

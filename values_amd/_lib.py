@@ -77,7 +77,7 @@ class Config(C.Structure):
         "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
         "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
-        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit")]
+        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit", "c2s_no_wide")]
 
 
 class UncOutputs(C.Structure):

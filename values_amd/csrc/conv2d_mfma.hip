@@ -131,9 +131,12 @@ __global__ __launch_bounds__(512) void conv2d_mfma_kernel(Conv2dKArgs ka) {
     const unsigned soff = (unsigned)(((ty * TY * S) * rowf + (tx * TX * S) * a.in_pitch + chunk * NSUB * 16) * 4);
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, K_NUMREC, 0x00020000);
+    // channels at and beyond min(Cin, in_pitch) read as zero: a tensor of C real channels may arrive with pitch round4(C)
+    // (HRNet-W18's 18-channel branch: 20 floats per pixel instead of 32)
+    const int clim = min(a.Cin, a.in_pitch) - chunk * NSUB * 16;
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const bool b = ((bad >> it) & 1u) || (NSUB > 1 && (int)isub[it] >= nsub);
+      const bool b = ((bad >> it) & 1u) || (int)isub[it] * 16 + (tid & 3) * 4 >= clim;   // NTH % 4 == 0: q = tid % 4
       const unsigned vo = b ? K_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
@@ -405,7 +408,7 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
             a.w_family, vx_conv2d_family(a.Cin, a.Cout, a.KS));
   // outputs leave as 16-byte groups of 4 channels: a Cout that is not a multiple of 4 writes its last group up to
   // round4(Cout) (zeros beyond Cout), which the pitch must cover
-  if (a.in_pitch < a.Cin || a.in_pitch % 4 || a.out_pitch < a.out_coff + (a.Cout + 3) / 4 * 4 || a.out_pitch % 4 || a.out_coff % 4)
+  if (a.in_pitch <= a.Cin - 16 || a.in_pitch % 4 || a.out_pitch < a.out_coff + (a.Cout + 3) / 4 * 4 || a.out_pitch % 4 || a.out_coff % 4)
     VX_FAIL(VX_E_ALIGN, "vx_conv2d: pitches/offsets must be multiples of 4 floats and cover the channels");
   if (!vx_aligned16(a.in) || !vx_aligned16(a.out) || !vx_aligned16(a.w_packed) || (a.bias && !vx_aligned16(a.bias)))
     VX_FAIL(VX_E_ALIGN, "vx_conv2d: pointers must be 16-byte aligned");

@@ -21,6 +21,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 struct Conv2dSArgs {
   vx_conv2d_args a;
   int OH, OW, tiles_x, tiles_y, nchunks;   // nchunks = ceil(Cin/16 / NSUB)
+  int w_all;                               // every chunk's weights stay in LDS for the kernel's life (launch_c2s: they fit)
   unsigned mx, my;
 };
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   unsigned voff[IN_IT];
   int ldst[IN_IT];
   unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0;
-  unsigned isub[IN_IT];
+  // (the piece's sub-block rides in bits 24.. of ldst: one register per piece less across the multiply phase)
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
     const int idx = tid + it * NTH;
@@ -124,24 +125,25 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     voff[it] = (unsigned)((dyr * rowf + dxr * a.in_pitch + sub * 16 + q * 4 + biasf) * 4);
     const int par = (hy % S) * S + (hx % S);
     ldst[it] = ((sub * 2 + (q >> 1)) * PLANE + par * NPP + (hy / S) * PXW + hx / S) * 8 + (q & 1) * 4;   // halves
-    isub[it] = (unsigned)sub;
+    ldst[it] |= sub << 24;
     if (idx >= NPIECE) ibad_always |= 1u << it;
     if (dxr < 0) ibad_xlo |= 1u << it;
     if (dxr >= a.W - lastx * S) ibad_xhi |= 1u << it;
     if (dyr < 0) ibad_ylo |= 1u << it;
     if (dyr >= a.H - lasty * S) ibad_yhi |= 1u << it;
   }
-  // this lane's (tap | sub-block, octet) of every step, as a position offset into a precision plane
-  int toff[NSTEP];
+  // this lane's (tap | sub-block, octet) of every step, as a position offset into a precision plane.  3x3: the five steps
+  // of a sub-block repeat for the next one 2 PLANE positions further -- five registers, the rest an immediate offset
+  constexpr int NTOFF = KS == 3 ? 5 : NSTEP;
+  int toff[NTOFF];
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) {
+  for (int s = 0; s < NTOFF; ++s) {
     const int oct = g & 1;
     if (KS == 3) {
-      const int sub = s / 5;
-      int tap = 2 * (s % 5) + (g >> 1);
+      int tap = 2 * s + (g >> 1);
       if (tap > 8) tap = 8;                       // zero-weight padding tap: re-read a valid position
       const int ky = tap / 3, kx = tap % 3;
-      toff[s] = (sub * 2 + oct) * PLANE + ((ky % S) * S + (kx % S)) * NPP + (ky / S) * PXW + kx / S;
+      toff[s] = oct * PLANE + ((ky % S) * S + (kx % S)) * NPP + (ky / S) * PXW + kx / S;
     } else {
       toff[s] = ((2 * s + (g >> 1)) * 2 + oct) * PLANE;
     }
@@ -156,20 +158,23 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   };
 
   const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
-  f32x4 ibuf[IN_IT], wbuf[W_IT];
+  // whole-Cin items (3x3, NSUB > 1: vx_conv2d_s16 runs them with ONE chunk): the weights are copied once, no weight
+  // prefetch registers live across the multiply phase
+  constexpr bool WRES = KS == 3 && NSUB > 1;
+  f32x4 ibuf[IN_IT], wbuf[WRES ? 1 : W_IT];
   // prologue (vx_conv2d_args.in_scale): the folded BatchNorm of the PRODUCING conv (+ ReLU) applied on the way into LDS.
   // The scale / shift rows of the item's image group are staged into a small LDS table by prefetch() (after the second
   // barrier of the previous item: commit() of this item reads them behind the next barrier).
   const bool pre = a.in_scale != nullptr;
-  float* s_ss = smem + IN_FLOATS + W_FLOATS + NW * NT * 16 * 2;    // [scale | shift][NSUB * 16] of the item's chunk
+  const int w_res_floats = (ka.w_all ? ka.nchunks : 1) * W_FLOATS;   // LDS floats the weights take
+  float* s_ss = smem + IN_FLOATS + w_res_floats + NW * NT * 16 * 2;  // [scale | shift][NSUB * 16] of the item's chunk
   unsigned p_bad = 0;
-  const bool w_resident = ka.nchunks == 1;
+  const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
 
   auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w) {
     int n, tx, ty;
     decode(tile_lin, n, tx, ty);
-    const int nsub = min(NSUB, nsub_all - chunk * NSUB);   // sub-blocks in this chunk
     unsigned bad = ibad_always;
     if (tx == 0) bad |= ibad_xlo;
     if (tx == ka.tiles_x - 1) bad |= ibad_xhi;
@@ -179,32 +184,38 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     const unsigned soff = (unsigned)(((ty * TY * S) * rowf + (tx * TX * S) * a.in_pitch + chunk * NSUB * 16) * 4);
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.in + (size_t)(have ? n : 0) * in_sample - biasf), 0, K_NUMREC, 0x00020000);
+    // channels at and beyond min(Cin, in_pitch) read as zero (conv2d_mfma.hip)
+    const int clim = min(a.Cin, a.in_pitch) - chunk * NSUB * 16;
+    unsigned cbad = 0;
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it)
+      if ((ldst[it] >> 24) * 16 + (tid & 3) * 4 >= clim) cbad |= 1u << it;   // NTH % 4 == 0: the piece's quad is tid % 4
+    bad |= cbad;
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const bool b = ((bad >> it) & 1u) || (NSUB > 1 && (int)isub[it] >= nsub);
+      const bool b = (bad >> it) & 1u;
       const unsigned vo = b ? K_OOB : voff[it];
       ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)vo, (int)soff, 0));
     }
     if (pre) {
       p_bad = bad;
-#pragma unroll
-      for (int it = 0; it < IN_IT; ++it)
-        if (NSUB > 1 && (int)isub[it] >= nsub) p_bad |= 1u << it;
       // this chunk's channels of the image's statistics group (channels beyond Cin: scale = shift = 0 -> zeros)
       if (tid < 2 * NSUB * 16) {
         const int which = tid / (NSUB * 16), c = tid % (NSUB * 16), ch = chunk * NSUB * 16 + c;
         const int grp = a.in_group_images > 0 ? (have ? n : 0) / a.in_group_images : 0;
         const float* row = (which ? a.in_shift : a.in_scale) + (size_t)grp * a.in_cpitch;
-        s_ss[tid] = ch < a.Cin ? row[ch] : 0.f;
+        s_ss[tid] = ch < min(a.Cin, a.in_cpitch) ? row[ch] : 0.f;
       }
     }
-    const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * W_FLOATS);
+    if constexpr (!WRES) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(w_cg + (size_t)chunk * W_FLOATS);
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int idx = tid + it * NTH;
-      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (have && with_w && idx < W_FLOATS / 4) v = src[idx];
-      wbuf[it] = v;
+      for (int it = 0; it < W_IT; ++it) {
+        const int idx = tid + it * NTH;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (have && with_w && idx < W_FLOATS / 4) v = src[idx];
+        wbuf[it] = v;
+      }
     }
   };
   auto commit = [&](bool with_w) {
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
       if (tid + it * NTH < NPIECE) {
         f16x4 hi, lo;
         if (pre) {
-          const int c = (int)isub[it] * 16 + (tid & 3) * 4;           // NTH % 4 == 0: the lane's quad is idx % 4 in every iteration
+          const int c = (ldst[it] >> 24) * 16 + (tid & 3) * 4;           // NTH % 4 == 0: the lane's quad is idx % 4 in every iteration
           const f32x4 sc = *reinterpret_cast<const f32x4*>(s_ss + c);
           const f32x4 sh = *reinterpret_cast<const f32x4*>(s_ss + NSUB * 16 + c);
           f32x4 v = ibuf[it];
@@ -227,14 +238,16 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
           ibuf[it] = v;
         }
         split4(ibuf[it], hi, lo);
-        *reinterpret_cast<f16x4*>(s_hi + ldst[it]) = hi;
-        *reinterpret_cast<f16x4*>(s_lo + ldst[it]) = lo;
+        *reinterpret_cast<f16x4*>(s_hi + (ldst[it] & 0xFFFFFF)) = hi;
+        *reinterpret_cast<f16x4*>(s_lo + (ldst[it] & 0xFFFFFF)) = lo;
       }
-    if (with_w) {
+    if constexpr (!WRES) {
+      if (with_w) {
 #pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        const int idx = tid + it * NTH;
-        if (idx < W_FLOATS / 4) reinterpret_cast<f32x4*>(s_w)[idx] = wbuf[it];
+        for (int it = 0; it < W_IT; ++it) {
+          const int idx = tid + it * NTH;
+          if (idx < W_FLOATS / 4) reinterpret_cast<f32x4*>(s_w)[idx] = wbuf[it];
+        }
       }
     }
   };
@@ -250,7 +263,13 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 
   int tile_lin = blockIdx.x, chunk = 0;
   bool have = tile_lin < total;
-  prefetch(tile_lin, 0, have, true);
+  if (WRES || (ka.w_all && ka.nchunks > 1)) {   // all chunks' weights resident: one cooperative copy for the kernel's life (conv3d_s16.hip).
+    // Per item the 3x3 layers of 18 / 36 channels otherwise re-stage 20 / 30 KB of weights next to a 20-KB image
+    const f32x4* src = reinterpret_cast<const f32x4*>(w_cg);
+    for (int i = tid; i < ka.nchunks * (W_FLOATS / 4); i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+    w_fresh = false;
+  }
+  prefetch(tile_lin, 0, have, !(WRES || (ka.w_all && ka.nchunks > 1)));
   f32x4 acc[R][NT], accx[R][NT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
 
   // statistics of the tile finished last: its per-wave sums sit in s_red and are combined after the NEXT barrier
   // of the item loop (no barrier of their own in the epilogue; conv3d_s16.hip)
-  float* s_red = smem + IN_FLOATS + W_FLOATS;  // [NW][NT][16][2] (floats: image = IMG_H, weights = W_FLOATS)
+  float* s_red = smem + IN_FLOATS + w_res_floats;  // [NW][NT][16][2] (floats: image = IMG_H, weights = W_FLOATS per chunk)
   int pend_tile = -1;
   auto flush_stats = [&]() {
     if (pend_tile >= 0 && tid < NT * 16) {
@@ -297,10 +316,11 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
       // sub-blocks beyond the layer's Cin were steered out of range by prefetch -> zeros; their weights are zero too)
       (void)nsub;
       f16x8 ah[2][NT], al[2][NT], bh[2][R], bl[2][R];
+      const _Float16* s_wc = s_w + (ka.w_all ? chunk * (2 * W_FLOATS) : 0);   // this item's weights
       auto load_step = [&](int s, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const _Float16* wp = s_w + s * W_STEP + ((nt * 2) * 64 + lane) * 8;
+          const _Float16* wp = s_wc + s * W_STEP + ((nt * 2) * 64 + lane) * 8;
           ah[slot][nt] = *reinterpret_cast<const f16x8*>(wp);
           al[slot][nt] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
         }
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         for (int r = 0; r < R; ++r) {
           // output row r of the wave = PXW positions further: one address register per step, the rest is the
           // instruction's immediate offset (conv3d_s16.hip)
-          const int p = (vbase[0] + toff[s]) * 8 + r * PXW * 8;
+          const int p = (vbase[0] + toff[KS == 3 ? s % 5 : s]) * 8 + (KS == 3 ? (s / 5) * 2 * PLANE * 8 : 0) + r * PXW * 8;
           bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
           bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
         }
@@ -484,21 +504,24 @@ int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout,
 }
 
 template <int KS, int S, int NT, int NSUB, int TY>
-static int launch_c2s(const Conv2dSArgs& ka, hipStream_t s) {
+static int launch_c2s(const Conv2dSArgs& ka_in, hipStream_t s) {
   constexpr int HX = 15 * S + KS, HY = (TY - 1) * S + KS;
   constexpr int NPP = ((HX + S - 1) / S) * ((HY + S - 1) / S);
   constexpr int PLANE = ((S * S * NPP + 15) / 16) * 16;
   constexpr int IMG_H = NSUB * 2 * PLANE * 8;
   constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;
-  constexpr size_t lds = (size_t)IMG_H * 4 + (size_t)NSTEP * NT * 2 * 64 * 8 * 2 + (size_t)8 * NT * 16 * 2 * 4 +
-                         (size_t)2 * NSUB * 16 * 4;   // + the prologue's scale / shift table
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  constexpr size_t wch = (size_t)NSTEP * NT * 2 * 64 * 8 * 2;
+  constexpr size_t rest = (size_t)IMG_H * 4 + (size_t)8 * NT * 16 * 2 * 4 + (size_t)2 * NSUB * 16 * 4;   // image, statistics, prologue table
+  static_assert(rest + wch <= 160 * 1024, "LDS budget");
+  Conv2dSArgs ka = ka_in;
+  ka.w_all = (ka.nchunks > 1 && rest + ka.nchunks * wch <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0;
+  const size_t lds = rest + (ka.w_all ? ka.nchunks : 1) * wch;
+  static size_t attr_lds = 0;
   auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY>;
-  if (!attr_set) {
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv2d(s16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    attr_set = true;
+    attr_lds = lds;
   }
   const vx_conv2d_args& a = ka.a;
   const int total_tiles = ka.tiles_x * ka.tiles_y * a.N;
@@ -537,6 +560,16 @@ int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s) {
   ka.nchunks = (a.Cin / 16 + c.NSUB - 1) / c.NSUB;
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
+  // 3x3 layers of 2 / 3 input sub-blocks (HRNet: 18 / 36 / 48 channels): ONE item per tile with all sub-blocks staged
+  // together -- a third / half of the barriers, prefetches and commits, and the weights resident.  The packed layout does
+  // not change ([chunk][step] with five steps per sub-block is the same sequence either way).  Stride 2 with three
+  // sub-blocks does not fit (120 KB of parity planes + 92 KB of weights).
+  const int nsub = a.Cin / 16;
+  if (a.KS == 3 && !vx_cfg().c2s_no_wide && (nsub == 2 || (nsub == 3 && a.S == 1))) {
+    ka.nchunks = 1;
+    if (a.S == 1) return nsub == 2 ? dispatch_c2s<3, 1, 2, 16>(ka, c.NT, s) : dispatch_c2s<3, 1, 3, 16>(ka, c.NT, s);
+    return dispatch_c2s<3, 2, 2, 8>(ka, c.NT, s);
+  }
   if (a.KS == 3 && a.S == 1) return dispatch_c2s<3, 1, 1, 16>(ka, c.NT, s);
   if (a.KS == 3 && a.S == 2) return dispatch_c2s<3, 2, 1, 8>(ka, c.NT, s);
   return dispatch_c2s<1, 1, 4, 16>(ka, c.NT, s);

@@ -136,12 +136,19 @@ def _r16(c: int) -> int:
     return (c + 15) // 16 * 16
 
 
+def _rp(c: int) -> int:
+    """pitch (floats per pixel) of an activation of c channels: the next multiple of 4, the channels beyond c zero.  The
+    convolutions take Cin = round16(c) and read channels at and beyond the pitch as zeros (vx_conv2d_args.in_pitch), so
+    HRNet-W18's 18-channel full-resolution branch moves 20 floats per pixel, not 32 (round 2's layout)."""
+    return (c + 3) // 4 * 4
+
+
 def _pad_mask(m: torch.Tensor, dev) -> torch.Tensor:
     """(B, C, H, W) bool keep-mask -> channels-last uint8 with the channel padding of the activations"""
     t = m.to(dev).permute(0, 2, 3, 1).to(torch.uint8)
     c = t.shape[-1]
-    if c % 16:
-        t = torch.nn.functional.pad(t, (0, _r16(c) - c))
+    if c % 4:
+        t = torch.nn.functional.pad(t, (0, _rp(c) - c))
     return t.contiguous()
 
 
@@ -303,15 +310,15 @@ class HighResolutionNet(nn.Module):
         for name, mod in self.named_modules():
             if isinstance(mod, nn.Conv2d):
                 w = mod.weight.detach().to(dev, torch.float32).contiguous()
-                if name in ("last_layer.0", "cov_factor_conv.0") and any(c % 16 for c in self._last_parts):
+                if name in ("last_layer.0", "cov_factor_conv.0") and any(c % 4 for c in self._last_parts):
                     # the head reads the concat of the four PADDED stage-4 tensors: spread the input channels
-                    wpad = torch.zeros((w.shape[0], sum(_r16(c) for c in self._last_parts)) + tuple(w.shape[2:]),
+                    wpad = torch.zeros((w.shape[0], sum(_rp(c) for c in self._last_parts)) + tuple(w.shape[2:]),
                                        dtype=torch.float32, device=dev)
                     src = dst = 0
                     for c in self._last_parts:
                         wpad[:, dst:dst + c] = w[:, src:src + c]
                         src += c
-                        dst += _r16(c)
+                        dst += _rp(c)
                     w = wpad.contiguous()
                 cout, cin, ks, _ = w.shape
                 wp = torch.empty(lib.vx_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=dev)
@@ -335,13 +342,13 @@ class HighResolutionNet(nn.Module):
         lib = _lib.load()
         wp, b, cin, cout, ks, stride, _w, fam = self._pk[name]
         cin_pad = (cin + 15) // 16 * 16
-        assert x.C == cin_pad or x.C == cin, (name, x.C, cin)
+        assert x.C == _rp(cin) or x.C == cin, (name, x.C, cin)
         n, h, w = x.N, x.H, x.W
         oh = (h + 2 * (ks // 2) - ks) // stride + 1
         ow = (w + 2 * (ks // 2) - ks) // stride + 1
         pitch = (cout + 3) // 4 * 4
-        if cout % 16 and stats:     # feeds another conv: keep the zero-padded round16(C) layout (see __init__)
-            pitch = _r16(cout)
+        if cout % 4 and stats:      # feeds another conv: the channels [cout, round4(cout)) stay zero (see __init__)
+            pitch = _rp(cout)
             # the conv writes channels [0, round4(cout)) only, so the zero tail survives from forward to forward: one
             # buffer per layer and geometry, zero-filled once (a fill kernel per conv launch was the top entry of the
             # W18 profile)
@@ -382,7 +389,7 @@ class HighResolutionNet(nn.Module):
             prof.append((lib.vx_last_kernel_name().decode(), 2.0 * ks * ks * cin * cout * n * oh * ow,
                          4.0 * (n * h * w * cin + n * oh * ow * cout + ks * ks * cin * cout), e0, e1))
         self._hold += [out, part]
-        act = _Act(out, pitch if (cout % 16 and stats) else cout)
+        act = _Act(out, pitch if (cout % 4 and stats) else cout)
         act.real_c = cout
         return act, part, ntiles
 
@@ -557,10 +564,10 @@ class HighResolutionNet(nn.Module):
         n, cin, h, w = x.shape
         if cin != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
-        xin = torch.zeros((n, h, w, 16), dtype=torch.float32, device=x.device)   # pad image channels to one 16-block
+        xin = torch.zeros((n, h, w, _rp(cin)), dtype=torch.float32, device=x.device)   # channels-last, pitch round4(cin)
         xin[..., :cin] = x.permute(0, 2, 3, 1)
         self._hold.append(xin)
-        a = _Act(xin, 16)
+        a = _Act(xin, _rp(cin))
         r = self._conv_bn(a, "conv1", "bn1")
         r = self._conv_bn_after(r, "conv2", "bn2")
         a = self._aff(r[0], r[1], r[2], relu=True)

@@ -675,8 +675,10 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     views, hf, vf = tta_views_8(x, noisy)
 
     def step_eager(i):
-        lg = predict_logits_2d([model], views, tta=True, hflip_views=hf, vflip_views=vf)
-        return process_output_2d(lg)
+        # every view's softmax is taken in its forward's upsampling pass (the outputs -- softmax_pred and the maps -- are the
+        # reference's; the full-resolution logits, which process_output never sees, are not written)
+        pr = predict_logits_2d([model], views, tta=True, hflip_views=hf, vflip_views=vf, softmax=True)
+        return process_output_2d(None, probs=pr)
 
     # the product path for a fixed image geometry: the step captured once as a hipGraph (the eager walk is ~950 launches
     # from Python and host-bound), replayed per step with the views copied into the graph's inputs
@@ -686,7 +688,7 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
         eager = summarise(et, B * max(2, args.steps // 2), max(2, args.steps // 2))
         model._hold_last = None
         torch.cuda.empty_cache()
-    gp = None if args.eager else GraphedPredictor2D([model], views, tta=True, hflip_views=hf, vflip_views=vf)
+    gp = None if args.eager else GraphedPredictor2D([model], views, tta=True, hflip_views=hf, vflip_views=vf, keep_logits=False)
 
     def step(i):
         return gp(views) if gp is not None else step_eager(i)

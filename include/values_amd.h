@@ -427,6 +427,11 @@ int vx_affine_gather(const vx_affine_args* a, vx_stream_t stream);
  * (test_2D.py:304-309), bit 1 a VerticalFlip one (8-view extension, BASELINE config 4). */
 int vx_bilinear_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
                      const int32_t* dst, const int32_t* flip, vx_stream_t stream);
+/* The same upsample followed by F.softmax(dim=1) (test_2D.py:300-303: `output_softmax = F.softmax(output, dim=1)` of every
+ * forward), in one pass: out holds PROBABILITIES, the full-resolution logits are never written.  Bit-identical to
+ * vx_bilinear_nchw + vx_softmax_planar. */
+int vx_bilinear_softmax_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
+                             const int32_t* dst, const int32_t* flip, vx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * K14: sliding-window accumulation of a batch of patches (DataCarrier3D.concat_data,

@@ -367,6 +367,7 @@ def test_graphed_predictor_2d_replays_the_eager_bits():
     noisy = x + torch.from_numpy(formula_tensor(tuple(x.shape), tag=83, scale=0.1)).float().cuda()
     views, hf, vf = tta_views_8(x, noisy)
     gp = GraphedPredictor2D([m], views, tta=True, hflip_views=hf, vflip_views=vf)
+    gp2 = GraphedPredictor2D([m], views, tta=True, hflip_views=hf, vflip_views=vf, keep_logits=False)
     for scale in (1.0, 0.7, 1.0):
         vs = [v * scale for v in views]
         out = gp(vs)
@@ -374,6 +375,12 @@ def test_graphed_predictor_2d_replays_the_eager_bits():
         ref = process_output_2d(lg)
         torch.cuda.synchronize()
         assert torch.equal(gp.logits, lg), scale
+        # keep_logits=False: every view's softmax in its upsampling pass (vx_bilinear_softmax_nchw) -- no full-resolution
+        # logits in the graph, the same bits in every output
+        out2 = gp2(vs)
+        assert gp2.logits is None
+        for k in ref:
+            assert torch.equal(out2[k], ref[k]), (k, scale)
         for k in ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax", "pred_seg"):
             assert torch.equal(out[k], ref[k]), (k, scale)
     with pytest.raises(ValueError):

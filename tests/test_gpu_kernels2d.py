@@ -231,3 +231,33 @@ def test_bilinear_nchw_slots_and_hflip():
     assert (out[0].cpu().double() - torch.flip(ref[1], [-1])).abs().max().item() < 2e-6
     assert (out[3].cpu().double() - ref[2]).abs().max().item() < 2e-6
     assert (out[1] == -77.0).all()
+
+
+@pytest.mark.parametrize("C", [2, 5, 19, 40])
+def test_bilinear_softmax_nchw_is_bilinear_then_softmax(C):
+    """vx_bilinear_softmax_nchw (round 3): the final upsample with F.softmax(dim=1) of the upsampled logits taken before the
+    store (test_2D.py:300-303) -- bit for bit vx_bilinear_nchw followed by vx_softmax_planar, slots and both un-flips
+    included, and the float64 reference within 1e-6."""
+    lib = _lib.load()
+    pitch = (C + 3) // 4 * 4
+    x = torch.from_numpy(formula_tensor((3, C, 16, 30), 261, scale=3.0))
+    xd = torch.zeros((3, 16, 30, pitch), dtype=torch.float32, device=DEV)
+    xd[..., :C] = nhwc(x.float()).to(DEV)
+    dst = torch.tensor([2, 0, 3], dtype=torch.int32, device=DEV)
+    flip = torch.tensor([0, 1, 3], dtype=torch.int32, device=DEV)
+    lg = torch.full((4, C, 64, 120), -77.0, dtype=torch.float32, device=DEV)
+    pr = torch.full((4, C, 64, 120), -77.0, dtype=torch.float32, device=DEV)
+    _lib.check(lib.vx_bilinear_nchw(_lib.ptr(xd), pitch, 3, 16, 30, C, 64, 120, _lib.ptr(lg), _lib.ptr(dst), _lib.ptr(flip),
+                                    _lib.stream_ptr()), "bilinear_nchw")
+    _lib.check(lib.vx_bilinear_softmax_nchw(_lib.ptr(xd), pitch, 3, 16, 30, C, 64, 120, _lib.ptr(pr), _lib.ptr(dst), _lib.ptr(flip),
+                                            _lib.stream_ptr()), "bilinear_softmax_nchw")
+    two = torch.empty_like(lg)
+    _lib.check(lib.vx_softmax_planar(_lib.ptr(lg), 4, C, 64 * 120, _lib.ptr(two), _lib.stream_ptr()), "softmax_planar")
+    torch.cuda.synchronize()
+    for slot in (0, 2, 3):
+        assert torch.equal(pr[slot], two[slot]), slot
+    assert (pr[1] == -77.0).all()                                  # an unused slot stays untouched
+    ref = torch.softmax(F.interpolate(x.float().double(), size=(64, 120), mode="bilinear", align_corners=False), dim=1)
+    assert (pr[2].cpu().double() - ref[0]).abs().max().item() < 1e-6
+    assert (pr[0].cpu().double() - torch.flip(ref[1], [-1])).abs().max().item() < 1e-6
+    assert (pr[3].cpu().double() - torch.flip(ref[2], [-1, -2])).abs().max().item() < 1e-6

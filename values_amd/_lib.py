@@ -160,6 +160,7 @@ SIGNATURES = {
     "vx_bn_finalize_groups": (_i, [_p, _i, _i, _i, _i, _i64, C.c_float, _p, _p, _p, _p, _p]),
     "vx_affine_gather": (_i, [C.POINTER(AffineArgs), _p]),
     "vx_bilinear_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "vx_bilinear_softmax_nchw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vx_evalmetrics_workspace_bytes": (_i64, []),
     "vx_ncc_sums": (_i, [_p, _i, _p, _i, _i64, _i, C.c_double, C.c_double, _p, _p, _p]),
     "vx_platt_sums": (_i, [_p, _i, _p, _p, _i, _i64, _i, C.c_double, C.c_double, C.c_double, C.c_double, _p, _p, _p]),

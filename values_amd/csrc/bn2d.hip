@@ -185,6 +185,110 @@ __global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* __restr
   }
 }
 
+// The same upsample with F.softmax(dim=1) of the upsampled logits applied before the store (test_2D.py:300-303 takes the
+// softmax of every view's output): the full-resolution LOGITS are never written -- at 1024 x 512 x 19 classes x 32 views
+// that is a 1.27 GB write and read, and the separate softmax pass another read.  Every value is computed exactly as
+// bilinear_nchw_kernel followed by softmax_planar_kernel compute it (same expressions, same order): the same bits.
+// (three sweeps over the classes, each re-evaluating the interpolation from the four low-resolution pixels -- they sit
+// in L1 / L2 -- instead of a register array of C values: with the array fully unrolled for 32 classes hipcc hoisted all
+// 128 loads and spilled 6 000 registers' worth; the sweeps need 40 registers and any C)
+__global__ __launch_bounds__(256) void bilinear_softmax_nchw_kernel(const float* __restrict__ x, int x_pitch, int N, int H, int W,
+                                                                    int C, int OH, int OW, float* __restrict__ out,
+                                                                    const int32_t* __restrict__ dst, const int32_t* __restrict__ flip) {
+  const float ry = (float)H / (float)OH, rx = (float)W / (float)OW;
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_coord(oy, H, ry, y0, y1, ly);
+    bil_coord(ox, W, rx, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p00 = x + (((size_t)n * H + y0) * W + x0) * x_pitch;
+    const float* p01 = x + (((size_t)n * H + y0) * W + x1) * x_pitch;
+    const float* p10 = x + (((size_t)n * H + y1) * W + x0) * x_pitch;
+    const float* p11 = x + (((size_t)n * H + y1) * W + x1) * x_pitch;
+    const int slot = dst ? dst[n] : n;
+    const int fl = flip ? flip[n] : 0;
+    const int wx = (fl & 1) ? OW - 1 - ox : ox;
+    const int wy = (fl & 2) ? OH - 1 - oy : oy;
+    float* o = out + (size_t)slot * C * OH * OW + (size_t)wy * OW + wx;
+    auto val = [&](int c) { return hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]); };
+    float m = val(0);
+    for (int c = 1; c < C; ++c) m = fmaxf(m, val(c));
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(val(c) - m);
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; ++c) o[(size_t)c * OH * OW] = expf(val(c) - m) * inv;
+  }
+}
+
+// Up to 32 classes with the low-resolution pitch a multiple of 4: the four corner pixels arrive as 16-byte pieces and the
+// C interpolated logits stay in registers (one exp per class).  The value of every logit is the same expression as above.
+template <int C4>
+__global__ __launch_bounds__(256) void bilinear_softmax_nchw_vec_kernel(const float* __restrict__ x, int x_pitch, int N, int H, int W,
+                                                                        int C, int OH, int OW, float* __restrict__ out,
+                                                                        const int32_t* __restrict__ dst, const int32_t* __restrict__ flip) {
+  const float ry = (float)H / (float)OH, rx = (float)W / (float)OW;
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_coord(oy, H, ry, y0, y1, ly);
+    bil_coord(ox, W, rx, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const f32x4* p00 = reinterpret_cast<const f32x4*>(x + (((size_t)n * H + y0) * W + x0) * x_pitch);
+    const f32x4* p01 = reinterpret_cast<const f32x4*>(x + (((size_t)n * H + y0) * W + x1) * x_pitch);
+    const f32x4* p10 = reinterpret_cast<const f32x4*>(x + (((size_t)n * H + y1) * W + x0) * x_pitch);
+    const f32x4* p11 = reinterpret_cast<const f32x4*>(x + (((size_t)n * H + y1) * W + x1) * x_pitch);
+    const int slot = dst ? dst[n] : n;
+    const int fl = flip ? flip[n] : 0;
+    const int wx = (fl & 1) ? OW - 1 - ox : ox;
+    const int wy = (fl & 2) ? OH - 1 - oy : oy;
+    float* o = out + (size_t)slot * C * OH * OW + (size_t)wy * OW + wx;
+    float v[4 * C4];
+#pragma unroll
+    for (int q = 0; q < C4; ++q) {
+      const f32x4 a = p00[q], b = p01[q], c_ = p10[q], d = p11[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = hy * (hx * a[j] + lx * b[j]) + ly * (hx * c_[j] + lx * d[j]);
+    }
+    float m = v[0];
+#pragma unroll
+    for (int c = 1; c < 4 * C4; ++c)
+      if (c < C) m = fmaxf(m, v[c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * C4; ++c)
+      if (c < C) { v[c] = expf(v[c] - m); den += v[c]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int c = 0; c < 4 * C4; ++c)
+      if (c < C) o[(size_t)c * OH * OW] = v[c] * inv;
+  }
+}
+
+extern "C" int vx_bilinear_softmax_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
+                                        const int32_t* dst, const int32_t* flip, vx_stream_t stream) {
+  if (!x || !out) VX_FAIL(VX_E_NULL, "vx_bilinear_softmax_nchw: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || x_pitch < C) VX_FAIL(VX_E_SHAPE, "vx_bilinear_softmax_nchw: bad shape");
+  const int64_t total = (int64_t)N * OH * OW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  const int c4 = (C + 3) / 4;
+  const bool vec = x_pitch % 4 == 0 && x_pitch >= 4 * c4 && vx_aligned16(x) && c4 <= 8;
+#define VX_BS_LAUNCH(K) hipLaunchKernelGGL(K, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_pitch, N, H, W, C, OH, OW, out, dst, flip)
+  if (vec && c4 <= 1) VX_BS_LAUNCH(bilinear_softmax_nchw_vec_kernel<1>);
+  else if (vec && c4 <= 2) VX_BS_LAUNCH(bilinear_softmax_nchw_vec_kernel<2>);
+  else if (vec && c4 <= 5) VX_BS_LAUNCH(bilinear_softmax_nchw_vec_kernel<5>);
+  else if (vec) VX_BS_LAUNCH(bilinear_softmax_nchw_vec_kernel<8>);
+  else VX_BS_LAUNCH(bilinear_softmax_nchw_kernel);
+#undef VX_BS_LAUNCH
+  VX_CHECK_LAUNCH("vx_bilinear_softmax_nchw");
+  return VX_OK;
+}
+
 extern "C" int vx_bilinear_nchw(const float* x, int x_pitch, int N, int H, int W, int C, int OH, int OW, float* out,
                                 const int32_t* dst, const int32_t* flip, vx_stream_t stream) {
   if (!x || !out) VX_FAIL(VX_E_NULL, "vx_bilinear_nchw: null pointer");

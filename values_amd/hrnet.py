@@ -603,7 +603,7 @@ class HighResolutionNet(nn.Module):
             outs.append(raw)
         return outs
 
-    def _head(self, feats: List[_Act], out: torch.Tensor, size, dst, flip, drop_mode, seed, masks):
+    def _head(self, feats: List[_Act], out: torch.Tensor, size, dst, flip, drop_mode, seed, masks, softmax=False):
         lib = _lib.load()
         n, h0, w0 = feats[0].N, feats[0].H, feats[0].W
         ctot = sum(f.C for f in feats)
@@ -620,16 +620,21 @@ class HighResolutionNet(nn.Module):
             raw, _, _ = self._conv(r[0], "last_layer.3", stats=False, pre=(r[1], r[2]))
         else:
             raw, _, _ = self._conv(self._aff(r[0], r[1], r[2], relu=True), "last_layer.3", stats=False)
-        _lib.check(lib.vx_bilinear_nchw(_lib.ptr(raw.t), raw.pitch, n, h0, w0, self.num_classes, size[0], size[1],
-                                        _lib.ptr(out), _lib.ptr(dst), _lib.ptr(flip), self._st), "vx_bilinear_nchw")
+        # softmax: `out` receives F.softmax(dim=1) of the upsampled logits (what test_2D.py:300-303 takes of every forward)
+        # in the same pass; the full-resolution logits are not written
+        fn = lib.vx_bilinear_softmax_nchw if softmax else lib.vx_bilinear_nchw
+        _lib.check(fn(_lib.ptr(raw.t), raw.pitch, n, h0, w0, self.num_classes, size[0], size[1],
+                      _lib.ptr(out), _lib.ptr(dst), _lib.ptr(flip), self._st), "vx_bilinear_nchw")
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
     def forward_samples(self, x: torch.Tensor, n_samples: int = 1, dropout_masks: Optional[Sequence] = None,
                         seeds: Optional[Sequence[int]] = None, hflip_back: bool = False,
                         out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0,
-                        vflip_back: bool = False, groups: int = 1, group_flips: Optional[Sequence[int]] = None) -> torch.Tensor:
-        """(n_samples, B, C, H, W) logits: backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
+                        vflip_back: bool = False, groups: int = 1, group_flips: Optional[Sequence[int]] = None,
+                        softmax_out: bool = False) -> torch.Tensor:
+        """(n_samples, B, C, H, W) logits (softmax_out: their class softmax instead, computed in the
+        upsampling pass): backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
         [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
         (a HorizontalFlip TTA view, test_2D.py:304-309); vflip_back: along H (VerticalFlip, the 8-view extension)."""
         _lib.require_gpu()
@@ -686,7 +691,7 @@ class HighResolutionNet(nn.Module):
             else:
                 dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
             self._hold.append(dst)
-            self._head(feats, out, (h, w), dst, flip, mode, seed, masks)
+            self._head(feats, out, (h, w), dst, flip, mode, seed, masks, softmax=softmax_out)
         self._hold_last = self._hold  # keep everything alive until the stream has consumed it
         self._groups = 1
         if user_out:

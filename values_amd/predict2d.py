@@ -36,10 +36,12 @@ def tta_views_8(x: torch.Tensor, x_noisy: torch.Tensor):
 @torch.no_grad()
 def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False, hflip_views: Optional[Sequence[bool]] = None,
                       dropout_masks=None, seeds=None, vflip_views: Optional[Sequence[bool]] = None,
-                      batch_views: bool = True) -> torch.Tensor:
+                      batch_views: bool = True, softmax: bool = False) -> torch.Tensor:
     """data: (B,3,H,W) tensor, or with tta a list of view tensors (the dataset's 4 views, cityscapes_dataset.py:76-99,
     or the 8 of tta_views_8) and hflip_views[i] = "HorizontalFlip" in transforms of view i (vflip_views likewise).
-    Returns logits (B, Npred_total, C, H, W).  batch_views: the TTA views travel as ONE batch whose BatchNorm statistics
+    Returns logits (B, Npred_total, C, H, W) -- with softmax=True their class softmax (F.softmax(output, dim=1) of every
+    forward, test_2D.py:300-303), taken inside the model's final upsampling pass so that the full-resolution logits are
+    never written (not for SSN members: their draws are logits); process_output_2d(probs=...) takes it.  batch_views: the TTA views travel as ONE batch whose BatchNorm statistics
     are kept per view (vx_bn_finalize_groups) -- the same numbers as one forward per view, an eighth of the launches."""
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -50,6 +52,8 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
     C = models[0].num_classes
     if getattr(models[0], "ssn", False) and not tta and len(models) == 1:
         # test_2D.py:285-299: one forward -> distribution, n_pred draws of it
+        if softmax:
+            raise ValueError("predict_logits_2d: softmax=True is for deterministic / dropout members (an SSN member's draws are logits)")
         return models[0].forward_ssn(views[0]).sample_images(n_pred, seed=None if seeds is None else seeds[0])
     out = torch.empty((B * total, C, H, W), dtype=torch.float32, device=dev)
     for mi, model in enumerate(models):
@@ -59,17 +63,17 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
                      for vi in range(len(views))]
             model.forward_samples(torch.cat([v.to(dev, torch.float32) for v in views], 0), 1,
                                   seeds=None if seeds is None else [seeds[mi] * 131], out=out, slot_stride=total,
-                                  slot_offset=base, groups=len(views), group_flips=codes)
+                                  slot_offset=base, groups=len(views), group_flips=codes, softmax_out=softmax)
         elif tta:
             for vi, view in enumerate(views):
                 model.forward_samples(view, 1, hflip_back=bool(hflip_views[vi]) if hflip_views else False,
                                       vflip_back=bool(vflip_views[vi]) if vflip_views else False,
                                       seeds=None if seeds is None else [seeds[mi] * 131 + vi],
-                                      out=out, slot_stride=total, slot_offset=base + vi)
+                                      out=out, slot_stride=total, slot_offset=base + vi, softmax_out=softmax)
         else:
             model.forward_samples(views[0], n_pred, dropout_masks=None if dropout_masks is None else dropout_masks[mi],
                                   seeds=None if seeds is None else [seeds[mi] * 131 + t for t in range(n_pred)],
-                                  out=out, slot_stride=total, slot_offset=base)
+                                  out=out, slot_stride=total, slot_offset=base, softmax_out=softmax)
     return out.view(B, total, C, H, W)
 
 
@@ -82,7 +86,9 @@ class GraphedPredictor2D:
     construction (every replay draws the same masks -- use the eager path for fresh MC-dropout samples)."""
 
     def __init__(self, models: Sequence, example, n_pred: int = 1, tta: bool = False, hflip_views=None, vflip_views=None,
-                 seeds=None, ssn: bool = False):
+                 seeds=None, ssn: bool = False, keep_logits: bool = True):
+        """keep_logits=False: the graph holds no full-resolution logits (`self.logits` is None) -- every forward's softmax
+        is taken in its upsampling pass (predict_logits_2d(softmax=True)); the maps are the same bits."""
         _lib.require_gpu()
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.models, self.tta = list(models), tta
@@ -93,7 +99,12 @@ class GraphedPredictor2D:
         self._kw = dict(n_pred=n_pred, tta=tta, hflip_views=hflip_views, vflip_views=vflip_views, seeds=seeds)
         self._ssn = ssn
 
+        fused = not keep_logits and not ssn
+
         def run():
+            if fused:
+                pr = predict_logits_2d(self.models, self.x if tta else self.x[0], softmax=True, **self._kw)
+                return None, process_output_2d(None, ssn=ssn, probs=pr)
             lg = predict_logits_2d(self.models, self.x if tta else self.x[0], **self._kw)
             return lg, process_output_2d(lg, ssn=ssn)
 
@@ -129,14 +140,16 @@ class GraphedPredictor2D:
 
 
 @torch.no_grad()
-def process_output_2d(logits: torch.Tensor, ssn: bool = False) -> Dict[str, torch.Tensor]:
-    """logits (B, Npred, C, H, W) -> per-image maps like process_output: softmax_pred (B, Npred, C, H, W),
+def process_output_2d(logits: Optional[torch.Tensor], ssn: bool = False, probs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """logits (B, Npred, C, H, W) -- or probs, their class softmax from predict_logits_2d(softmax=True) -- -> per-image maps like process_output: softmax_pred (B, Npred, C, H, W),
     mean_softmax (B, C, H, W), pred_seg (B, H, W) u8 argmax of the mean (save_prediction, test_2D.py:116-149) and
     pred_entropy [/ aleatoric_uncertainty / epistemic_uncertainty] (B, H, W)."""
     lib = _lib.load()
-    B, T, Cc, H, W = logits.shape
-    probs = torch.empty_like(logits)
-    _lib.check(lib.vx_softmax_planar(_lib.ptr(logits), B * T, Cc, H * W, _lib.ptr(probs), _lib.stream_ptr()), "vx_softmax_planar")
+    if probs is None:
+        B, T, Cc, H, W = logits.shape
+        probs = torch.empty_like(logits)
+        _lib.check(lib.vx_softmax_planar(_lib.ptr(logits), B * T, Cc, H * W, _lib.ptr(probs), _lib.stream_ptr()), "vx_softmax_planar")
+    B, T, Cc, H, W = probs.shape
     m = uncertainty_maps(probs, from_logits=False)
     out = {"softmax_pred": probs, "mean_softmax": m["mean_softmax"], "pred_seg": m["argmax"]}
     if T > 1:
@@ -144,7 +157,7 @@ def process_output_2d(logits: torch.Tensor, ssn: bool = False) -> Dict[str, torc
         a, e = ("aleatoric_uncertainty", "epistemic_uncertainty") if not ssn else ("epistemic_uncertainty", "aleatoric_uncertainty")
         out[a], out[e] = m["expected_entropy"], m["mutual_information"]
     else:  # calculate_one_minus_msr: 1 - max softmax under the key "pred_entropy" (test_3D.py:521-525)
-        msr = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
+        msr = torch.empty((B, H, W), dtype=torch.float32, device=probs.device)
         for b in range(B):
             _lib.check(lib.vx_one_minus_msr(_lib.ptr(probs[b, 0]), _lib.VX_F32, Cc, H * W, _lib.ptr(msr[b]), _lib.stream_ptr()),
                        "vx_one_minus_msr")

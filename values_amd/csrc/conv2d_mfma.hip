@@ -297,7 +297,7 @@ static inline C2Cfg c2_config(int KS, int S, int Cout) {
   C2Cfg c;
   c.NT = (Cout % 48 == 0) ? 3 : ((Cout % 32 == 0) ? 2 : 1);
   c.NSUB = KS == 1 ? 4 : 1;
-  c.TY = S == 2 ? 8 : 16;
+  c.TY = 16;
   return c;
 }
 
@@ -354,7 +354,7 @@ extern "C" int vx_pack_conv2d(const float* w_torch, float* w_packed, int Cin, in
 
 extern "C" int vx_conv2d_tiles(int H, int W, int KS, int S) {
   const int OH = (H + 2 * (KS / 2) - KS) / S + 1, OW = (W + 2 * (KS / 2) - KS) / S + 1;
-  const int TY = S == 2 ? 8 : 16;
+  const int TY = 16;
   return ((OW + 15) / 16) * ((OH + TY - 1) / TY);
 }
 
@@ -431,6 +431,6 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   hipStream_t s = (hipStream_t)stream;
   if (a.KS == 3 && a.S == 1) return dispatch_c2<3, 1, 1, 16>(ka, c.NT, s);
-  if (a.KS == 3 && a.S == 2) return dispatch_c2<3, 2, 1, 8>(ka, c.NT, s);
+  if (a.KS == 3 && a.S == 2) return dispatch_c2<3, 2, 1, 16>(ka, c.NT, s);
   return dispatch_c2<1, 1, 4, 16>(ka, c.NT, s);
 }

@@ -452,7 +452,7 @@ static inline C2SCfg c2s_config(int KS, int S, int Cout) {
     if (cost < bestc) { bestc = cost; c.NT = nt; }   // ties: the smaller tile count (less padding)
   }
   c.NSUB = KS == 1 ? 4 : 1;
-  c.TY = S == 2 ? 8 : 16;
+  c.TY = 16;
   return c;
 }
 int vx_conv2d_s16_row_tiles(int KS, int Cout) { return c2s_config(KS, 1, Cout).NT; }
@@ -565,12 +565,11 @@ int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s) {
   // not change ([chunk][step] with five steps per sub-block is the same sequence either way).  Stride 2 with three
   // sub-blocks does not fit (120 KB of parity planes + 92 KB of weights).
   const int nsub = a.Cin / 16;
-  if (a.KS == 3 && !vx_cfg().c2s_no_wide && (nsub == 2 || (nsub == 3 && a.S == 1))) {
+  if (a.KS == 3 && a.S == 1 && !vx_cfg().c2s_no_wide && (nsub == 2 || nsub == 3)) {
     ka.nchunks = 1;
-    if (a.S == 1) return nsub == 2 ? dispatch_c2s<3, 1, 2, 16>(ka, c.NT, s) : dispatch_c2s<3, 1, 3, 16>(ka, c.NT, s);
-    return dispatch_c2s<3, 2, 2, 8>(ka, c.NT, s);
+    return nsub == 2 ? dispatch_c2s<3, 1, 2, 16>(ka, c.NT, s) : dispatch_c2s<3, 1, 3, 16>(ka, c.NT, s);
   }
   if (a.KS == 3 && a.S == 1) return dispatch_c2s<3, 1, 1, 16>(ka, c.NT, s);
-  if (a.KS == 3 && a.S == 2) return dispatch_c2s<3, 2, 1, 8>(ka, c.NT, s);
+  if (a.KS == 3 && a.S == 2) return dispatch_c2s<3, 2, 1, 16>(ka, c.NT, s);
   return dispatch_c2s<1, 1, 4, 16>(ka, c.NT, s);
 }

@@ -89,6 +89,8 @@ typedef struct vx_config {
                               instead of reading the once-per-volume output of vx_prenorm_split */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
+  int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of
+                              the octet-granular one (3 / 7 steps).  Changes the packed layout (vx_conv2d_family) */
 } vx_config;
 int vx_get_config(vx_config* out);
 int vx_set_config(const vx_config* cfg);

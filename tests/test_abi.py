@@ -95,7 +95,15 @@ def test_host_only_queries(lib, vxcfg):
     assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (3, 8))] == [2, 1, 0]
     # 2D split-fp16 family = 10 + row tiles per workgroup (the packed layout is [row group][...][row tile])
     assert [lib.vx_conv2d_family(64, co, ks) for co, ks in ((64, 3), (720, 1), (64, 5))] == [12, 15, 0]
-    assert [lib.vx_conv2d_family(18, co, 3) for co in (18, 36, 72, 144, 48, 96, 19)] == [12, 13, 13, 13, 13, 13, 12]
+    # + 100 x the octets of the octet-granular K schedule for 3x3 layers of <= 8 or 17..24 REAL input channels (round 3)
+    assert [lib.vx_conv2d_family(18, co, 3) for co in (18, 36, 72, 144, 48, 96, 19)] == [312, 313, 313, 313, 313, 313, 312]
+    assert [lib.vx_conv2d_family(ci, 64, 3) for ci in (3, 8, 9, 16, 17, 24, 25, 36)] == [112, 112, 12, 12, 312, 312, 12, 12]
+    assert lib.vx_conv2d_family(18, 36, 1) == 13                    # 1x1 layers keep the sub-block schedule
+    assert lib.vx_conv2d_packed_floats(18, 18, 3) == 7 * 2 * 2 * 64 * 8 // 2      # 7 K steps x 2 row tiles, not 10
+    assert lib.vx_conv2d_packed_floats(3, 64, 3) == 2 * 3 * 2 * 2 * 64 * 8 // 2   # 2 row groups x 3 steps x 2 tiles
+    vxcfg.set(c2s_no_oct=1)
+    assert lib.vx_conv2d_family(18, 18, 3) == 12 and lib.vx_conv2d_packed_floats(18, 18, 3) == 10 * 2 * 2 * 64 * 8 // 2
+    vxcfg.set(c2s_no_oct=0)
     assert [lib.vx_conv2d_family(270, co, 1) for co in (270, 720, 19)] == [15, 15, 12]
     vxcfg.set(conv_fp32=1)      # native-fp32 kernels: their own packings and families
     assert lib.vx_conv3d_k3_packed_floats(16, 8) == 27 * 16 * 8   # Cout == 8, Cin in {8, 16}: 4x4x1 kernel, dense

@@ -82,6 +82,7 @@ def test_conv2d_matches_oracle(cin, cout, ks, s, shape, mode, vxcfg):
 @pytest.mark.parametrize("cin,cout,ks,s,shape", [
     (18, 18, 3, 1, (2, 20, 33)), (36, 36, 3, 1, (1, 16, 30)), (18, 36, 3, 2, (2, 17, 31)), (3, 64, 3, 2, (1, 32, 48)),
     (36, 72, 3, 2, (1, 16, 30)), (270, 19, 1, 1, (1, 9, 14)), (40, 48, 3, 1, (1, 8, 15)),
+    (8, 16, 3, 1, (1, 16, 20)), (24, 24, 3, 2, (1, 16, 31)), (17, 18, 3, 1, (1, 9, 17)), (5, 36, 3, 2, (2, 33, 18)),
 ])
 @pytest.mark.parametrize("mode", ["split16", "fp32"])
 def test_conv2d_narrow_input_pitch_and_whole_cin_items(cin, cout, ks, s, shape, mode, vxcfg):
@@ -109,6 +110,21 @@ def test_conv2d_narrow_input_pitch_and_whole_cin_items(cin, cout, ks, s, shape, 
         finally:
             vxcfg.set(c2s_no_wide=0)
         assert torch.equal(got, per_sub) and torch.equal(st, st2)
+        # (3) 3x3 layers of <= 8 / 17..24 real input channels are packed for the octet-granular K schedule (3 / 7 steps of four
+        # (tap, octet) units instead of 5 / 10 of two taps x a 16-channel block); c2s_no_oct: the sub-block packing -- another
+        # summation order, the same oracle
+        lib = _lib.load()
+        oct_family = lib.vx_conv2d_family(cin, cout, ks) >= 100
+        assert oct_family == (ks == 3 and (cin <= 8 or 16 < cin <= 24))
+        vxcfg.set(c2s_no_oct=1)
+        try:
+            assert lib.vx_conv2d_family(cin, cout, ks) < 100
+            sub_k, _, _ = run_conv2d(x, wt, None, ks, s, narrow=True)
+        finally:
+            vxcfg.set(c2s_no_oct=0)
+        assert (sub_k.double() - ref).abs().max().item() < 3e-5
+        if not oct_family:
+            assert torch.equal(got, sub_k)
 
 
 def test_conv2d_pitch_offset_into_concat():

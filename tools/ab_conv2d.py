@@ -40,24 +40,25 @@ def make(lib, spec):
     pre = f[6] if len(f) > 6 else 0
     g = torch.Generator(device="cpu").manual_seed(7)
     cp = (cin + 15) // 16 * 16
-    x = torch.zeros((N, H, W, cp)); x[..., :cin] = torch.randn((N, H, W, cin), generator=g); x = x.to(dev)
-    w = torch.zeros((cout, cp, ks, ks)); w[:, :cin] = torch.randn((cout, cin, ks, ks), generator=g) * 0.05; w = w.to(dev)
-    wp = torch.empty(lib.vx_conv2d_packed_floats(cp, cout, ks), dtype=torch.float32, device=dev)
-    assert lib.vx_pack_conv2d(_lib.ptr(w), _lib.ptr(wp), cp, cout, ks, _lib.stream_ptr()) == 0
+    pit = (cin + 3) // 4 * 4                                              # activations travel at pitch round4(C)
+    x = torch.zeros((N, H, W, pit)); x[..., :cin] = torch.randn((N, H, W, cin), generator=g); x = x.to(dev)
+    w = (torch.randn((cout, cin, ks, ks), generator=g) * 0.05).to(dev)      # packed with the REAL channel count, as the model does
+    wp = torch.empty(lib.vx_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=dev)
+    assert lib.vx_pack_conv2d(_lib.ptr(w), _lib.ptr(wp), cin, cout, ks, _lib.stream_ptr()) == 0
     oh = (H + 2 * (ks // 2) - ks) // stride + 1; ow = (W + 2 * (ks // 2) - ks) // stride + 1
     pitch = (cout + 15) // 16 * 16
     out = torch.zeros((N, oh, ow, pitch), device=dev)
     a = _lib.Conv2dArgs()
-    a.w_family = lib.vx_conv2d_family(cp, cout, ks)
-    a.in_ = x.data_ptr(); a.in_pitch = cp; a.w_packed = wp.data_ptr(); a.bias = None
+    a.w_family = lib.vx_conv2d_family(cin, cout, ks)
+    a.in_ = x.data_ptr(); a.in_pitch = pit; a.w_packed = wp.data_ptr(); a.bias = None
     a.out = out.data_ptr(); a.out_pitch = pitch; a.out_coff = 0
     a.N, a.H, a.W, a.Cin, a.Cout, a.KS, a.S = N, H, W, cp, cout, ks, stride
     part = torch.empty((N * lib.vx_conv2d_tiles(H, W, ks, stride), cout, 2), device=dev)
     a.stats_partial = part.data_ptr()
     keep.extend([x, w, wp, out, part])
     if pre:
-        sc = torch.ones((1, cp), device=dev); sh = torch.zeros((1, cp), device=dev)
-        a.in_scale, a.in_shift, a.in_relu, a.in_cpitch, a.in_group_images = sc.data_ptr(), sh.data_ptr(), 1, cp, 0
+        sc = torch.ones((1, pit), device=dev); sh = torch.zeros((1, pit), device=dev)
+        a.in_scale, a.in_shift, a.in_relu, a.in_cpitch, a.in_group_images = sc.data_ptr(), sh.data_ptr(), 1, pit, 0
         keep.extend([sc, sh])
     return a
 

@@ -77,7 +77,7 @@ class Config(C.Structure):
         "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
         "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
         "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
-        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit", "c2s_no_wide")]
+        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -230,7 +230,7 @@ def pack_mode():
     cache on it, and every launch carries the family its weights were packed for (w_family): the library refuses a
     mismatch."""
     c = get_config()
-    return (c.conv_fp32, c.conv_no_c8, c.s16_no_xp, c.c2s_no_nt5)
+    return (c.conv_fp32, c.conv_no_c8, c.s16_no_xp, c.c2s_no_nt5, c.c2s_no_oct)
 
 
 def check(rc: int, what: str = ""):

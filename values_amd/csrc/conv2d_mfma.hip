@@ -23,6 +23,7 @@ int64_t vx_conv2d_s16_packed_floats(int Cin, int Cout, int KS);
 int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, hipStream_t s);
 int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s);
 int vx_conv2d_s16_row_tiles(int KS, int Cout);
+int vx_conv2d_s16_octets(int Cin, int KS);
 static inline bool c2_split16() { return vx_cfg().conv_fp32 == 0; }
 
 struct Conv2dKArgs {
@@ -327,7 +328,9 @@ static inline int c2_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1
 extern "C" int vx_conv2d_family(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return 0;
   if (!c2_split16()) return 3;
-  return 10 + vx_conv2d_s16_row_tiles(KS, Cout);   // the packed layout is [row group][...][row tile]: bound to the tile count
+  // the packed layout is [row group][...][row tile]: bound to the tile count; + 100 x the octets of the octet-granular K
+  // schedule when the layer's REAL input channel count is packed for it (vx_conv2d_s16_octets)
+  return 10 + vx_conv2d_s16_row_tiles(KS, Cout) + 100 * vx_conv2d_s16_octets(Cin, KS);
 }
 
 extern "C" int64_t vx_conv2d_packed_floats(int Cin, int Cout, int KS) {
@@ -403,9 +406,16 @@ extern "C" int vx_conv2d(const vx_conv2d_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: Cin=%d must be a positive multiple of 16 (pad the input), Cout=%d positive", a.Cin, a.Cout);
   if ((a.KS != 1 && a.KS != 3) || (a.S != 1 && a.S != 2) || (a.KS == 1 && a.S != 1))
     VX_FAIL(VX_E_SHAPE, "vx_conv2d: kernel %d stride %d unsupported (3x3 s1/s2, 1x1 s1)", a.KS, a.S);
-  if (a.w_family != vx_conv2d_family(a.Cin, a.Cout, a.KS))
-    VX_FAIL(VX_E_DTYPE, "vx_conv2d: weights packed for kernel family %d, the library is configured for family %d: re-pack them",
-            a.w_family, vx_conv2d_family(a.Cin, a.Cout, a.KS));
+  {
+    // a.Cin is the PADDED channel count; weights packed for the octet-granular schedule carry their octet count in the
+    // family (the real count was 8 oct - 7 .. 8 oct): accepted when it pads to this Cin
+    const int fam = vx_conv2d_family(a.Cin, a.Cout, a.KS), oct = a.w_family / 100;
+    const bool octet_ok = oct > 0 && c2_split16() && a.KS == 3 && (oct * 8 + 15) / 16 * 16 == a.Cin &&
+                          vx_conv2d_s16_octets(oct * 8, a.KS) == oct && a.w_family % 100 == fam % 100;
+    if (a.w_family != fam && !octet_ok)
+      VX_FAIL(VX_E_DTYPE, "vx_conv2d: weights packed for kernel family %d, the library is configured for family %d: re-pack them",
+              a.w_family, fam);
+  }
   // outputs leave as 16-byte groups of 4 channels: a Cout that is not a multiple of 4 writes its last group up to
   // round4(Cout) (zeros beyond Cout), which the pitch must cover
   if (a.in_pitch <= a.Cin - 16 || a.in_pitch % 4 || a.out_pitch < a.out_coff + (a.Cout + 3) / 4 * 4 || a.out_pitch % 4 || a.out_coff % 4)

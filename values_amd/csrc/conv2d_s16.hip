@@ -61,7 +61,12 @@ __device__ __forceinline__ float row_ror(float x, int rot) {
   return __builtin_bit_cast(float, r);
 }
 
-template <int KS, int S, int NT, int NSUB, int TY>
+// OCT > 0 (3x3 only, round 3): OCTET-granular K.  The legacy schedule spends a K = 32 step on two taps x one 16-channel
+// sub-block, so an 18-channel layer (two sub-blocks) takes 10 steps and the 3-channel image 5; here a step holds four
+// (tap, octet) units of 8 channels, u = 4 step + k-group -> tap = u / OCT, octet = u % OCT: 18 channels (OCT = 3) take 7
+// steps, up to 8 channels (OCT = 1) 3.  One work item per tile, weights resident; the packed layout is its own
+// (pack_conv2d_s16_kernel, vx_conv2d_family = ... + 100 OCT).
+template <int KS, int S, int NT, int NSUB, int TY, int OCT = 0>
 __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   constexpr int NW = 8, NTH = 512, TX = 16;
   constexpr int R = TY / NW;
@@ -70,13 +75,17 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   constexpr int PXW = (HX + S - 1) / S, PYH = (HY + S - 1) / S;   // positions per parity plane
   constexpr int NPP = PXW * PYH;
   constexpr int PLANE = ((NPAR * NPP + 15) / 16) * 16;            // positions per (sub, octet) plane, 16-aligned
-  constexpr int IMG_H = NSUB * 2 * PLANE * 8;                     // halves per precision plane
+  static_assert(OCT == 0 || (KS == 3 && NSUB == 1), "octet-granular K: 3x3 layers, one item per tile");
+  constexpr int NOCTP = OCT ? OCT : 2 * NSUB;                     // octet planes of the LDS image
+  constexpr int QPP = 2 * NOCTP;                                  // 16-byte quads staged per pixel
+  constexpr int IMG_H = NOCTP * PLANE * 8;                        // halves per precision plane
   constexpr int IN_FLOATS = IMG_H;                                // (hi + lo planes = 2 * IMG_H halves = IMG_H floats)
-  constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;            // K = 32 steps per item
+  constexpr int NSTEP = KS == 3 ? (OCT ? (9 * OCT + 3) / 4 : 5 * NSUB) : NSUB / 2;   // K = 32 steps per item
+  constexpr int TABC = OCT ? ((OCT * 8 + 15) / 16) * 16 : NSUB * 16;                 // channels of the prologue table
   constexpr int W_STEP = NT * 2 * 64 * 8;                         // weight halves per step
   constexpr int W_FLOATS = NSTEP * W_STEP / 2;                    // per item (chunk), in floats
   static_assert(KS == 3 || NSUB % 2 == 0, "1x1: sub-blocks are consumed in pairs");
-  constexpr int NPIECE = HX * HY * 4 * NSUB;                      // 16-byte pieces of the input tile
+  constexpr int NPIECE = HX * HY * QPP;                           // 16-byte pieces of the input tile
   constexpr int IN_IT = (NPIECE + NTH - 1) / NTH;
   constexpr int W_IT = (W_FLOATS / 4 + NTH - 1) / NTH;
   static_assert(TY % NW == 0 && IN_IT <= 16, "tile config");
@@ -113,19 +122,20 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   unsigned voff[IN_IT];
   int ldst[IN_IT];
   unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0;
-  // (the piece's sub-block rides in bits 24.. of ldst: one register per piece less across the multiply phase)
+  // (the piece's channel quad rides in bits 24.. of ldst: one register per piece less across the multiply phase)
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
     const int idx = tid + it * NTH;
-    const int q = idx % 4;
-    const int pix = (idx / 4) % (HX * HY);
-    const int sub = idx / (4 * HX * HY);
+    // qq = the piece's channel quad (channels 4 qq .. 4 qq + 3).  Legacy order [sub-block][pixel][quad of the block] (a
+    // thread's quad within its block is tid % 4 in every iteration); octet mode [pixel][quad]
+    const int pix = OCT ? (idx / QPP) % (HX * HY) : (idx / 4) % (HX * HY);
+    const int qq = OCT ? idx % QPP : (idx / (4 * HX * HY)) * 4 + idx % 4;
     const int hx = pix % HX, hy = pix / HX;
     const int dxr = hx - KS / 2, dyr = hy - KS / 2;       // input pixel relative to the tile's input origin
-    voff[it] = (unsigned)((dyr * rowf + dxr * a.in_pitch + sub * 16 + q * 4 + biasf) * 4);
+    voff[it] = (unsigned)((dyr * rowf + dxr * a.in_pitch + qq * 4 + biasf) * 4);
     const int par = (hy % S) * S + (hx % S);
-    ldst[it] = ((sub * 2 + (q >> 1)) * PLANE + par * NPP + (hy / S) * PXW + hx / S) * 8 + (q & 1) * 4;   // halves
-    ldst[it] |= sub << 24;
+    ldst[it] = ((qq >> 1) * PLANE + par * NPP + (hy / S) * PXW + hx / S) * 8 + (qq & 1) * 4;   // halves
+    ldst[it] |= qq << 24;
     if (idx >= NPIECE) ibad_always |= 1u << it;
     if (dxr < 0) ibad_xlo |= 1u << it;
     if (dxr >= a.W - lastx * S) ibad_xhi |= 1u << it;
@@ -134,12 +144,18 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   }
   // this lane's (tap | sub-block, octet) of every step, as a position offset into a precision plane.  3x3: the five steps
   // of a sub-block repeat for the next one 2 PLANE positions further -- five registers, the rest an immediate offset
-  constexpr int NTOFF = KS == 3 ? 5 : NSTEP;
+  constexpr int NTOFF = OCT ? NSTEP : (KS == 3 ? 5 : NSTEP);
   int toff[NTOFF];
 #pragma unroll
   for (int s = 0; s < NTOFF; ++s) {
     const int oct = g & 1;
-    if (KS == 3) {
+    if (OCT) {
+      int u = 4 * s + g;                          // this lane's (tap, octet) unit of the step
+      if (u > 9 * OCT - 1) u = 9 * OCT - 1;       // zero-weight padding units re-read a valid position
+      const int tap = u / OCT, o = u % OCT;
+      const int ky = tap / 3, kx = tap % 3;
+      toff[s] = o * PLANE + ((ky % S) * S + (kx % S)) * NPP + (ky / S) * PXW + kx / S;
+    } else if (KS == 3) {
       int tap = 2 * s + (g >> 1);
       if (tap > 8) tap = 8;                       // zero-weight padding tap: re-read a valid position
       const int ky = tap / 3, kx = tap % 3;
@@ -160,14 +176,14 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
   const float* w_cg = a.w_packed + (size_t)cg * ka.nchunks * W_FLOATS;
   // whole-Cin items (3x3, NSUB > 1: vx_conv2d_s16 runs them with ONE chunk): the weights are copied once, no weight
   // prefetch registers live across the multiply phase
-  constexpr bool WRES = KS == 3 && NSUB > 1;
+  constexpr bool WRES = (KS == 3 && NSUB > 1) || OCT > 0;
   f32x4 ibuf[IN_IT], wbuf[WRES ? 1 : W_IT];
   // prologue (vx_conv2d_args.in_scale): the folded BatchNorm of the PRODUCING conv (+ ReLU) applied on the way into LDS.
   // The scale / shift rows of the item's image group are staged into a small LDS table by prefetch() (after the second
   // barrier of the previous item: commit() of this item reads them behind the next barrier).
   const bool pre = a.in_scale != nullptr;
   const int w_res_floats = (ka.w_all ? ka.nchunks : 1) * W_FLOATS;   // LDS floats the weights take
-  float* s_ss = smem + IN_FLOATS + w_res_floats + NW * NT * 16 * 2;  // [scale | shift][NSUB * 16] of the item's chunk
+  float* s_ss = smem + IN_FLOATS + w_res_floats + NW * NT * 16 * 2;  // [scale | shift][TABC] of the item's chunk
   unsigned p_bad = 0;
   const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     unsigned cbad = 0;
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it)
-      if ((ldst[it] >> 24) * 16 + (tid & 3) * 4 >= clim) cbad |= 1u << it;   // NTH % 4 == 0: the piece's quad is tid % 4
+      if ((ldst[it] >> 24) * 4 >= clim) cbad |= 1u << it;
     bad |= cbad;
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
@@ -200,8 +216,8 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
     if (pre) {
       p_bad = bad;
       // this chunk's channels of the image's statistics group (channels beyond Cin: scale = shift = 0 -> zeros)
-      if (tid < 2 * NSUB * 16) {
-        const int which = tid / (NSUB * 16), c = tid % (NSUB * 16), ch = chunk * NSUB * 16 + c;
+      if (tid < 2 * TABC) {
+        const int which = tid / TABC, c = tid % TABC, ch = chunk * NSUB * 16 + c;
         const int grp = a.in_group_images > 0 ? (have ? n : 0) / a.in_group_images : 0;
         const float* row = (which ? a.in_shift : a.in_scale) + (size_t)grp * a.in_cpitch;
         s_ss[tid] = ch < min(a.Cin, a.in_cpitch) ? row[ch] : 0.f;
@@ -224,9 +240,9 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
       if (tid + it * NTH < NPIECE) {
         f16x4 hi, lo;
         if (pre) {
-          const int c = (ldst[it] >> 24) * 16 + (tid & 3) * 4;           // NTH % 4 == 0: the lane's quad is idx % 4 in every iteration
+          const int c = (ldst[it] >> 24) * 4;
           const f32x4 sc = *reinterpret_cast<const f32x4*>(s_ss + c);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(s_ss + NSUB * 16 + c);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(s_ss + TABC + c);
           f32x4 v = ibuf[it];
           const bool zero = (p_bad >> it) & 1u;                        // zero padding belongs to the activated tensor
 #pragma unroll
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         for (int r = 0; r < R; ++r) {
           // output row r of the wave = PXW positions further: one address register per step, the rest is the
           // instruction's immediate offset (conv3d_s16.hip)
-          const int p = (vbase[0] + toff[KS == 3 ? s % 5 : s]) * 8 + (KS == 3 ? (s / 5) * 2 * PLANE * 8 : 0) + r * PXW * 8;
+          const int p = (vbase[0] + toff[(KS == 3 && !OCT) ? s % 5 : s]) * 8 + ((KS == 3 && !OCT) ? (s / 5) * 2 * PLANE * 8 : 0) + r * PXW * 8;
           bh[slot][r] = *reinterpret_cast<const f16x8*>(s_hi + p);
           bl[slot][r] = *reinterpret_cast<const f16x8*>(s_lo + p);
         }
@@ -350,7 +366,8 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         // the schedule, pinned (conv3d_s16.hip): one fragment read of step s + 1 behind each of this step's first matrix
         // instructions -- left alone hipcc sinks every read to just before its consumer and the LDS latency is exposed
         // (not the five-row-tile 1x1 instance: it spills as it is, and ten times more with two sets of fragments live)
-        if constexpr (!(KS == 1 && NT >= 5)) {
+        // (nor the stride-2, three-row-tile octet instance: 13 staged pieces per thread leave no room for the second set)
+        if constexpr (!(KS == 1 && NT >= 5) && !(OCT == 3 && S == 2 && NT == 3)) {
           constexpr int NRD = 2 * NT + 2 * R, NMF = 3 * R * NT;
           constexpr int PAIRS = NRD < NMF ? NRD : NMF;
           if (s == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
@@ -456,12 +473,23 @@ static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   return c;
 }
 int vx_conv2d_s16_row_tiles(int KS, int Cout) { return c2s_config(KS, 1, Cout).NT; }
+// octets of the octet-granular K schedule (conv2d_s16_kernel's OCT) a 3x3 layer of Cin REAL input channels is packed for;
+// 0 = the sub-block schedule.  1: up to 8 channels (the image: 3 instead of 5 K steps); 3: 17..24 channels (HRNet-W18's
+// full-resolution branch: 7 instead of 10).  Two octets are one sub-block (the same 5 steps), 4 and 6 save one step of 10 /
+// 15, and five octets (36 channels) would save 3 of 15 but do not fit beside the stride-2 parity planes: not built.
+int vx_conv2d_s16_octets(int Cin, int KS) {
+  if (KS != 3 || vx_cfg().c2s_no_oct) return 0;
+  if (Cin <= 8) return 1;
+  if (Cin > 16 && Cin <= 24) return 3;
+  return 0;
+}
 static inline int c2s_rows_padded(int Cout, int NT) { return ((Cout + 16 * NT - 1) / (16 * NT)) * (16 * NT); }
 
-// torch (Cout, Cin, KS, KS) fp32 -> [row group][chunk][step][nt][hi | lo][lane][8 halves]
+// torch (Cout, Cin, KS, KS) fp32 -> [row group][chunk][step][nt][hi | lo][lane][8 halves]; OCT > 0: one chunk, k-group kg of
+// step s = unit u = 4 s + kg -> (tap u / OCT, octet u % OCT), units beyond 9 OCT are zeros
 __global__ void pack_conv2d_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int KS,
-                                       int NT, int NSUB, int nchunks, int64_t total) {
-  const int nstep = KS == 3 ? 5 * NSUB : NSUB / 2, ntap = KS * KS;
+                                       int NT, int NSUB, int nchunks, int64_t total, int OCT) {
+  const int nstep = OCT ? (9 * OCT + 3) / 4 : (KS == 3 ? 5 * NSUB : NSUB / 2), ntap = KS * KS;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int j = r % 8; r /= 8;
@@ -473,10 +501,16 @@ __global__ void pack_conv2d_s16_kernel(const float* __restrict__ w, _Float16* __
     const int rgrp = (int)r;
     const int row = (rgrp * NT + nt) * 16 + (lane & 15);
     const int kg = lane >> 4;
-    int tap, sub;
-    if (KS == 3) { sub = chunk * NSUB + step / 5; tap = 2 * (step % 5) + (kg >> 1); }
-    else { sub = chunk * NSUB + 2 * step + (kg >> 1); tap = 0; }
-    const int ci = sub * 16 + 8 * (kg & 1) + j;
+    int tap, sub, ci;
+    if (OCT) {
+      const int u = 4 * step + kg;
+      tap = u < 9 * OCT ? u / OCT : ntap;
+      ci = (u % OCT) * 8 + j;
+    } else {
+      if (KS == 3) { sub = chunk * NSUB + step / 5; tap = 2 * (step % 5) + (kg >> 1); }
+      else { sub = chunk * NSUB + 2 * step + (kg >> 1); tap = 0; }
+      ci = sub * 16 + 8 * (kg & 1) + j;
+    }
     float v = 0.f;
     if (row < Cout && ci < Cin && tap < ntap) v = w[((size_t)row * Cin + ci) * ntap + tap];
     const _Float16 h = (_Float16)v;
@@ -486,38 +520,41 @@ __global__ void pack_conv2d_s16_kernel(const float* __restrict__ w, _Float16* __
 
 int64_t vx_conv2d_s16_packed_floats(int Cin, int Cout, int KS) {
   const C2SCfg c = c2s_config(KS, 1, Cout);
-  const int nsub_all = (Cin + 15) / 16, nchunks = (nsub_all + c.NSUB - 1) / c.NSUB;
-  const int nstep = KS == 3 ? 5 * c.NSUB : c.NSUB / 2;
+  const int oct = vx_conv2d_s16_octets(Cin, KS);
+  const int nsub_all = (Cin + 15) / 16, nchunks = oct ? 1 : (nsub_all + c.NSUB - 1) / c.NSUB;
+  const int nstep = oct ? (9 * oct + 3) / 4 : (KS == 3 ? 5 * c.NSUB : c.NSUB / 2);
   return (int64_t)(c2s_rows_padded(Cout, c.NT) / 16 / c.NT) * nchunks * nstep * c.NT * 2 * 64 * 8 / 2;
 }
 
 int vx_pack_conv2d_s16(const float* w_torch, float* w_packed, int Cin, int Cout, int KS, hipStream_t s) {
   const C2SCfg c = c2s_config(KS, 1, Cout);
-  const int nsub_all = (Cin + 15) / 16, nchunks = (nsub_all + c.NSUB - 1) / c.NSUB;
+  const int oct = vx_conv2d_s16_octets(Cin, KS);
+  const int nsub_all = (Cin + 15) / 16, nchunks = oct ? 1 : (nsub_all + c.NSUB - 1) / c.NSUB;
   const int64_t total = vx_conv2d_s16_packed_floats(Cin, Cout, KS) * 2;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv2d_s16_kernel, dim3(blocks), dim3(256), 0, s, w_torch, reinterpret_cast<_Float16*>(w_packed), Cin,
-                     Cout, KS, c.NT, c.NSUB, nchunks, total);
+                     Cout, KS, c.NT, c.NSUB, nchunks, total, oct);
   VX_CHECK_LAUNCH("vx_pack_conv2d(s16)");
   return VX_OK;
 }
 
-template <int KS, int S, int NT, int NSUB, int TY>
+template <int KS, int S, int NT, int NSUB, int TY, int OCT = 0>
 static int launch_c2s(const Conv2dSArgs& ka_in, hipStream_t s) {
   constexpr int HX = 15 * S + KS, HY = (TY - 1) * S + KS;
   constexpr int NPP = ((HX + S - 1) / S) * ((HY + S - 1) / S);
   constexpr int PLANE = ((S * S * NPP + 15) / 16) * 16;
-  constexpr int IMG_H = NSUB * 2 * PLANE * 8;
-  constexpr int NSTEP = KS == 3 ? 5 * NSUB : NSUB / 2;
+  constexpr int IMG_H = (OCT ? OCT : 2 * NSUB) * PLANE * 8;
+  constexpr int NSTEP = KS == 3 ? (OCT ? (9 * OCT + 3) / 4 : 5 * NSUB) : NSUB / 2;
+  constexpr int TABC = OCT ? ((OCT * 8 + 15) / 16) * 16 : NSUB * 16;
   constexpr size_t wch = (size_t)NSTEP * NT * 2 * 64 * 8 * 2;
-  constexpr size_t rest = (size_t)IMG_H * 4 + (size_t)8 * NT * 16 * 2 * 4 + (size_t)2 * NSUB * 16 * 4;   // image, statistics, prologue table
+  constexpr size_t rest = (size_t)IMG_H * 4 + (size_t)8 * NT * 16 * 2 * 4 + (size_t)2 * TABC * 4;   // image, statistics, prologue table
   static_assert(rest + wch <= 160 * 1024, "LDS budget");
   Conv2dSArgs ka = ka_in;
   ka.w_all = (ka.nchunks > 1 && rest + ka.nchunks * wch <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0;
   const size_t lds = rest + (ka.w_all ? ka.nchunks : 1) * wch;
   static size_t attr_lds = 0;
-  auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY>;
+  auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY, OCT>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv2d(s16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -531,21 +568,22 @@ static int launch_c2s(const Conv2dSArgs& ka_in, hipStream_t s) {
   if (per_cu > 2) per_cu = 2;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
-  static const char* kname = vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY);
+  static const char* kname = OCT ? vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY, OCT)
+                                 : vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY);
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(512), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv2d(s16)");
   return VX_OK;
 }
 
-template <int KS, int S, int NSUB, int TY>
+template <int KS, int S, int NSUB, int TY, int OCT = 0>
 static int dispatch_c2s(const Conv2dSArgs& ka, int NT, hipStream_t s) {
   if constexpr (KS == 1) {
-    if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY>(ka, s);
+    if (NT == 5) return launch_c2s<KS, S, 5, NSUB, TY, OCT>(ka, s);
   }
-  if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY>(ka, s);
-  if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY>(ka, s);
-  return launch_c2s<KS, S, 1, NSUB, TY>(ka, s);
+  if (NT == 3) return launch_c2s<KS, S, 3, NSUB, TY, OCT>(ka, s);
+  if (NT == 2) return launch_c2s<KS, S, 2, NSUB, TY, OCT>(ka, s);
+  return launch_c2s<KS, S, 1, NSUB, TY, OCT>(ka, s);
 }
 
 // arguments validated by vx_conv2d (conv2d_mfma.hip)
@@ -564,6 +602,12 @@ int vx_conv2d_s16(const vx_conv2d_args& a, hipStream_t s) {
   // together -- a third / half of the barriers, prefetches and commits, and the weights resident.  The packed layout does
   // not change ([chunk][step] with five steps per sub-block is the same sequence either way).  Stride 2 with three
   // sub-blocks does not fit (120 KB of parity planes + 92 KB of weights).
+  const int oct = a.w_family / 100;     // octet-granular K: the weights were packed for it (vx_conv2d checked the family)
+  if (oct) {
+    ka.nchunks = 1;
+    if (oct == 1) return a.S == 1 ? dispatch_c2s<3, 1, 1, 16, 1>(ka, c.NT, s) : dispatch_c2s<3, 2, 1, 16, 1>(ka, c.NT, s);
+    return a.S == 1 ? dispatch_c2s<3, 1, 1, 16, 3>(ka, c.NT, s) : dispatch_c2s<3, 2, 1, 16, 3>(ka, c.NT, s);
+  }
   const int nsub = a.Cin / 16;
   if (a.KS == 3 && a.S == 1 && !vx_cfg().c2s_no_wide && (nsub == 2 || nsub == 3)) {
     ka.nchunks = 1;

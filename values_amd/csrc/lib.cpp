@@ -76,6 +76,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_dbplain = env_int("VX_S16_NO_DBPLAIN", 0);
   g_cfg.s16_no_upsplit = env_int("VX_S16_NO_UPSPLIT", 0);
   g_cfg.c2s_no_wide = env_int("VX_C2S_NO_WIDE", 0);
+  g_cfg.c2s_no_oct = env_int("VX_C2S_NO_OCT", 0);
 }
 
 const vx_config& vx_cfg() {
@@ -98,5 +99,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 302; /* 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
+extern "C" int vx_version(void) { return 303; /* 0.3.3: vx_config.c2s_no_oct, vx_bilinear_softmax_nchw; 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
     ks, s = rng.choice([(3, 1), (3, 1), (3, 2), (1, 1)])
-    cin = rng.choice([3, 16, 18, 32, 36, 48, 64, 72, 96, 144, 192, 270]) if ks == 3 else rng.choice([16, 18, 48, 64, 96, 256, 270, 720])
+    cin = rng.choice([3, 5, 8, 16, 17, 18, 24, 25, 32, 36, 48, 64, 72, 96, 144, 192, 270]) if ks == 3 else rng.choice([16, 18, 48, 64, 96, 256, 270, 720])
     cout = rng.choice([16, 18, 32, 36, 48, 64, 72, 96, 144, 19, 4, 24, 128] + ([240, 320, 720] if ks == 1 else []))
     n = rng.randint(1, 3)
     h, w = rng.randint(1, 40), rng.randint(1, 70)
@@ -30,7 +30,7 @@ for case in range(cases):
     for mode in (0, 1):
         try:
             with _lib.config(conv_fp32=mode):
-                got, st, _ = run_conv2d(x, wt, b, ks, s)
+                got, st, _ = run_conv2d(x, wt, b, ks, s, narrow=bool(case & 1))
         except Exception as e:
             print(f"ERROR {tag} mode={mode}: {e}")
             bad += 1

@@ -277,3 +277,28 @@ def test_bilinear_softmax_nchw_is_bilinear_then_softmax(C):
     assert (pr[2].cpu().double() - ref[0]).abs().max().item() < 1e-6
     assert (pr[0].cpu().double() - torch.flip(ref[1], [-1])).abs().max().item() < 1e-6
     assert (pr[3].cpu().double() - torch.flip(ref[2], [-1, -2])).abs().max().item() < 1e-6
+
+
+def test_conv2d_weights_of_another_k_schedule_are_refused(vxcfg):
+    """The octet-granular packing of an 18-channel 3x3 layer (family 300 + row tiles) is accepted only for the Cin it pads
+    to and only while the library is configured for it: the same buffer under c2s_no_oct, or passed off as a 48-channel
+    layer's weights, is VX_E_DTYPE -- not numbers from the wrong layout."""
+    lib = _lib.load()
+    x = torch.zeros((1, 8, 16, 20), dtype=torch.float32, device=DEV)
+    wt = torch.zeros((18, 18, 3, 3), dtype=torch.float32, device=DEV)
+    wp = torch.empty(lib.vx_conv2d_packed_floats(18, 18, 3), dtype=torch.float32, device=DEV)
+    _lib.check(lib.vx_pack_conv2d(_lib.ptr(wt), _lib.ptr(wp), 18, 18, 3, _lib.stream_ptr()), "pack2d")
+    out = torch.zeros((1, 8, 16, 20), dtype=torch.float32, device=DEV)
+    a = _lib.Conv2dArgs()
+    a.w_family = lib.vx_conv2d_family(18, 18, 3)
+    assert a.w_family == 312
+    a.in_ = x.data_ptr(); a.in_pitch = 20; a.w_packed = wp.data_ptr(); a.out = out.data_ptr(); a.out_pitch = 20
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KS, a.S = 1, 8, 16, 32, 18, 3, 1
+    _lib.check(lib.vx_conv2d(C.byref(a), _lib.stream_ptr()), "the configuration it was packed under")
+    a.Cin, a.in_pitch = 48, 48          # 312 = three octets: pads to 32 input channels, not 48
+    big = torch.zeros((1, 8, 16, 48), dtype=torch.float32, device=DEV)
+    a.in_ = big.data_ptr()
+    assert lib.vx_conv2d(C.byref(a), _lib.stream_ptr()) == -3 and b"family" in lib.vx_last_error_string()
+    a.Cin, a.in_pitch, a.in_ = 32, 20, x.data_ptr()
+    vxcfg.set(c2s_no_oct=1)
+    assert lib.vx_conv2d(C.byref(a), _lib.stream_ptr()) == -3 and b"family" in lib.vx_last_error_string()

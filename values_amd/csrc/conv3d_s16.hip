@@ -964,8 +964,18 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
       return launch_s16<CB, NT, 16, 8, 4, 8, XP>(ka, s);
     }
   }
-  if (tx == 16) return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
-  if (tx == 8) return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
+  // (the decoder's LeakyReLU + hash-dropout epilogue as a compile-time instance on the small tiles too: its run-time form
+  // re-tests five flags per column tile)
+  if (tx == 16) {
+    if (epi == 1) return launch_s16<CB, NT, 16, 4, 4, 8, XP, 0, 1>(ka, s);
+    if (epi == 0) return launch_s16<CB, NT, 16, 4, 4, 8, XP, 0, 0>(ka, s);
+    return launch_s16<CB, NT, 16, 4, 4, 8, XP>(ka, s);
+  }
+  if (tx == 8) {
+    if (epi == 1) return launch_s16<CB, NT, 8, 8, 4, 8, XP, 0, 1>(ka, s);
+    if (epi == 0) return launch_s16<CB, NT, 8, 8, 4, 8, XP, 0, 0>(ka, s);
+    return launch_s16<CB, NT, 8, 8, 4, 8, XP>(ka, s);
+  }
   return launch_s16<CB, NT, 4, 4, 4, 4, XP>(ka, s);
 }
 

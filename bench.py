@@ -595,7 +595,7 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
     from values_amd import UNet3D
     from values_amd.dist import ensemble_uncertainty_sharded
     M, S = 5, args.size
-    Vg = args.volumes or 16
+    Vg = args.volumes or 64                       # 64 volumes x 5 members = 320 forwards per step and GPU, as config C2 runs (16: 3 545 volumes/s, 32: 4 371, 64: 5 067 on one box)
     V = Vg * world                                    # weak scaling: volumes per step grow with the ranks
     members = []
     for m in range(M):

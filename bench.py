@@ -662,7 +662,9 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     from values_amd.hrnet_configs import hrnet_w18_extra, hrnet_w48_extra
     from values_amd.hrnet import HighResolutionNet
     from values_amd.predict2d import GraphedPredictor2D, predict_logits_2d, process_output_2d, tta_views_8
-    B = args.volumes or 4
+    # images per step and GPU: 8 (64 views per forward) for W18 -- 142 / 149 / 151 images/s at 4 / 8 / 12 on one box; W48 holds ~25 GB of
+    # intermediates per image of a forward: 4
+    B = args.volumes or (8 if args.hrnet_width == 18 else 4)
     H, W, NC = 512, 1024, 19
     extra = hrnet_w48_extra(False) if args.hrnet_width == 48 else hrnet_w18_extra(False)
     cfg = {"MODEL": {"EXTRA": extra, "ALIGN_CORNERS": False, "INPUT_CHANNELS": 3},

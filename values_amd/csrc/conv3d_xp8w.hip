@@ -597,14 +597,15 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const bool f_lrelu = EPI == 3 ? a.act == VX_ACT_LRELU : !STATS;
     const bool f_relu = EPI == 3 && a.act == VX_ACT_RELU;
     // fused head: this lane's 4 of the 8 weights of up to 4 classes; the bias rides in the g-even lane (conv3d_s16.hip)
-    constexpr int HC = EPI == 2 ? 4 : 1;
+    constexpr bool HEAD = EPI == 2 || EPI == 5;     // EPI 5: LeakyReLU + fused head WITHOUT dropout (deterministic ensemble members)
+    constexpr int HC = HEAD ? 4 : 1;
     float hw4[HC][4], hb[HC];
 #pragma unroll
     for (int c = 0; c < HC; ++c) {
       hb[c] = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) hw4[c][k] = 0.f;
-      if (EPI == 2 && c < a.head_C) {
+      if (HEAD && c < a.head_C) {
         if (!(g & 1)) hb[c] = a.head_b[c];
 #pragma unroll
         for (int k = 0; k < 4; ++k) hw4[c][k] = a.head_w[c * 8 + oc + k];
@@ -714,7 +715,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         e_ci = ci;
         col_of(ci, e_n, e_ty, e_tx);
         if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(seed_out, a.drop_layer, (uint32_t)e_n);
-        if (EPI == 2) {
+        if (HEAD) {
           e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
           const int slot = a.head_dst ? a.head_dst[e_n] : e_n;
           int gx = e_tx * 32 + lx, gy = e_ty * 8 + ly0, gz = lz;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
         }
-        if (EPI == 2) {
+        if (HEAD) {
           float* o = e_ho + (ptrdiff_t)k * e_hz + (ptrdiff_t)r * e_hy;
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
@@ -975,13 +976,14 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   else if (a.head_out) epi = 2;
   else if (a.drop_mode == VX_DROP_HASH) epi = 1;
   else epi = 3;
-  if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // head without dropout: general kernel
+  if (epi == 2 && a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_NONE) epi = 5;        // head without dropout (ensemble members)
+  if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // other heads: general kernel
   if (epi == 1 && a.act != VX_ACT_LRELU) return 1;
   const int up = a.up_in ? 1 : 0;
   // producer waves: two per SIMD where the staging is heavy; the head epilogue (32 scattered 4-byte stores per lane and
   // item) is the longer side of its layer and runs better against one (measured per layer, tools/show_layers.py)
   // (the pooling epilogue holds 8 image rows + the window state: 128 VGPRs at 16 waves would spill 28 dwords)
-  const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 4 ? 4 : 8);
+  const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 5 || epi == 4 ? 4 : 8);
   if (a.pool_out && nch != 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): the pooled output goes with Cin = 8");
   if (a.out_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): out_split is an epilogue of the tile kernel");
   if (a.up_split && !up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): up_split without up_in");
@@ -997,6 +999,7 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
     return npw == 8 ? launch_xp8w<N_, E_, P_, U_, 8>(ka, s) : launch_xp8w<N_, E_, P_, U_, 4>(ka, s)
   XP8W_CASE(1, 4, 0, 0); XP8W_CASE(1, 4, 1, 0); XP8W_CASE(1, 4, 2, 0); XP8W_CASE(1, 0, 2, 0);
   XP8W_CASE(1, 0, 0, 0); XP8W_CASE(1, 0, 1, 0); XP8W_CASE(1, 1, 0, 0); XP8W_CASE(1, 2, 0, 0); XP8W_CASE(1, 3, 0, 0); XP8W_CASE(1, 3, 1, 0);
+  XP8W_CASE(1, 5, 0, 0);
   XP8W_CASE(2, 1, 0, 0); XP8W_CASE(2, 1, 1, 0); XP8W_CASE(2, 3, 0, 0); XP8W_CASE(2, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 1); XP8W_CASE(2, 1, 1, 1); XP8W_CASE(2, 3, 0, 1); XP8W_CASE(2, 3, 1, 1);
 #undef XP8W_CASE

@@ -88,7 +88,8 @@ class GraphedPredictor2D:
     def __init__(self, models: Sequence, example, n_pred: int = 1, tta: bool = False, hflip_views=None, vflip_views=None,
                  seeds=None, ssn: bool = False, keep_logits: bool = True):
         """keep_logits=False: the graph holds no full-resolution logits (`self.logits` is None) -- every forward's softmax
-        is taken in its upsampling pass (predict_logits_2d(softmax=True)); the maps are the same bits."""
+        is taken in its upsampling pass (predict_logits_2d(softmax=True)); the maps are the same bits.  (An SSN member's
+        draws ARE logits: with ssn=True the logits are kept whatever the flag says.)"""
         _lib.require_gpu()
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.models, self.tta = list(models), tta
@@ -145,6 +146,8 @@ def process_output_2d(logits: Optional[torch.Tensor], ssn: bool = False, probs: 
     mean_softmax (B, C, H, W), pred_seg (B, H, W) u8 argmax of the mean (save_prediction, test_2D.py:116-149) and
     pred_entropy [/ aleatoric_uncertainty / epistemic_uncertainty] (B, H, W)."""
     lib = _lib.load()
+    if probs is None and logits is None:
+        raise ValueError("process_output_2d: give logits or probs")
     if probs is None:
         B, T, Cc, H, W = logits.shape
         probs = torch.empty_like(logits)

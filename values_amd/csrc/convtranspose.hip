@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void convT_k2s2_rows_kernel(vx_convT_args a, i
 struct ConvTDecode { unsigned mW, mH, mD; };   // 2^32 / d + 1 (0: d == 1); exact while v * d < 2^32 (launcher checks)
 __device__ __forceinline__ unsigned ct_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
 
-template <int CIN, int RT>
+// MASK: the injected-mask dropout of the parity tests as its own instance -- a (run-time) branch around its mask load made
+// hipcc put an `s_waitcnt vmcnt(0)` at the join, on EVERY path: each column tile then waited for the stores of the tile
+// before and for its own freshly issued prefetch
+template <int CIN, int RT, bool MASK = false>
 __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, int ncoltiles, int nvox_in, ConvTDecode dc) {
   constexpr int Q = CIN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,11 +197,20 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
   };
   // (only where the registers allow it: with 64 / 128 input channels the extra fragments spill -- measured +40 %)
   constexpr bool PF = CIN <= 32;
+  // the lane's bias vectors, once: loaded inside the row-tile loop each of them drew an `s_waitcnt vmcnt(0)` -- which also waits
+  // for the STORES of the row tile before, so every row tile paid a store's latency (0.29 ms for a 0.84-GB launch)
+  constexpr bool HB = PF || RT <= 4;      // (64 input channels x 8 row tiles has no registers left for them)
+  f32x4 biasr[HB ? RT : 1];
+  if constexpr (HB) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) biasr[rt] = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);
+  }
   f32x4 xnext[Q];
   if constexpr (PF) {
     const int ct0 = blockIdx.x * 4 + wave;
     load_x(ct0 < ncoltiles ? ct0 : ncoltiles - 1, xnext);
   }
+  const uint32_t seed0 = vx_seed_of(a, a.drop_seed);    // (the optional device seed word: read once, not per column tile)
   for (int ct = blockIdx.x * 4 + wave; ct < ncoltiles; ct += wstride) {
     const int v = ct * 16 + m;                 // flattened input voxel of this lane's column
     const bool ok = v < nvox_in;
@@ -217,10 +229,12 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
     q = ct_div(r, dc.mH); const int y = (int)(r - q * (unsigned)a.H); r = q;
     q = ct_div(r, dc.mD); const int z = (int)(r - q * (unsigned)a.D);
     const int n = (int)q;
-    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
+    const uint32_t dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);
+      f32x4 acc;
+      if constexpr (HB) acc = biasr[rt];
+      else acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);
 #pragma unroll
       for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -239,8 +253,9 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
         const uint32_t bits = vx_drop_bits4(dkey, (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + oco[rt]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
-      } else if (a.drop_mode == VX_DROP_MASK) {
-        const uint32_t mk = ok ? *reinterpret_cast<const uint32_t*>(a.drop_mask + (orow * OW + ox) * a.Cout + oco[rt]) : 0u;
+      }
+      if constexpr (MASK) {
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (orow * OW + ox) * a.Cout + oco[rt]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * acc[j] : 0.f;
       }
@@ -250,10 +265,10 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
              ((((ox >> xs) * 2 + a.out_half) << xs) + (ox & (a.out_xblk - 1))) * a.Cout + oco[rt];
       else
         op = a.out + (orow * OW + ox) * a.out_pitch + a.out_coff + oco[rt];
-      if (ok) {
-        *reinterpret_cast<f32x4*>(op) = acc;
-        rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
-      }
+      // no `if (ok)`: the lanes beyond the last voxel were clamped onto it (vc) and store ITS values a second time -- a branch
+      // around the store made every wait for the prefetched column tile a vmcnt(0) over this tile's eight stores
+      *reinterpret_cast<f32x4*>(op) = acc;
+      rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
     }
   }
   if (a.range_flag) {
@@ -278,8 +293,12 @@ static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   dc.mW = magic(a.W); dc.mH = magic(a.H); dc.mD = magic(a.D);
   static const char* kname = vx_kname("convT_k2s2_mfma_kernel<%d,%d>", CIN, RT);
   vx_note_kernel(kname);
-  hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
-                     ncoltiles, (int)nvox, dc);
+  if (a.drop_mode == VX_DROP_MASK)
+    hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT, true>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
+                       ncoltiles, (int)nvox, dc);
+  else
+    hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT, false>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
+                       ncoltiles, (int)nvox, dc);
   VX_CHECK_LAUNCH("vx_convT_k2s2(mfma)");
   return VX_OK;
 }

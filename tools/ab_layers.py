@@ -65,7 +65,7 @@ def make(lib, spec):
         rep = 10 if (cin == 8 and N % 10 == 0) else 1
         if rep > 1:
             x2 = torch.randn((N // rep, edge, edge, edge, cin), generator=g).to(dev); a.in_ = x2.data_ptr(); keep.append(x2)
-        mean = torch.zeros((N // rep, 8), device=dev); rstd = torch.ones((N // rep, 8), device=dev)
+        mean = torch.zeros((N // rep, cin), device=dev); rstd = torch.ones((N // rep, cin), device=dev)   # (one row of Cin statistics per source sample)
         a.in_mean, a.in_rstd, a.in_drop_mode, a.in_drop_seed, a.in_drop_layer, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1, 7, 1, rep
         keep.extend([mean, rstd])
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, 1, 2

@@ -42,7 +42,7 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
         rep = 10 if (cin == 8 and N % 10 == 0) else 1
         if rep > 1:
             x = torch.randn((N // rep, edge, edge, edge, cin), device=dev); a.in_ = x.data_ptr()
-        mean = torch.zeros((N // rep, 8), device=dev); rstd = torch.ones((N // rep, 8), device=dev)
+        mean = torch.zeros((N // rep, cin), device=dev); rstd = torch.ones((N // rep, cin), device=dev)   # (one row of Cin statistics per source sample)
         a.in_mean, a.in_rstd, a.in_drop_mode, a.in_drop_seed, a.in_drop_layer, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1, 7, 1, rep
         if pre == 2:      # the once-per-volume pre-split tensor (vx_prenorm_split), as the MC-dropout forward feeds contr_1_2
             _lib.check(lib.vx_prenorm_split(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), N // rep, edge ** 3, 2.0, _lib.stream_ptr()), "presplit")

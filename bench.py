@@ -76,11 +76,15 @@ def layer_table(F=8, S=64):
     return t
 
 
-def launch_cost(kind, ci, co, edge, N):
-    """(algorithmic FLOPs, input bytes, output bytes, weight bytes) of one layer over N samples."""
+def launch_cost(kind, ci, co, edge, N, N_in=None):
+    """(algorithmic FLOPs, input bytes, output bytes, weight bytes) of one layer over N samples.  N_in: DISTINCT input
+    samples when several output samples read the same input tensor (MC-dropout: the T samples of a volume share
+    contr_1_1's output, so contr_1_2 reads it once per volume -- counting it T times overstated that layer's GB/s 1.6x)."""
     vox = edge ** 3
+    if N_in is None:
+        N_in = N
     if kind == "conv":
-        return 2.0 * 27 * ci * co * vox * N, 4.0 * ci * vox * N, 4.0 * co * vox * N, 4.0 * 27 * ci * co
+        return 2.0 * 27 * ci * co * vox * N, 4.0 * ci * vox * N_in, 4.0 * co * vox * N, 4.0 * 27 * ci * co
     if kind == "convT":
         return 2.0 * ci * co * 8 * vox * N, 4.0 * ci * vox * N, 4.0 * 8 * co * vox * N, 4.0 * 8 * ci * co
     if kind == "conv1x1":
@@ -88,7 +92,7 @@ def launch_cost(kind, ci, co, edge, N):
     return 0.0, 0.0, 0.0, 0.0
 
 
-def fused_cost(parts, tab, n_of):
+def fused_cost(parts, tab, n_of, n_in_of=None):
     """Algorithmic FLOPs and bytes of ONE launch that computes the layers `parts` in sequence: a tensor handed from one
     fused layer to the next is never moved, so the launch reads the first layer's input plus what each later layer takes
     from elsewhere (expand_1_1 after upscale2: the skip half) and writes the last layer's output."""
@@ -98,7 +102,7 @@ def fused_cost(parts, tab, n_of):
         if part not in tab:
             continue
         kind, ci, co, edge = tab[part]
-        f1, bi, bo, bw = launch_cost(kind, ci, co, edge, n_of(part))
+        f1, bi, bo, bw = launch_cost(kind, ci, co, edge, n_of(part), n_in_of(part) if n_in_of else None)
         fl += f1
         by += bw + (bi if prev_out is None else max(bi - prev_out, 0.0))
         prev_out = bo
@@ -120,7 +124,9 @@ def profiled_forward(model, x, n_samples, seed):
     run = _lib.UNet3DRun()
     run.x = x.data_ptr()
     run.N, run.D, run.H, run.W, run.repeat = N, D, H, W, n_samples
-    run.drop_mode, run.seed = _lib.VX_DROP_HASH, seed
+    # the dropout mode the model's own forward would pick (values_amd/unet3d.py:_run): deterministic ensemble members run none
+    hashed = model.training and model.dropout_prob > 0
+    run.drop_mode, run.seed = (_lib.VX_DROP_HASH if hashed else _lib.VX_DROP_NONE), seed
     run.logits = out.data_ptr()
     run.workspace = ws.data_ptr() + off
     run.workspace_bytes = ws_bytes
@@ -137,7 +143,7 @@ def profiled_forward(model, x, n_samples, seed):
     return rows
 
 
-def roofline_leg(model, x, T, reps=3):
+def roofline_leg(model, x, T, reps=3, chunks=None):
     """Per-launch HIP-event times of the forwards one step launches: the SAME volume chunks the timed path runs, one
     after the other on this stream -- so the average launch duration is the one a rocprofv3 trace of this command shows
     for the kernel.  The binding roof of the dominant kernel is the larger of flops / matrix peak and bytes / HBM peak."""
@@ -145,7 +151,8 @@ def roofline_leg(model, x, T, reps=3):
     tab = layer_table(S=x.shape[-1])
     V = x.shape[0]
     N = V * T
-    chunks, _ = _volume_chunks(V, None, False, T)
+    if chunks is None:
+        chunks, _ = _volume_chunks(V, None, False, T)
     acc = {}
     per_label = {}
     for rep in range(reps + 1):
@@ -158,7 +165,9 @@ def roofline_leg(model, x, T, reps=3):
                 per_label.setdefault(label, []).append(ms)
                 # a fused launch carries every layer it computes; MC-dropout: contr_1_1 runs once per volume (its T
                 # samples share input and statistics)
-                fl, by = fused_cost(label.split("+"), tab, lambda part: Vc if part == "contr_1_1" else Vc * T)
+                # ... and contr_1_2 reads that once-per-volume tensor: Vc distinct input samples, Vc * T output samples
+                fl, by = fused_cost(label.split("+"), tab, lambda part: Vc if part == "contr_1_1" else Vc * T,
+                                    lambda part: Vc if part in ("contr_1_1", "contr_1_2") else Vc * T)
                 name = kname or label.split(":")[0]
                 a = acc.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
                 a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
@@ -608,6 +617,13 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
         return ensemble_uncertainty_sharded(members, x, world, rank, n_pred=1)
 
     times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # one member's forward over this rank's volumes (n_pred = 1, no dropout): the launches a step issues M times
+        from values_amd.dist import ensemble_work_items
+        vb = max(1, max((v1 - v0) for _, v0, v1 in ensemble_work_items(M, V, world)[rank]))
+        roof, _ = roofline_leg(members[0], x[:vb], 1, chunks=[(0, vb)])
+        roof["note"] = f"one member's forward over a {vb}-volume block; a step launches it once per (member, block) item"
     line = {"metric": "uncertainty-volumes/sec (64^3, 5-member deep ensemble)", "unit": "volumes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -615,7 +631,7 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
                                    "block) items dealt over the ranks, RCCL sum-reduce of sufficient statistics + finalize",
                        "volumes_per_step": V, "forwards_per_step": V * M,
                        "sharding": f"{M} members x volume blocks over {world} rank(s)"},
-            "roofline": None, "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": None}
     line.update(summarise(times, V * args.steps, args.steps))
     return line
 
@@ -641,6 +657,12 @@ def run_c5(args, world, rank, dev, barrier, reduce_max):
         return out
 
     times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # the forwards of one patch batch (16 patches x T = 320 samples, the launch geometry predict_image_sliding uses)
+        xp = torch.stack([im[:P, :P, :P] for im in imgs[:1]] * 16)[:, None].contiguous()
+        roof, _ = roofline_leg(model, xp, T, chunks=[(0, 16)])
+        roof["note"] = "one patch batch (16 patches of 64^3 x T = 20 samples per launch), as predict_image_sliding issues them"
     line = {"metric": "uncertainty-images/sec (128^3 sliding window, T=20 MC-dropout)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -648,7 +670,7 @@ def run_c5(args, world, rank, dev, barrier, reduce_max):
                                    "patch, on-device softmax accumulation + count map, one uncertainty reduction per image",
                        "images_per_gpu_per_step": B, "patch_forwards_per_step": B * 27 * T,
                        "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
-            "roofline": None, "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": None}
     line.update(summarise(times, B * world * args.steps, args.steps))
     line["patch_volumes_per_s"] = round(line["value"] * 27, 1)       # comparable with C2's 64^3 volumes/s at T = 20
     return line

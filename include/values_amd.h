@@ -67,26 +67,29 @@ int vx_drop_hash_mask(uint32_t seed, uint32_t layer, int N, int64_t elems_per_sa
  * the family they were packed for: see `w_family` in the args structs -- a launch whose weights were packed under a
  * different configuration fails with VX_E_DTYPE instead of computing with the wrong layout. */
 typedef struct vx_config {
-  int32_t conv_fp32;      /* 0: split-fp16 products on the f16 matrix cores (default); 1: native fp32 matrix kernels;
-                             2: native fp32 only for Cout == 8 layers */
-  int32_t conv_no_c8;     /* fp32 mode: x-pair kernel instead of the 4x4x1 kernel for Cout == 8 */
-  int32_t conv_no_xcd;    /* plain blockIdx -> tile order instead of the XCD-aware one */
-  int32_t conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs;   /* workgroups per CU of the persistent grids; 0 = default */
-  int32_t s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, s16_no_prenorm, s16_no_xp8, s16_skip_raw;
-  int32_t c2s_no_nt5, convt_no_mfma, no_head_fusion;
-  int32_t s16_range_check; /* 1 (default): split-fp16 convs flag |x| >= 65504 (vx_unet3d_run.status) */
+  int32_t conv_fp32;      /* 0: split-fp16 products on the f16 matrix cores (default); 1: native fp32 matrix kernels (the exact
+                             fmaf-chain fallback family: what the fp16 range guard re-runs on); 2: native fp32 only for Cout == 8 layers */
+  /* data-flow A/B switches: each selects between kernels / launch sequences that compute the same result, and each is run
+   * against the float64 oracle by tests/test_gpu_unet3d.py::test_level0_fusion_variants_vs_oracle_32 */
+  int32_t s16_no_prenorm;  /* separate InstanceNorm / LeakyReLU / dropout passes instead of normalise-on-load in the consuming conv */
+  int32_t s16_no_xp8;      /* the general tile kernels instead of the z-column kernels on the full-resolution Cout == 8 layers */
+  int32_t s16_skip_raw;    /* 1 (default): contr_1_2's raw output goes into the skip half, expand_1_1 normalises it on load */
+  int32_t no_head_fusion;  /* separate vx_conv1x1_ncdhw launch instead of the 1x1x1 head in expand_1_2's epilogue */
   int32_t s16_no_upfuse;   /* separate upscale2 launch + concat read instead of the up-convolution fused into expand_1_1 */
-  int32_t s16_pw;          /* z-column kernel: producer waves per workgroup, 4 or 8 (0 = per-layer default) */
-  int32_t s16_prio;        /* z-column kernel, wave priorities: 0 none, 1 producers raised, 2 consumers raised, 3 waves 4..7 raised */
   int32_t s16_no_poolfuse; /* separate pooling pass over contr_1_2's output instead of the window maxima from its epilogue */
   int32_t storage16;       /* OPT-IN reduced-storage throughput mode (default 0): expand_1_1's full-resolution output is stored
                               as fp16 and expand_1_2 consumes it unsplit (2 instead of 3 matrix products).  Maps then differ from
                               the float64 reference by ~1e-3: bench.py --storage16 reports the measured differences */
-  int32_t s16_no_dbplain;  /* plain (not x-pair) tile layers: two barriers per item on ONE LDS image and the large tile instead of the
-                              staggered double-buffered schedule on the 16 x 4 x 4 tile */
+  int32_t s16_no_dbplain;  /* plain (not x-pair) single-chunk tile layers whose tile is 16 x 4 x 4: ONE LDS image with two barriers
+                              per item instead of two staggered images with one (same tile, same statistics layout, same bits) */
+  int32_t s16_generic;     /* the tile kernel's GENERIC instance (run-time epilogue, one LDS image, two barriers per item) wherever a
+                              specialised one (compile-time epilogue, double-buffered staggered schedule) would run: the reference
+                              of tests/test_gpu_kernels.py::test_conv3d_k3_specialised_instances_equal_generic (bit for bit) */
   int32_t s16_no_upsplit;  /* expand_2_2 stores plain floats and the fused up-convolution splits them per step (round 2) */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
+  int32_t s16_no_poolfuse2; /* levels 1-3: a separate normalise + pool pass over contr_l_2's output instead of the window maxima
+                              from its epilogue + vx_pool_finish (round 4) */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
   int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of
@@ -238,6 +241,7 @@ typedef struct vx_conv3d_args {
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
 int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
+int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_split (vx_prenorm_split's output) for this layer */
 /* pooled[c] = any_dropped ? max(s f(m), 0) : s f(m) with f(m) = LeakyReLU((m - mean[n][c]) * rstd[n][c]), s = 2 with
  * dropout (drop_scale2 != 0) else 1: the MaxPool3d(2, 2) of Dropout(LeakyReLU(InstanceNorm(x))) from the window maxima and
  * flags vx_conv3d_k3 left in pool_out / pool_flags (bit-identical to pooling the normalised tensor: f is monotone). */

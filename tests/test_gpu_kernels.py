@@ -191,7 +191,7 @@ def _fused_head_case(lib, cin, shape, ncls, xb, conv_mode):
 def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mode, vxcfg):
     """The large-tile instances of conv3d_s16.hip with compile-time epilogues (EPI 0 / 1 / 2) and the double-buffered,
     staggered item loop (DB 2 / 3) must give the bits of the generic kernel (two barriers per item, run-time
-    epilogue: VX_S16_NO_DB=1 VX_S16_NO_EPI=1) -- output, statistics partials and fused head, hash dropout included."""
+    epilogue: vx_config.s16_generic) -- output, statistics partials and fused head, hash dropout included."""
     if mode == "lrelu_hash_head" and cout != 8:
         pytest.skip("the head rides in x-pair epilogues only")
     lib = _lib.load()
@@ -233,8 +233,7 @@ def test_conv3d_k3_specialised_instances_equal_generic(cin, cout, shape, xb, mod
 
     vxcfg.delenv("VX_CONV_FP32", raising=False)
     got = run()
-    vxcfg.setenv("VX_S16_NO_DB", "1")
-    vxcfg.setenv("VX_S16_NO_EPI", "1")
+    vxcfg.set(s16_generic=1)
     ref = run()
     for g, r in zip(got, ref):
         assert torch.equal(g, r)

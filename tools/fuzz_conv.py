@@ -31,7 +31,7 @@ for case in range(cases):
     nt = lib.vx_conv3d_k3_tiles(d, h, w)
 
     def run(env):
-        with _lib.config(**{"s16_no_db": 0, "s16_no_epi": 0, "conv_fp32": 0, **env}):
+        with _lib.config(**{"s16_no_xp8": 0, "s16_generic": 0, "conv_fp32": 0, **env}):
             wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
             _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
             out = torch.full((n, d, h, w, cout), -3.0, device=dev)
@@ -60,7 +60,7 @@ for case in range(cases):
     got = run({})
     if os.environ.get("FUZZ_VERBOSE"):
         print("  default ok", flush=True)
-    gen = run({"s16_no_db": 1, "s16_no_epi": 1})
+    gen = run({"s16_no_xp8": 1, "s16_generic": 1})     # the tile kernel's generic instance (round 4: s16_no_db / s16_no_epi became ONE field)
     if os.environ.get("FUZZ_VERBOSE"):
         print("  generic ok", flush=True)
     f32 = run({"conv_fp32": 1})

@@ -74,10 +74,8 @@ class AffineArgs(C.Structure):
 class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
-        "conv_fp32", "conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs",
-        "s16_no_xp", "s16_no_db", "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw",
-        "c2s_no_nt5", "convt_no_mfma", "no_head_fusion",
-        "s16_range_check", "s16_no_upfuse", "s16_pw", "s16_prio", "s16_no_poolfuse", "storage16", "s16_no_dbplain", "s16_no_upsplit", "s16_no_presplit", "c2s_no_wide", "c2s_no_oct")]
+        "conv_fp32", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw", "no_head_fusion", "s16_no_upfuse", "s16_no_poolfuse",
+        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfuse2", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -124,6 +122,7 @@ SIGNATURES = {
     "vx_conv3d_k3_prologue_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_upfuse_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_poolfuse_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_presplit_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
@@ -230,7 +229,7 @@ def pack_mode():
     cache on it, and every launch carries the family its weights were packed for (w_family): the library refuses a
     mismatch."""
     c = get_config()
-    return (c.conv_fp32, c.conv_no_c8, c.s16_no_xp, c.c2s_no_nt5, c.c2s_no_oct)
+    return (c.conv_fp32, c.c2s_no_oct)
 
 
 def check(rc: int, what: str = ""):

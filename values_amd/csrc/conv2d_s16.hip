@@ -367,7 +367,8 @@ __global__ __launch_bounds__(512) void conv2d_s16_kernel(Conv2dSArgs ka) {
         // instructions -- left alone hipcc sinks every read to just before its consumer and the LDS latency is exposed
         // (not the five-row-tile 1x1 instance: it spills as it is, and ten times more with two sets of fragments live)
         // (nor the stride-2, three-row-tile octet instance: 13 staged pieces per thread leave no room for the second set)
-        if constexpr (!(KS == 1 && NT >= 5) && !(OCT == 3 && S == 2 && NT == 3)) {
+        // (round 4: every stride-2 three-row-tile instance -- the sub-block one sat at 256 VGPRs with 3 spilled into scratch)
+        if constexpr (!(KS == 1 && NT >= 5) && !(S == 2 && NT == 3)) {
           constexpr int NRD = 2 * NT + 2 * R, NMF = 3 * R * NT;
           constexpr int PAIRS = NRD < NMF ? NRD : NMF;
           if (s == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
@@ -464,7 +465,7 @@ static inline C2SCfg c2s_config(int KS, int S, int Cout) {
   float bestc = 1e30f;
   c.NT = 1;
   for (int nt : {1, 2, 3, 5}) {
-    if (nt == 5 && (vx_cfg().c2s_no_nt5 || KS == 3)) continue;   // 3x3 with five tiles: 256 VGPRs and scratch
+    if (nt == 5 && KS == 3) continue;   // 3x3 with five tiles: 256 VGPRs and scratch
     const float cost = (float)((r16 + nt - 1) / nt) * (cs + (float)nt);
     if (cost < bestc) { bestc = cost; c.NT = nt; }   // ties: the smaller tile count (less padding)
   }
@@ -551,7 +552,7 @@ static int launch_c2s(const Conv2dSArgs& ka_in, hipStream_t s) {
   constexpr size_t rest = (size_t)IMG_H * 4 + (size_t)8 * NT * 16 * 2 * 4 + (size_t)2 * TABC * 4;   // image, statistics, prologue table
   static_assert(rest + wch <= 160 * 1024, "LDS budget");
   Conv2dSArgs ka = ka_in;
-  ka.w_all = (ka.nchunks > 1 && rest + ka.nchunks * wch <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0;
+  ka.w_all = (ka.nchunks > 1 && rest + ka.nchunks * wch <= 160 * 1024) ? 1 : 0;
   const size_t lds = rest + (ka.w_all ? ka.nchunks : 1) * wch;
   static size_t attr_lds = 0;
   auto kern = conv2d_s16_kernel<KS, S, NT, NSUB, TY, OCT>;
@@ -568,8 +569,8 @@ static int launch_c2s(const Conv2dSArgs& ka_in, hipStream_t s) {
   if (per_cu > 2) per_cu = 2;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
-  static const char* kname = OCT ? vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY, OCT)
-                                 : vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY);
+  // every template argument, defaulted ones included: the list rocprofv3 prints for the instance
+  static const char* kname = vx_kname("conv2d_s16_kernel<%d,%d,%d,%d,%d,%d>", KS, S, NT, NSUB, TY, OCT);
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ygroups), dim3(512), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv2d(s16)");

@@ -31,7 +31,6 @@ struct ConvC8Args {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z;
   unsigned mx, my, mz;   // ceil(2^32 / tiles_*) for the tile decode
-  int no_xcd;            // A/B knob (VX_CONV_NO_XCD): round-robin tile order
   int dbg;               // DIAGNOSTIC BUILD ONLY (-DVX_CONV_STAMPS, env VX_C8_DBG): phase ablation, wrong results by design
   unsigned long long* stamps;  // VX_CONV_STAMPS diagnostic builds only
 };
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
   // per round instead of every 8th tile, so the halo a tile shares with its neighbours is fetched into one L2 once
   // rather than into all eight (measured fabric-side FETCH_SIZE: 1.7-2.3 x the input with the round-robin order).
   int tile_lin = blockIdx.x, chunk = 0;
-  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if ((gridDim.x & 7) == 0) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -399,7 +398,6 @@ static int launch_c8(const ConvC8Args& ka, hipStream_t s) {
   constexpr int max_waves = NCH == 1 ? 16 : 24;   // 100 / 73 VGPRs per lane: 4 / 6 waves per SIMD
   if (per_cu * NW > max_waves) per_cu = max_waves / NW;
   if (per_cu < 1) per_cu = 1;
-  if (vx_cfg().c8_per_cu > 0) per_cu = vx_cfg().c8_per_cu;   // tuning knob
   int gx = 256 * per_cu;
   if (gx > total_tiles) gx = total_tiles;
   static const char* kname = vx_kname("conv3d_k3_c8_kernel<%d,%d,%d,%d>", NCH, TXV, TY, TZ);
@@ -414,7 +412,6 @@ int vx_conv3d_k3_c8(const vx_conv3d_args& a, int txv, int ty, int tz, hipStream_
   ConvC8Args ka;
   ka.a = a;
   ka.dbg = 0;   // phase ablation: diagnostic build only (below)
-  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);

@@ -54,7 +54,6 @@ struct ConvKArgs {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;  // floor(2^32 / tiles_*) + 1: exact t / tiles_* = umulhi(t, m) for t * tiles_* < 2^32
-  int no_xcd;               // A/B knob (VX_CONV_NO_XCD): round-robin tile order
   unsigned long long* dbg;  // VX_CONV_STAMPS diagnostic builds only
 };
 
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
   // compute this item, and run the epilogue after a tile's last chunk.
   // XCD-aware tile order (see conv3d_c8.hip): each XCD takes a contiguous run of tiles per round
   int tile_lin = blockIdx.x, chunk = 0;
-  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if ((gridDim.x & 7) == 0) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have, true);
   f32x4 acc[R][NT];
@@ -466,9 +465,8 @@ static inline ConvCfg conv_config(int Cin, int Cout) {
   // file / conv3d_c8.hip (an exact fmaf chain; the A/B baseline), VX_CONV_FP32=2 keeps fp32 only for Cout = 8.
   // (vx_config: read once; a launch checks its weights' w_family against what this returns NOW)
   const int fp32 = vx_cfg().conv_fp32;
-  const bool no_c8 = vx_cfg().conv_no_c8 != 0;   // fp32 mode: x-pair kernel instead of the 4x4x1 one
   c.S16 = (fp32 == 0 || (fp32 == 2 && Cout != 8)) ? 1 : 0;
-  c.C8 = (!c.S16 && !no_c8 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
+  c.C8 = (!c.S16 && vx_conv3d_c8_applies(Cin, Cout)) ? 1 : 0;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
   c.XP = (Cout == 8) ? 1 : 0;
   // x-pair layers always go in chunks of 8 channels (same speed as one chunk of 16 here, and the packing the
@@ -606,7 +604,6 @@ static int launch_conv(const ConvKArgs& ka, hipStream_t s) {
   const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   if (per_cu * NW > 32) per_cu = 32 / NW;
-  if (vx_cfg().conv_per_cu > 0) per_cu = vx_cfg().conv_per_cu;  // tuning knob
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   dim3 grid((unsigned)gx, (unsigned)ygroups);
@@ -644,6 +641,12 @@ extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
 
 extern "C" int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout) {
   return Cin == 8 && !vx_cfg().s16_no_poolfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
+// in_split (vx_prenorm_split's fp16 pairs) is read by the z-column kernel's staging waves only: the tile kernel's prologue
+// takes the raw tensor (in_repeat) -- a caller that pre-splits where this says 0 has overwritten its tensor for nothing
+extern "C" int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout) {
+  return Cin == 8 && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
@@ -722,7 +725,6 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
   ka.dbg = nullptr;
-  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

@@ -32,7 +32,6 @@ struct ConvSArgs {
   vx_conv3d_args a;
   int tiles_x, tiles_y, tiles_z, nchunks;
   unsigned mx, my, mz;
-  int no_xcd;
   int ty8;   // 16 x 8 x 4 tiles (vx_conv3d_s16_tile)
   int w_all; // every chunk's weights fit in LDS next to the image: staged once, never re-staged per item
   int dbg;   // DIAGNOSTIC BUILD ONLY (-DVX_CONV_STAMPS, env VX_S16_DBG): 1 no epilogue, 2 also no staging, 3 also no
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     for (int i = tid; i < ka.nchunks * (W_H / 8); i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = w_cg[i];
   }
   int tile_lin = blockIdx.x, chunk = 0;
-  if ((gridDim.x & 7) == 0 && !ka.no_xcd) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if ((gridDim.x & 7) == 0) tile_lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   bool have = tile_lin < total;
   prefetch(tile_lin, 0, have, !(ka.w_all && ka.nchunks > 1));
   if (ka.w_all && ka.nchunks > 1) w_fresh = false;
@@ -861,7 +860,7 @@ struct S16Cfg { int CB, NT, XP; };
 static inline S16Cfg s16_config(int Cin, int Cout) {
   S16Cfg c;
   c.NT = (Cout % 32 == 0) ? 2 : 1;
-  c.XP = (Cout == 8 && !vx_cfg().s16_no_xp) ? 1 : 0;
+  c.XP = Cout == 8 ? 1 : 0;
   c.CB = c.XP ? 8 : ((Cin % 16 == 0) ? 16 : 8);
   return c;
 }
@@ -896,7 +895,7 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   static_assert((DB ? 2 : 1) * img + (DB == 3 ? 2 : 1) * wch + red <= 160 * 1024, "LDS budget");
   ConvSArgs ka = ka_in;
   ka.w_all = DB ? (ka.nchunks > 1 ? 1 : 0)   // double-buffered variants: the dispatch made sure everything fits
-                : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024 && !vx_cfg().s16_no_wall) ? 1 : 0);
+                : ((ka.nchunks > 1 && img + ka.nchunks * wch + red <= 160 * 1024) ? 1 : 0);
   const size_t lds = (DB ? 2 : 1) * img + (ka.w_all ? ka.nchunks : 1) * wch + red;
   auto kern = conv3d_k3_s16_kernel<CB, NT, TX, TY, TZ, NW, XP, DB, EPI>;
   static size_t attr_lds = 0;
@@ -910,7 +909,6 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   const int ygroups = XP ? 1 : (a.Cout + 16 * NT - 1) / (16 * NT);
   int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   if (per_cu * NW > 16) per_cu = 16 / NW > 0 ? 16 / NW : 1;
-  if (vx_cfg().s16_per_cu > 0) per_cu = vx_cfg().s16_per_cu;
   int gx = (256 * per_cu + ygroups - 1) / ygroups;
   if (gx > total_tiles) gx = total_tiles;
   static const char* kname = vx_kname("conv3d_k3_s16_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", CB, NT, TX, TY, TZ, NW, XP, DB, EPI);
@@ -920,26 +918,26 @@ static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
   return VX_OK;
 }
 
-static inline bool s16_dbplain() { return !vx_cfg().s16_no_dbplain && !vx_cfg().s16_no_db; }
+static inline bool s16_dbplain() { return !vx_cfg().s16_no_dbplain && !vx_cfg().s16_generic; }
 
 template <int CB, int NT, int XP>
 static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
   // epilogue specialisation of the large-tile instances (EPI in the kernel's header)
   const vx_conv3d_args& a = ka.a;
   int epi = 3;
-  if (!vx_cfg().s16_no_epi) {
-    if (a.act == VX_ACT_NONE && a.drop_mode == VX_DROP_NONE && !a.head_out && a.out) epi = 0;
-    else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && !a.head_out && a.out) epi = 1;
-    else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
-  }
+  const bool generic = vx_cfg().s16_generic != 0;   // parity reference: run-time epilogue, one LDS image, two barriers per item
+  if (generic) epi = 3;
+  else if (a.act == VX_ACT_NONE && a.drop_mode == VX_DROP_NONE && !a.head_out && a.out) epi = 0;
+  else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && !a.head_out && a.out) epi = 1;
+  else if (a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH && a.head_out && XP) epi = 2;
   if constexpr (XP == 1) {   // single-chunk x-pair layers: double-buffered LDS image (one barrier per item)
-    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !vx_cfg().s16_no_db) {
+    if (tx == 16 && ka.ty8 && ka.nchunks == 1 && !generic) {
       if (epi == 0) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 0>(ka, s);
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 1>(ka, s);
       if (epi == 2) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 2>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 2, 3>(ka, s);
     }
-    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !vx_cfg().s16_no_db && !vx_cfg().s16_no_db3) {   // 16 -> 8 channels
+    if (tx == 16 && ka.ty8 && ka.nchunks == 2 && !generic) {   // 16 -> 8 channels
       if (epi == 1) return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 1>(ka, s);
       return launch_s16<CB, NT, 16, 8, 4, 8, XP, 3, 3>(ka, s);
     }
@@ -991,7 +989,7 @@ void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz) {
   // two row tiles per wave (Cout % 32 == 0) on the large tile would need > 256 registers (75 spilled): small tile there
   // (measured 32->32 @64^3: 321 TFLOP/s on 16x4x4 tiles against 204 on the spilling 16x8x4 instance)
   const bool nt2 = !xp && Cout % 32 == 0;
-  const bool ty8 = tx == 16 && H >= 32 && !nt2 && !vx_cfg().s16_no_ty8;
+  const bool ty8 = tx == 16 && H >= 32 && !nt2;
   *txv = xp ? 2 * tx : tx;
   *ty = (tx == 8 || ty8) ? 8 : 4;
   *tz = 4;
@@ -1017,7 +1015,6 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   ka.mx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.my = (unsigned)((1ull << 32) / (unsigned)ka.tiles_y) + 1u;
   ka.mz = (unsigned)((1ull << 32) / (unsigned)ka.tiles_z) + 1u;
-  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.dbg = 0;
   ka.stamps = nullptr;
 #ifdef VX_CONV_STAMPS

@@ -21,9 +21,7 @@ struct Xp8wArgs {
   int ncols;                  // columns in the launch (N * tiles_y * tiles_x)
   unsigned mcps, mtx;         // multiply-high magics: / (tiles_x * tiles_y), / tiles_x
   int stat_epc;               // statistics entries per column in stats_partial (entry 0 real, the rest zero)
-  int no_xcd;
   unsigned long long* stamps;
-  int prio;                   // 1: producers at s_setprio 2, 2: consumers at s_setprio 2, 3: waves 4..7 at s_setprio 1
   int abl;                    // diagnostic build only: phase ablation bits (1 no multiply, 2 no epilogue, 4 no commit, 8 no loads)
 };
 
@@ -80,6 +78,17 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
   float* s_red = reinterpret_cast<float*>(s_w + NCH * W_H);
 
   const vx_conv3d_args& a = ka.a;
+  // Fields a wave needs once per item or per column (the pooled output's pointers, the statistics buffer) are re-read from
+  // the kernarg segment WHERE THEY ARE USED: left to the compiler every kernel argument is loaded at the top and stays in
+  // SGPRs for the kernel's life -- the pooling instances held 106 and spilled 8-10 of them into VGPR lanes (v_readlane in
+  // the item loop, scratch reserved for the lane register).  The empty asm hides the pointer's origin, so the loads cannot
+  // be hoisted back.
+  auto kernarg = [&]() {
+    typedef const Xp8wArgs __attribute__((address_space(4))) * kp_t;      // constant address space: scalar loads
+    kp_t p = (kp_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
   // ---- the columns of this workgroup ----
   int vb = blockIdx.x;
   const int G = (int)gridDim.x;
-  if ((G & 7) == 0 && !ka.no_xcd) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // one XCD: neighbouring columns
+  if ((G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // one XCD: neighbouring columns
   const int ncol_wg = vb < ka.ncols ? (ka.ncols - vb + G - 1) / G : 0;
 
   struct Cur { int ci, s; };      // column number of this workgroup, step within the column (0 .. KZ)
@@ -136,7 +145,6 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     //   * dropout = the keep bit ANDed into the piece's SCALE (2 instructions per element);
     //   * rows outside the volume issue no load and commit zeros without touching the vector ALU.
     // The 2 halo voxels per row (x = -1, x = 32) are gathered into one or two extra iterations of the old per-lane form.
-    if (ka.prio == 1) __builtin_amdgcn_s_setprio(2);
     const int pw = wave - NW;
     constexpr int NCS = UP ? 1 : NCH;             // chunks staged from memory (UP: chunk 0 is computed)
     constexpr int RU = TZ * HY;                   // rows of a step, per chunk
@@ -569,8 +577,6 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     static_assert(!POOLM || (NCH == 1 && R == 4), "pooling epilogue: one-chunk layers");
     const int lz = POOLM ? (wave >> 2) * 2 : wave / WPZ, ly0 = POOLM ? (wave & 3) * 2 : (wave % WPZ) * R;
     const bool late = wave >= NW / 2;
-    if (ka.prio == 2) __builtin_amdgcn_s_setprio(2);
-    if (ka.prio == 3 && late) __builtin_amdgcn_s_setprio(1);
     // ---- compute-phase constants ----
     // B fragment of (kz, row j): s_img[chunk][prec][parity g & 1][(slot * HY + ly0 + j) * HXP + m + (g >> 1)]
     const int bfrag0 = (g & 1) * PP * 8 + ((ly0 * HXP) + m + (g >> 1)) * 8;
@@ -714,7 +720,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (ci != e_ci) {   // a new column: sample, tile row / column, dropout key, head pointers
         e_ci = ci;
         col_of(ci, e_n, e_ty, e_tx);
-        if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(seed_out, a.drop_layer, (uint32_t)e_n);
+        if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(seed_out, kernarg()->a.drop_layer, (uint32_t)e_n);
         if (HEAD) {
           e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
           const int slot = a.head_dst ? a.head_dst[e_n] : e_n;
@@ -732,7 +738,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
                                         : vox0 * (unsigned)a.out_pitch * 4u;
       const unsigned e0 = vox0 * 8u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<char*>(a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
+          (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling: the bits of multiply-then-add)
@@ -815,8 +821,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           for (int j = 0; j < 4; ++j) mx[j] = fmaxf(pl_max[j], o[j]);
           const int Dp = a.D >> 1, Hp = a.H >> 1, Wp = a.W >> 1;
           const size_t pv = (((size_t)e_n * Dp + ((k * TZ + lz) >> 1)) * Hp + ((e_ty * 8 + ly0) >> 1)) * Wp + e_tx * 16 + m;
-          *reinterpret_cast<f32x4*>(a.pool_out + pv * 8 + oc) = mx;
-          a.pool_flags[pv * 2 + (g & 1)] = pl_any | oany;
+          const auto kp = kernarg();
+          *reinterpret_cast<f32x4*>(kp->a.pool_out + pv * 8 + oc) = mx;
+          kp->a.pool_flags[pv * 2 + (g & 1)] = pl_any | oany;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) pl_max[j] = -INFINITY;
@@ -843,8 +850,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     auto flush_col = [&](int ci) {
       int n, ty, tx;
       col_of(ci, n, ty, tx);
-      const int ntile = cps * ka.stat_epc;
-      float* dst = a.stats_partial + (((size_t)n * ntile + (size_t)(ty * ka.tiles_x + tx) * ka.stat_epc) * 8) * 2;
+      const auto kp = kernarg();
+      const int epc = kp->stat_epc;
+      const int ntile = cps * epc;
+      float* dst = kp->a.stats_partial + (((size_t)n * ntile + (size_t)(ty * ka.tiles_x + tx) * epc) * 8) * 2;
       if (tid < 8) {
         float s = 0.f, q = 0.f;
 #pragma unroll
@@ -855,7 +864,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         dst[tid * 2 + 0] = s;
         dst[tid * 2 + 1] = q;
       }
-      for (int i = 16 + tid; i < ka.stat_epc * 16; i += 256) {
+      for (int i = 16 + tid; i < epc * 16; i += 256) {
         if (tid < 256) dst[i] = 0.f;
       }
     };
@@ -917,7 +926,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
 // ---------------------------------------------------------------------------------------------------------------
 bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout) {
-  if (vx_cfg().conv_fp32 != 0 || vx_cfg().s16_no_xp || vx_cfg().s16_no_xp8) return false;
+  if (vx_cfg().conv_fp32 != 0 || vx_cfg().s16_no_xp8) return false;
   // D >= 8: a column has at least two items (the statistics hand-off between the wave halves needs the spacing)
   return Cout == 8 && (Cin == 8 || Cin == 16) && W % 32 == 0 && H % 8 == 0 && D % 4 == 0 && W >= 32 && H >= 8 && D >= 8;
 }
@@ -935,8 +944,7 @@ static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(xp8w): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     attr = true;
   }
-  int gx = 256;
-  if (vx_cfg().s16_per_cu > 0) gx = 256 * vx_cfg().s16_per_cu;
+  int gx = 256;                // one persistent workgroup per CU (its LDS image fills the CU)
   if (gx > ka.ncols) gx = ka.ncols;
   static const char* kname = vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW, IN16);   // as rocprofv3 prints it
   vx_note_kernel(kname);
@@ -956,10 +964,8 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   ka.mcps = (unsigned)((1ull << 32) / (unsigned)cps) + 1u;
   ka.mtx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.stat_epc = stat_tiles / cps;
-  ka.no_xcd = vx_cfg().conv_no_xcd ? 1 : 0;
   ka.stamps = nullptr;
   ka.abl = 0;
-  ka.prio = vx_cfg().s16_prio;
 #ifdef VX_CONV_STAMPS
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("VX_XP_ABL")) ka.abl = atoi(e);
@@ -980,10 +986,10 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // other heads: general kernel
   if (epi == 1 && a.act != VX_ACT_LRELU) return 1;
   const int up = a.up_in ? 1 : 0;
-  // producer waves: two per SIMD where the staging is heavy; the head epilogue (32 scattered 4-byte stores per lane and
-  // item) is the longer side of its layer and runs better against one (measured per layer, tools/show_layers.py)
-  // (the pooling epilogue holds 8 image rows + the window state: 128 VGPRs at 16 waves would spill 28 dwords)
-  const int npw = vx_cfg().s16_pw == 8 ? 8 : vx_cfg().s16_pw == 4 ? 4 : (epi == 2 || epi == 5 || epi == 4 ? 4 : 8);
+  // producer waves: 8 (two per SIMD) for the two-chunk layers, whose staging is the heavy side; 4 for the one-chunk layers:
+  // their consumers hold R = 4 image rows + accumulators (134-161 VGPRs) and at 16 waves per workgroup (128-VGPR cap) EVERY
+  // one-chunk instance spilled 5-30 VGPRs into its item loop (round-3 verdict; tools/check_spills.sh now fails the build on any
+  // such instance).  The round-3 knob vx_config.s16_pw and the 20 instances behind it are gone.
   if (a.pool_out && nch != 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): the pooled output goes with Cin = 8");
   if (a.out_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): out_split is an epilogue of the tile kernel");
   if (a.up_split && !up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): up_split without up_in");
@@ -992,11 +998,11 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (a.in_f16) {
     if (!(nch == 1 && epi == 2 && pre == 0 && !up && !a.in_xblk))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): fp16 input goes with the dense 8-channel layer that carries the fused head");
-    return npw == 8 ? launch_xp8w<1, 2, 0, 0, 8, 1>(ka, s) : launch_xp8w<1, 2, 0, 0, 4, 1>(ka, s);
+    return launch_xp8w<1, 2, 0, 0, 4, 1>(ka, s);
   }
 #define XP8W_CASE(N_, E_, P_, U_)                                                         \
   if (nch == N_ && epi == E_ && pre == P_ && up == U_)                                    \
-    return npw == 8 ? launch_xp8w<N_, E_, P_, U_, 8>(ka, s) : launch_xp8w<N_, E_, P_, U_, 4>(ka, s)
+    return launch_xp8w<N_, E_, P_, U_, (N_ == 2 ? 8 : 4)>(ka, s)
   XP8W_CASE(1, 4, 0, 0); XP8W_CASE(1, 4, 1, 0); XP8W_CASE(1, 4, 2, 0); XP8W_CASE(1, 0, 2, 0);
   XP8W_CASE(1, 0, 0, 0); XP8W_CASE(1, 0, 1, 0); XP8W_CASE(1, 1, 0, 0); XP8W_CASE(1, 2, 0, 0); XP8W_CASE(1, 3, 0, 0); XP8W_CASE(1, 3, 1, 0);
   XP8W_CASE(1, 5, 0, 0);

@@ -285,14 +285,14 @@ static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   const int groups = (a.Cout / 2) / RT;          // 8 * Cout rows = Cout / 2 row tiles
   int bx = (ncoltiles + 3) / 4;
   int per = 32;   // workgroups per CU in the grid: more, shorter address streams write faster (fill: 5.1 TB/s at 2048 WGs, 6.5 at 32768)
-  if (vx_cfg().convt_wgs > 0) per = vx_cfg().convt_wgs;
   const int cap = (256 * per + groups - 1) / groups;
   if (bx > cap) bx = cap;
   auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
   ConvTDecode dc;
   dc.mW = magic(a.W); dc.mH = magic(a.H); dc.mD = magic(a.D);
-  static const char* kname = vx_kname("convT_k2s2_mfma_kernel<%d,%d>", CIN, RT);
-  vx_note_kernel(kname);
+  static const char* kname = vx_kname("convT_k2s2_mfma_kernel<%d,%d,false>", CIN, RT);
+  static const char* kname_m = vx_kname("convT_k2s2_mfma_kernel<%d,%d,true>", CIN, RT);
+  vx_note_kernel(a.drop_mode == VX_DROP_MASK ? kname_m : kname);
   if (a.drop_mode == VX_DROP_MASK)
     hipLaunchKernelGGL((convT_k2s2_mfma_kernel<CIN, RT, true>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a,
                        ncoltiles, (int)nvox, dc);
@@ -352,8 +352,7 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
   // matrix-core kernel for the channel counts the networks use (row tiles per workgroup: weights stay in <= 128 VGPRs)
   // (flat voxel index * largest dimension < 2^32: the multiply-high divisions of the index decode are then exact)
   const int64_t dmax = a.W > a.H ? (a.W > a.D ? a.W : a.D) : (a.H > a.D ? a.H : a.D);
-  if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && (int64_t)a.N * a.D * a.H * a.W * dmax < (1ll << 32) &&
-      !vx_cfg().convt_no_mfma) {
+  if ((int64_t)a.N * a.D * a.H * a.W < (1ll << 27) && (int64_t)a.N * a.D * a.H * a.W * dmax < (1ll << 32)) {
     hipStream_t s = (hipStream_t)stream;
     const int tiles = a.Cout / 2;
     if (a.Cin == 16 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<16, 4>(a, s) : launch_convT_mfma<16, 8>(a, s);

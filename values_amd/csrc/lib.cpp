@@ -48,33 +48,18 @@ static int env_int(const char* name, int dflt) {
 static void cfg_from_env() {
   memset(&g_cfg, 0, sizeof(g_cfg));
   g_cfg.conv_fp32 = env_int("VX_CONV_FP32", 0);
-  g_cfg.conv_no_c8 = env_int("VX_CONV_NO_C8", 0);
-  g_cfg.conv_no_xcd = env_int("VX_CONV_NO_XCD", 0);
-  g_cfg.conv_per_cu = env_int("VX_CONV_PER_CU", 0);
-  g_cfg.s16_per_cu = env_int("VX_S16_PER_CU", 0);
-  g_cfg.c8_per_cu = env_int("VX_C8_PER_CU", 0);
-  g_cfg.convt_wgs = env_int("VX_CONVT_WGS", 0);
-  g_cfg.s16_no_xp = env_int("VX_S16_NO_XP", 0);
-  g_cfg.s16_no_db = env_int("VX_S16_NO_DB", 0);
-  g_cfg.s16_no_db3 = env_int("VX_S16_NO_DB3", 0);
-  g_cfg.s16_no_epi = env_int("VX_S16_NO_EPI", 0);
-  g_cfg.s16_no_ty8 = env_int("VX_S16_NO_TY8", 0);
-  g_cfg.s16_no_wall = env_int("VX_S16_NO_WALL", 0);
   g_cfg.s16_no_prenorm = env_int("VX_S16_NO_PRENORM", 0);
   g_cfg.s16_no_xp8 = env_int("VX_S16_NO_XP8", 0);
   g_cfg.s16_skip_raw = env_int("VX_S16_SKIP_RAW", 1);
-  g_cfg.c2s_no_nt5 = env_int("VX_C2S_NO_NT5", 0);
-  g_cfg.convt_no_mfma = env_int("VX_CONVT_NO_MFMA", 0);
   g_cfg.no_head_fusion = env_int("VX_NO_HEAD_FUSION", 0);
-  g_cfg.s16_range_check = env_int("VX_S16_RANGE_CHECK", 1);
   g_cfg.s16_no_upfuse = env_int("VX_S16_NO_UPFUSE", 0);
-  g_cfg.s16_pw = env_int("VX_S16_PW", 0);
-  g_cfg.s16_prio = env_int("VX_S16_PRIO", 0);
   g_cfg.s16_no_poolfuse = env_int("VX_S16_NO_POOLFUSE", 0);
   g_cfg.s16_no_presplit = env_int("VX_S16_NO_PRESPLIT", 0);
   g_cfg.storage16 = env_int("VX_STORAGE16", 0);
   g_cfg.s16_no_dbplain = env_int("VX_S16_NO_DBPLAIN", 0);
+  g_cfg.s16_generic = env_int("VX_S16_GENERIC", 0);
   g_cfg.s16_no_upsplit = env_int("VX_S16_NO_UPSPLIT", 0);
+  g_cfg.s16_no_poolfuse2 = env_int("VX_S16_NO_POOLFUSE2", 0);
   g_cfg.c2s_no_wide = env_int("VX_C2S_NO_WIDE", 0);
   g_cfg.c2s_no_oct = env_int("VX_C2S_NO_OCT", 0);
 }
@@ -99,5 +84,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 303; /* 0.3.3: vx_config.c2s_no_oct, vx_bilinear_softmax_nchw; 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
+extern "C" int vx_version(void) { return 400; /* 0.4.0 (round 4): vx_config lost conv_no_c8, conv_no_xcd, conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs, s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, c2s_no_nt5, convt_no_mfma, s16_range_check, s16_pw, s16_prio (measured-slower variants and tuning knobs, with their instances); + vx_conv3d_k3_presplit_ok; 0.3.3: vx_config.c2s_no_oct, vx_bilinear_softmax_nchw; 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

@@ -291,7 +291,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
           // InstanceNorm + LeakyReLU + the fp16 split of the shared tensor ONCE per volume (in place); contr_1_2's staging
           // waves then only AND sample n's dropout bits in -- a third of their vector work (they are that layer's critical
           // path: tools/stamp_s16.py)
-          if (dm != VX_DROP_MASK && !vx_cfg().s16_no_presplit) {
+          // (only where contr_1_2 runs on the z-column kernel: the tile kernel's prologue reads the RAW tensor through
+          // in_repeat -- s16_no_xp = 1 with n_pred > 1 failed with VX_E_SHAPE after the scratch had been rewritten)
+          if (dm != VX_DROP_MASK && !vx_cfg().s16_no_presplit && vx_conv3d_k3_presplit_ok(L.D, L.H, L.W, F, F)) {
             VX_STEP("presplit:contr_1_1", vx_prenorm_split(scratch, p.mean, p.rstd, V, L.nvox, dm == VX_DROP_HASH ? 2.f : 1.f, stream));
             pre_split_ = true;
           }

@@ -56,6 +56,20 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(kernel, fname):
+    """HBM-side bytes per launch of `kernel` from the PMC counters: only a record taken on THIS build counts
+    (tools/pmc_traffic.py writes profiles/<fname> with the hash of the kernel sources); otherwise None."""
+    tpath = os.path.join(ROOT, "profiles", fname)
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("src_sha") == source_sha():
+                return rec.get("kernels", {}).get(kernel)
+        except Exception:
+            pass
+    return None
+
+
 def layer_table(F=8, S=64):
     """label -> (kernel family, Cin, Cout, spatial edge of the OUTPUT/input grid the MACs run on)."""
     t = {}
@@ -196,16 +210,7 @@ def roofline_leg(model, x, T, reps=3, chunks=None):
             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_step": a["launches"] // reps,
             "samples_per_launch": round(N / len(chunks), 1),
             "share_of_forward": round(a["ms"] / reps / total_ms, 3), "traffic": None}
-    # HBM-side bytes per launch from the PMC counters: only a record taken on THIS build counts (tools/pmc_traffic.py
-    # writes profiles/traffic.json with the source hash); otherwise null
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath))
-            if rec.get("src_sha") == source_sha():
-                roof["traffic"] = rec.get("kernels", {}).get(name)
-        except Exception:
-            pass
+    roof["traffic"] = pmc_traffic(name, "traffic.json")
     detail = {"forward_ms_sum_of_launches": round(total_ms, 3), "samples": N,
               "launches_per_forward": sum(v["launches"] for v in acc.values()) // reps // len(chunks),
               "kernels": {k: {"ms_per_step": round(v["ms"] / reps, 4), "launches": v["launches"] // reps,
@@ -377,6 +382,11 @@ def main():
                     "every step's maps are gathered on rank 0 inside the timed region, the metric SURVEY 8d defines)")
     ap.add_argument("--gather", action="store_true", help="(default since round 3; kept so that old command lines still parse)")
     ap.add_argument("--eager", action="store_true", help="C4: eager launches instead of the captured hipGraph")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="C4: run ONLY the roofline leg (single-stream eager forwards with a HIP event pair around every conv, 8 "
+                         "reps) and print its object: the command a rocprofv3 --kernel-trace --stats / --pmc pass wraps so that "
+                         "the CSV's per-kernel averages are those of the launches the `roofline` object times (the graph replay "
+                         "overlaps branch kernels on side streams, where rocprofv3's per-kernel durations are inflated)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
     ap.add_argument("--detail", type=str, default=None, help="write the per-kernel breakdown JSON here")
     args = ap.parse_args()
@@ -496,7 +506,10 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
             red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
             dev_maps = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
             flips = int((red["pred_seg_mean"] != ref_seg).sum().item())
-            t16 = timed_regions(step, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+            # an EAGER step: a graph captured above replays the default path's kernels whatever the configuration says now
+            def step16(i):
+                return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
+            t16 = timed_regions(step16, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
         s16 = summarise(t16, V * world * args.steps, args.steps)
         st16 = {"value": s16["value"], "ms_per_step": s16["ms_per_step"], "unit": "volumes/s",
                 "max_abs_diff_vs_default_path": dev_maps, "argmax_flips": flips, "voxels": int(ref_seg.numel()),
@@ -696,12 +709,25 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.randn((B, 3, H, W), generator=g).to(dev)
     noisy = (x + 0.05 * torch.randn((B, 3, H, W), generator=g).to(dev))
-    views, hf, vf = tta_views_8(x, noisy)
+    # the 8 views of a step are built ON the device by ONE launch inside the step (vx_tta_views_2d: flips as index arithmetic,
+    # channels-last at the stem's pitch) from the resident clean / noisy images -- round 3 prepared them outside the timed
+    # region with torch.flip and re-laid them out (permute + zero fill) inside it
+    from values_amd.data import tta_views_8_device
+    from values_amd.predict2d import NhwcViews
+    d8, hf, vf = tta_views_8_device(x, noisy)
+    views = NhwcViews(d8, hf, vf)
+
+    if args.roofline_only:
+        roof = model.profile_forward(views.t.view(-1, H, W, 4), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=8,
+                                     nhwc=True, reps=8)
+        roof["traffic"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
+        return {"config": "C4 roofline leg only", "hrnet_width": args.hrnet_width, "images": B, "roofline": roof}
 
     def step_eager(i):
         # every view's softmax is taken in its forward's upsampling pass (the outputs -- softmax_pred and the maps -- are the
         # reference's; the full-resolution logits, which process_output never sees, are not written)
-        pr = predict_logits_2d([model], views, tta=True, hflip_views=hf, vflip_views=vf, softmax=True)
+        tta_views_8_device(x, noisy, out=views.t)
+        pr = predict_logits_2d([model], views, tta=True, softmax=True)
         return process_output_2d(None, probs=pr)
 
     # the product path for a fixed image geometry: the step captured once as a hipGraph (the eager walk is ~950 launches
@@ -712,15 +738,21 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
         eager = summarise(et, B * max(2, args.steps // 2), max(2, args.steps // 2))
         model._hold_last = None
         torch.cuda.empty_cache()
-    gp = None if args.eager else GraphedPredictor2D([model], views, tta=True, hflip_views=hf, vflip_views=vf, keep_logits=False)
+    gp = None if args.eager else GraphedPredictor2D([model], views, tta=True, keep_logits=False)
 
     def step(i):
-        return gp(views) if gp is not None else step_eager(i)
+        if gp is None:
+            return step_eager(i)
+        tta_views_8_device(x, noisy, out=gp.x[0])      # this step's views straight into the graph's input
+        return gp()
 
     times = timed_regions(step, lambda: None, barrier, args.steps, args.warmup, max(1, args.repeats), reduce_max)
     roof = None
     if rank == 0 and not args.no_roofline and hasattr(model, "profile_forward"):
-        roof = model.profile_forward(torch.cat(views, 0), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=len(views))
+        roof = model.profile_forward(views.t.view(-1, H, W, 4), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=8,
+                                     nhwc=True)
+        # HBM-side bytes per launch (PMC passes around `--config C4 --roofline-only`: the same single-stream launches)
+        roof["traffic"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
     line = {"metric": f"uncertainty-images/sec (HRNet-W{args.hrnet_width}, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -467,6 +467,20 @@ int vx_softmax_variance(const float* x, int from_logits, int B, int T, int C, in
 int vx_ssn_sample(const float* head, const float* eps_w, const float* eps_d, uint32_t seed, int N, int S, int C, int R,
                   int64_t nvox, float epsilon, float* out, vx_stream_t stream);
 
+/* The TTA branch of Cityscapes_dataset.__getitem__ (uncertainty_modeling/data/cityscapes_dataset.py:76-99) as ONE launch:
+ * a batch of images -> the G views the 2D driver forwards (test_2D.py:299-311), normalised, channels-last float32 at pitch
+ * 4 (channel 3 = 0: the layout the stem convolution stages from), out [G][B][H][W][4], flips as index arithmetic.
+ *   src_u8 = 1: src [B][H][W][3] uint8; view = Normalize(mean, std, max_pixel_value)(maybe GaussNoise(maybe Flip(img))) with
+ *     the arithmetic of albumentations on uint8 input: noisy = uint8(clip(float(img) + field, 0, 255)), then
+ *     (v - mean * max) * (1 / (std * max)) in float32 -- bit-exact with values_amd.data.tta_views_2d.  noise0 / noise1:
+ *     additive fields [B][H][W][3] (the generator is third-party: albumentations 1.3.0 GaussNoise, so the fields are INPUTS).
+ *   src_u8 = 0: src = clean, noise0 = noisy, both [B][3][H][W] float32 already normalised (values_amd.predict2d.tta_views_8).
+ *   view_code [G] (HOST array): bit 0 HorizontalFlip, bit 1 VerticalFlip, bit 2 noisy, bit 3 the noise field is indexed at
+ *     the SOURCE pixel (flip of the noisy image) instead of the view's (noise drawn after the flip, as the dataset does),
+ *     bit 4 noise slot (u8 source).  The reference's four views: {0, 1, 4, 1 | 4 | 16}. */
+int vx_tta_views_2d(const void* src, int src_u8, const float* noise0, const float* noise1, const float* mean, const float* std,
+                    float max_pixel_value, int B, int H, int W, int G, const int32_t* view_code, float* out, vx_stream_t stream);
+
 /* Colour rendering of an arg-max mask (Tester.save_prediction, test_2D.py:124-134): rgb[i] = lut[labels[i]] with
  * labels[i] := unlabeled where ignore[i] != 0 (ignore nullable); lut [256][3] uint8, rgb [n][3]. */
 int vx_colorize_u8(const uint8_t* labels, const uint8_t* ignore, int64_t n, const uint8_t* lut, int unlabeled, uint8_t* rgb,

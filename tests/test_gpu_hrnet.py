@@ -349,6 +349,59 @@ def test_batched_tta_views_equal_one_forward_per_view():
                        predict_logits_2d([m2], v2, tta=True, hflip_views=h2, vflip_views=w2, batch_views=False))
 
 
+def test_tta_views_2d_on_device_is_the_dataset_branch_bit_for_bit():
+    """Row a17 (cityscapes_dataset.py:76-99): vx_tta_views_2d -- uint8 HWC image (+ the two noise fields, which are inputs:
+    albumentations' generator is third-party) -> the four normalised views in ONE launch, flips as index arithmetic,
+    channels-last at the stem's pitch.  Bit-exact with values_amd.data.tta_views_2d (the host restatement the CPU suite
+    pins), batches of images, a missing field (the view degenerates to the clean one), the 8-view set of config C4; and
+    fed to the network through NhwcViews it gives the bits of the host-built views."""
+    from values_amd.data import TTA_2D_VIEW_CODES, hflip_flags, tta_views_2d, tta_views_2d_device, tta_views_8_device
+    from values_amd.predict2d import NhwcViews, predict_logits_2d, tta_views_8
+    rng = np.random.default_rng(5)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    B, H, W = 3, 37, 50
+    imgs = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    imgs[0, :4] = 0; imgs[0, 4:8] = 255                       # the clip's two ends are reached
+    n0 = (rng.standard_normal((B, H, W, 3)) * 30).astype(np.float32)
+    n1 = (rng.standard_normal((B, H, W, 3)) * 30).astype(np.float32)
+    dv, names = tta_views_2d_device(torch.from_numpy(imgs), mean, std, noise=n0, noise_flipped=n1)
+    assert dv.shape == (4, B, H, W, 4) and dv.dtype == torch.float32
+    got = dv.cpu().numpy()
+    assert (got[..., 3] == 0).all()
+    for b in range(B):
+        ref, tr = tta_views_2d(imgs[b], mean, std, noise=n0[b], noise_flipped=n1[b])
+        assert hflip_flags(tr) == hflip_flags(names) == [False, True, False, True]
+        for g in range(4):
+            np.testing.assert_array_equal(got[g, b, :, :, :3].transpose(2, 0, 1), ref[g], err_msg=f"view {g} image {b}")
+    assert (got[2] != got[0]).any() and (got[3] != got[1]).any()
+    # a single (H, W, 3) image, no flipped-noise field: view 3 falls back to the clean flip, exactly as on the host
+    dv1, _ = tta_views_2d_device(imgs[1], mean, std, noise=n0[1])
+    ref, _ = tta_views_2d(imgs[1], mean, std, noise=n0[1])
+    for g in range(4):
+        np.testing.assert_array_equal(dv1[g, 0, :, :, :3].cpu().numpy().transpose(2, 0, 1), ref[g])
+    assert TTA_2D_VIEW_CODES == [0, 1, 4, 21]
+    # float source: the 8 views of config C4 = torch.flip of the clean / noisy tensors, laid out channels-last
+    m2, gg, _ = make(dropout_final=False)
+    x = torch.from_numpy(gg["input"]).cuda()
+    noisy = x * 1.02 + 0.01
+    views, hf, vf = tta_views_8(x, noisy)
+    d8, hf2, vf2 = tta_views_8_device(x, noisy)
+    assert hf2 == hf and vf2 == vf
+    for g in range(8):
+        assert torch.equal(d8[g][..., :3].permute(0, 3, 1, 2), views[g]), g
+    # ... and through the network: one batched forward of the device-built views = the host-built ones, bit for bit
+    a = predict_logits_2d([m2], NhwcViews(d8, hf2, vf2), tta=True)
+    b = predict_logits_2d([m2], views, tta=True, hflip_views=hf, vflip_views=vf)
+    assert torch.equal(a, b)
+    with pytest.raises(_lib_mod().VxError):
+        tta_views_2d_device(torch.from_numpy(imgs), mean, std, view_codes=[0, 99])
+
+
+def _lib_mod():
+    from values_amd import _lib
+    return _lib
+
+
 def test_graphed_predictor_2d_replays_the_eager_bits():
     """GraphedPredictor2D: predict_logits_2d + process_output_2d captured into one hipGraph (branches on side streams
     inside the capture) -- the replay gives the eager path's bits, for new inputs too; wrong shapes are refused."""

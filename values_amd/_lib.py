@@ -141,6 +141,8 @@ SIGNATURES = {
     "vx_softmax_accumulate": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vx_aleatoric_sample": (_i, [_p, _p, _u32, _i, _i, _i, _i64, _p, _p, _p]),
     "vx_colorize_u8": (_i, [_p, _p, _i64, _p, _i, _p, _p]),
+    "vx_tta_views_2d": (_i, [_p, _i, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, _i, _i, _i, _i,
+                             C.POINTER(C.c_int32), _p, _p]),
     "vx_select_workspace_bytes": (_i64, []),
     "vx_select_kth": (_i, [_p, _i64, _i64, _p, _p, _p]),
     "vx_count_nonzero_u8": (_i, [_p, _i64, _p, _p]),

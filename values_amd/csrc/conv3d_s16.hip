@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   f32x4 wbuf[W_IT];
   // normalise-on-load prologue (plain layers, dense input): the input is the RAW output of the previous conv of a
   // contract block; InstanceNorm with the given statistics, LeakyReLU and that conv's dropout are applied on the way into
-  // LDS (unet3D_module.py:231-237), as conv3d_xp8.hip does for the full-resolution layers.  Run-time flag: the element
+  // LDS (unet3D_module.py:231-237), as conv3d_xp8w.hip does for the full-resolution layers.  Run-time flag: the element
   // index of a piece is (soff + voff) / 4 - biasf because the tensor is dense (in_pitch == Cin), so it costs no table.
   const bool pre = !XP && a.in_mean != nullptr;
   const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       float mx = rmax;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      if (lane == 0 && !(mx < 32768.f)) atomicMax(a.range_flag, __float_as_uint(mx));   // see conv3d_xp8.hip
+      if (lane == 0 && !(mx < 32768.f)) atomicMax(a.range_flag, __float_as_uint(mx));   // see conv3d_xp8w.hip
     }
   };
   // ---- epilogue of item tl (conv3d_mfma.hip); its statistics go to the s_red slots at redo ----

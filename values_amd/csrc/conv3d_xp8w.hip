@@ -1,4 +1,4 @@
-// K1 for the FULL-RESOLUTION layers, wave-specialised form of conv3d_xp8.hip (same arithmetic, same LDS image, same
+// K1 for the FULL-RESOLUTION layers, wave-specialised form of round 2's tools/rejected/conv3d_xp8.hip (same arithmetic, same LDS image, same
 // results bit for bit): the z-column walk with the rolling LDS window, but the two kinds of work of a step run in
 // DIFFERENT waves instead of in sequence inside every wave:
 //
@@ -8,7 +8,7 @@
 //     image (split into fp16 hi / lo, the optional normalise-on-load prologue, the optional fused up-convolution), then
 //     issue the loads of step S_{j+2}.
 //
-// In conv3d_xp8.hip a wave spends 40-55 % of an item in its matrix phase and the rest converting, issuing loads and
+// In that first kernel a wave spends 40-55 % of an item in its matrix phase and the rest converting, issuing loads and
 // storing -- with two waves per SIMD the matrix pipe idles whenever both are outside their matrix phase (item = 7300 ..
 // 9400 cycles against 3456 matrix cycles per SIMD).  Here the staging instructions come from a third (and fourth)
 // wave of the SIMD and issue in the shadow of the consumers' MFMAs; one barrier per item as before.  The roles live in
@@ -43,7 +43,9 @@ struct Xp8wArgs {
 #define XP_WAIT_LOADS() do {} while (0)
 #endif
 
-// NCH, EPI, PRE, UP: as conv3d_xp8.hip.  NPW: producer waves (4 or 8).
+// NCH: 8-channel input chunks (1 or 2).  EPI: epilogue (0 bias + statistics + store, 1 LeakyReLU + hash dropout, 2 that + the
+// fused 1x1x1 head, 3 run-time activation, 4 / 5 below).  PRE: normalise-on-load prologue (0 none, 1 InstanceNorm + LeakyReLU +
+// dropout of the producing block, 2 pre-split input: mask only).  UP: fused up-convolution.  NPW: producer waves (4 or 8).
 // EPI = 4 (one-chunk layers): EPI 0 (bias + statistics + store) PLUS the 2 x 2 x 2 max-pool of the block that follows the
 // InstanceNorm (conv -> norm -> LeakyReLU -> Dropout -> MaxPool, unet3D_module.py:231-237, 303-310) -- the statistics are
 // not known yet, but (x - mean) * rstd and LeakyReLU are monotone, so max over the window of drop(f(x)) =
@@ -912,7 +914,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     float mx = rmax;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    // only magnitudes within a factor two of the fp16 limit are reported (conv3d_xp8.hip)
+    // only magnitudes within a factor two of the fp16 limit are reported (2 x the margin the norm kernels use)
     if (lane == 0 && !(mx < 32768.f)) atomicMax(a.range_flag, __float_as_uint(mx));
   }
 #ifdef VX_CONV_STAMPS

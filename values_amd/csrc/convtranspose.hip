@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
   if (a.range_flag) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
-    if (lane == 0 && !(rmax < 32768.f)) atomicMax(a.range_flag, __float_as_uint(rmax));   // see conv3d_xp8.hip
+    if (lane == 0 && !(rmax < 32768.f)) atomicMax(a.range_flag, __float_as_uint(rmax));   // see conv3d_xp8w.hip
   }
 }
 

@@ -246,7 +246,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // now that its staging runs in producer waves (on the kernel where every wave staged AND multiplied it grew 2.33 -> 2.95
   // and the fusion was neutral)
   // upscale2 inside expand_1_1: the up half of CAT_0 is computed from B_1 while expand_1_1 stages its tiles and never
-  // exists in memory (conv3d_xp8.hip, UP = 1)
+  // exists in memory (conv3d_xp8w.hip, UP = 1)
   const bool fuse_up = dm != VX_DROP_MASK && F == 8 && vx_conv3d_k3_upfuse_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, 2 * F, F);
   // MaxPool of the first block out of contr_1_2's epilogue (window maxima of the kept raw values + any-dropped bits, then
   // vx_pool_finish on 1/8 of the voxels) instead of a pass that re-reads the full-resolution tensor

@@ -51,6 +51,83 @@ def tta_views_2d(img: np.ndarray, mean: Sequence[float], std: Sequence[float], n
     return views, [list(t) for t in TTA_2D_TRANSFORMS]
 
 
+# view codes of vx_tta_views_2d (include/values_amd.h): bit 0 HorizontalFlip, bit 1 VerticalFlip, bit 2 noisy,
+# bit 3 noise field indexed at the source pixel, bit 4 noise slot
+TTA_2D_VIEW_CODES = [0, 1, 4, 1 | 4 | 16]                      # the reference's four views, noise drawn after the flip
+TTA_8_VIEW_CODES = [0, 1, 2, 3, 4 | 8, 5 | 8, 6 | 8, 7 | 8]    # config C4: {id, H, V, HV} of the clean and of the noisy image
+
+
+def tta_views_2d_device(img, mean: Sequence[float], std: Sequence[float], noise=None, noise_flipped=None,
+                        max_pixel_value: float = 255.0, view_codes: Optional[Sequence[int]] = None):
+    """tta_views_2d on the device, one launch (vx_tta_views_2d): img (B, H, W, 3) or (H, W, 3) uint8 tensor (host or
+    device), noise / noise_flipped float fields of the same shape or None.  Returns (views, transforms): views a float32
+    device tensor (G, B, H, W, 4) -- channels-last at pitch 4, channel 3 zero: the layout HighResolutionNet's stem stages
+    from (pass it on with nhwc=True) -- bit-exact with the host function's values; transforms as tta_views_2d."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.as_tensor(img)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dtype != torch.uint8 or t.dim() != 4 or t.shape[-1] != 3:
+        raise ValueError("tta_views_2d_device: img must be uint8 (B, H, W, 3)")
+    t = t.to(dev).contiguous()
+    B, H, W, _ = t.shape
+    codes = list(view_codes) if view_codes is not None else list(TTA_2D_VIEW_CODES)
+
+    def field(n):
+        if n is None:
+            return None
+        n = torch.as_tensor(n).to(dev, torch.float32)
+        if n.dim() == 3:
+            n = n.unsqueeze(0)
+        if tuple(n.shape) != (B, H, W, 3):
+            raise ValueError("tta_views_2d_device: noise fields have the image's shape")
+        return n.contiguous()
+    n0, n1 = field(noise), field(noise_flipped)
+    for g, c in enumerate(codes):      # a noisy view without its field degenerates to the clean one, as the host function's does
+        if (c & 4) and (n1 if (c & 16) else n0) is None:
+            codes[g] = c & 3
+    out = torch.empty((len(codes), B, H, W, 4), dtype=torch.float32, device=dev)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    vc = (C.c_int32 * len(codes))(*codes)
+    _lib.check(lib.vx_tta_views_2d(_lib.ptr(t), 1, _lib.ptr(n0), _lib.ptr(n1), m3, s3, float(max_pixel_value), B, H, W,
+                                   len(codes), vc, _lib.ptr(out), _lib.stream_ptr()), "vx_tta_views_2d")
+    names = [[nm for bit, nm in ((1, "HorizontalFlip"), (2, "VerticalFlip"), (4, "GaussNoise")) if c & bit] for c in codes]
+    return out, names
+
+
+def tta_views_8_device(x, x_noisy, out=None):
+    """values_amd.predict2d.tta_views_8 as one launch: x, x_noisy (B, 3, H, W) float32 device tensors (already normalised)
+    -> ((8, B, H, W, 4) channels-last views, hflip flags, vflip flags) in pred order.  out: write into this tensor (the
+    input of a captured graph: GraphedPredictor2D.x[0])."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    _lib.require_gpu()
+    lib = _lib.load()
+    x = x.to(torch.float32).contiguous()
+    xn = x_noisy.to(x.device, torch.float32).contiguous()
+    B, _, H, W = x.shape
+    codes = [0, 1, 2, 3, 4, 5, 6, 7]
+    if out is None:
+        out = torch.empty((8, B, H, W, 4), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (8, B, H, W, 4) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("tta_views_8_device: out must be a contiguous float32 (8, B, H, W, 4) tensor")
+    vc = (C.c_int32 * 8)(*codes)
+    _lib.check(lib.vx_tta_views_2d(_lib.ptr(x), 0, _lib.ptr(xn), None, None, None, 0.0, B, H, W, 8, vc, _lib.ptr(out),
+                                   _lib.stream_ptr()), "vx_tta_views_2d")
+    return out, [bool(c & 1) for c in codes], [bool(c & 2) for c in codes]
+
+
 def hflip_flags(transforms: Sequence[Sequence[str]]) -> List[bool]:
     """which views test_2D.py flips back (:304-309)."""
     return [any("HorizontalFlip" in s for s in t) for t in transforms]

@@ -227,12 +227,14 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
     per_member = [passes_per_member(m, n_pred, tta, n_aleatoric_samples) for m in models]
     stats = torch.zeros((V, Cc + 1) + spatial, dtype=torch.float32, device=dev)
     if seeds is None and range_check != "off":
-        seeds = pin_seeds(models, {}).get("seeds")      # a second run of this rank's items replays the same dropout bits
+        seeds = pin_seeds(models, {}, tta=tta).get("seeds")      # a second run of this rank's items replays the same dropout bits
 
     def my_items():
         stats.zero_()
         for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
-            kw = {"seeds": [seeds[m]]} if seeds is not None else {}
+            # one dropout stream per (member, volume block): the block's first volume offsets the member's seed, as
+            # predict_image_sliding offsets by the patch batch -- volumes at the same in-block index do not share masks
+            kw = {"seeds": [(int(seeds[m]) + lo) & 0xFFFFFFFF]} if seeds is not None else {}
             if tta:
                 kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
             logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,

@@ -560,12 +560,16 @@ class HighResolutionNet(nn.Module):
                 out.append(self._aff(r[0], r[1], r[2], relu=True))
         return out
 
-    def _backbone(self, x: torch.Tensor) -> List[_Act]:
-        n, cin, h, w = x.shape
-        if cin != self.in_channels:
-            raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
-        xin = torch.zeros((n, h, w, _rp(cin)), dtype=torch.float32, device=x.device)   # channels-last, pitch round4(cin)
-        xin[..., :cin] = x.permute(0, 2, 3, 1)
+    def _backbone(self, x: torch.Tensor, nhwc: bool = False) -> List[_Act]:
+        if nhwc:
+            cin = self.in_channels
+            xin = x
+        else:
+            n, cin, h, w = x.shape
+            if cin != self.in_channels:
+                raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
+            xin = torch.zeros((n, h, w, _rp(cin)), dtype=torch.float32, device=x.device)   # channels-last, pitch round4(cin)
+            xin[..., :cin] = x.permute(0, 2, 3, 1)
         self._hold.append(xin)
         a = _Act(xin, _rp(cin))
         r = self._conv_bn(a, "conv1", "bn1")
@@ -632,11 +636,13 @@ class HighResolutionNet(nn.Module):
                         seeds: Optional[Sequence[int]] = None, hflip_back: bool = False,
                         out: Optional[torch.Tensor] = None, slot_stride: int = 0, slot_offset: int = 0,
                         vflip_back: bool = False, groups: int = 1, group_flips: Optional[Sequence[int]] = None,
-                        softmax_out: bool = False) -> torch.Tensor:
+                        softmax_out: bool = False, nhwc: bool = False) -> torch.Tensor:
         """(n_samples, B, C, H, W) logits (softmax_out: their class softmax instead, computed in the
         upsampling pass): backbone once, DROPOUT_FINAL head per sample.  dropout_masks:
         [sample][4] keep-masks (B, C_k, H_k, W_k) bool (parity tests).  hflip_back: un-flip the output along W
-        (a HorizontalFlip TTA view, test_2D.py:304-309); vflip_back: along H (VerticalFlip, the 8-view extension)."""
+        (a HorizontalFlip TTA view, test_2D.py:304-309); vflip_back: along H (VerticalFlip, the 8-view extension).
+        nhwc: x is (N, H, W, 4) channels-last at the stem's pitch with channel 3 zero -- what vx_tta_views_2d writes
+        (values_amd.data.tta_views_2d_device): staged as it is, no permute / zero-fill copies."""
         _lib.require_gpu()
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         x = x.detach().to(dev, torch.float32)
@@ -647,7 +653,12 @@ class HighResolutionNet(nn.Module):
         # forwards' worth of activations are alive at once (W48 at 32 views: ~2 x 150 GB)
         self._hold_last = None
         self._hold = []
-        n, _, h, w = x.shape
+        if nhwc:
+            if x.dim() != 4 or x.shape[-1] != _rp(self.in_channels) or not x.is_contiguous():
+                raise ValueError(f"forward_samples(nhwc=True): expected a contiguous (N, H, W, {_rp(self.in_channels)}) tensor")
+            n, h, w, _ = x.shape
+        else:
+            n, _, h, w = x.shape
         # groups > 1: x holds `groups` independent BatchNorm batches of n / groups consecutive images (the TTA views of
         # one image batch, test_2D.py:299-311: every view is its own forward with its own batch statistics); group g is
         # un-flipped by group_flips[g] (bit 0 horizontal, bit 1 vertical) and lands in slot offset slot_offset + g
@@ -657,7 +668,7 @@ class HighResolutionNet(nn.Module):
             raise ValueError("forward_samples: batched view groups go with n_samples = 1")
         self._groups = groups
         try:
-            feats = self._backbone(x)
+            feats = self._backbone(x, nhwc=nhwc)
         except Exception:
             self._groups = 1
             raise
@@ -698,7 +709,7 @@ class HighResolutionNet(nn.Module):
             return out
         return out.view(n_samples, n, self.num_classes, h, w)
 
-    def profile_forward(self, x: torch.Tensor, peak_tflops: float, hbm_gbs: float, reps: int = 3, groups: int = 1):
+    def profile_forward(self, x: torch.Tensor, peak_tflops: float, hbm_gbs: float, reps: int = 3, groups: int = 1, nhwc: bool = False):
         """bench.py's roofline leg for the 2D path: one forward per rep on ONE stream with a HIP event pair around every
         convolution launch; the dominant convolution kernel instance with its algorithmic TFLOP/s and GB/s and the roof
         that binds it (the larger of flops / matrix roof and bytes / HBM roof)."""
@@ -709,7 +720,7 @@ class HighResolutionNet(nn.Module):
         try:
             for rep in range(reps + 1):
                 self._prof = []
-                self.forward_samples(x, 1, groups=groups)
+                self.forward_samples(x, 1, groups=groups, nhwc=nhwc)
                 torch.cuda.synchronize()
                 rows, self._prof = self._prof, None
                 if rep == 0:

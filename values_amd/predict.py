@@ -94,15 +94,31 @@ def guarded(models, run, mode: str = "fallback", what: str = "values_amd"):
                                "(limit 65504); re-run under values_amd._lib.config(conv_fp32=1)")
         with _lib.config(conv_fp32=1):     # native-fp32 matrix kernels: no range limit; each family keeps its own packed weights
             out = run()
+        # the norm / fan-out kernels record magnitudes whatever the conv family: the re-run raised the word again, and a
+        # pipelined caller that reads it later (model.check_range()) would see a stale overflow for a batch computed correctly
+        range_watch_begin(models)
     return out
 
 
-def pin_seeds(models, kw: dict) -> dict:
+def _draws_hash_dropout(m) -> bool:
+    return bool(getattr(m, "training", False)) and float(getattr(m, "dropout_prob", 0.0)) > 0 and hasattr(m, "next_seed")
+
+
+def pin_seeds(models, kw: dict, tta: bool = False) -> dict:
     """kw with explicit hash-dropout seeds: an un-seeded call draws them from the models' counters HERE, once, so that a
-    second run of the same batch (the range fallback) replays the same dropout bits."""
-    if kw.get("seeds") is None and kw.get("dropout_masks") is None and all(hasattr(m, "next_seed") for m in models):
-        kw = dict(kw, seeds=[m.next_seed() for m in models])
-    return kw
+    second run of the same batch (the range fallback) replays the same dropout bits.  Only members that DRAW hash dropout
+    get a counter seed: an aleatoric head keeps its sampler's fixed default seeds (1234 + member) and an SSN its own draw
+    counter -- their `seeds` argument means something else, and pinning it changed their default maps from call to call."""
+    if kw.get("seeds") is not None or kw.get("dropout_masks") is not None:
+        return kw
+    m0 = models[0]
+    if hasattr(m0, "rank") and hasattr(m0, "cov_factor_conv"):
+        return kw
+    if bool(getattr(m0, "aleatoric_loss", False)) and not tta:
+        return kw
+    if not any(_draws_hash_dropout(m) for m in models):
+        return kw
+    return dict(kw, seeds=[m.next_seed() if _draws_hash_dropout(m) else 0 for m in models])
 
 
 _side_streams: Dict[int, list] = {}
@@ -244,7 +260,10 @@ def predict_uncertainty(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta:
     if range_check not in ("fallback", "raise", "off"):
         raise ValueError("range_check must be 'fallback', 'raise' or 'off'")
     if range_check != "off":
-        kw = pin_seeds(models, kw)
+        kw = pin_seeds(models, kw, tta=tta)
+        if tta and x_noise is None:      # the generated noise view is drawn ONCE: a range fallback re-runs the same views
+            x_noise = gaussian_noise_view(x.to(x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device()),
+                                               torch.float32))
         return guarded(models, lambda: predict_uncertainty(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise, ssn=ssn,
                                                            want_sample_argmax=want_sample_argmax, range_check="off", **kw),
                        range_check, "predict_uncertainty")

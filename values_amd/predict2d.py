@@ -33,6 +33,17 @@ def tta_views_8(x: torch.Tensor, x_noisy: torch.Tensor):
     return views, hf, vf
 
 
+class NhwcViews:
+    """The TTA views of a batch as ONE channels-last tensor (G, B, H, W, 4) -- what vx_tta_views_2d writes
+    (values_amd.data.tta_views_2d_device / tta_views_8_device) -- plus which views the driver flips back.  predict_logits_2d
+    (tta=True) forwards it as one batch of G statistics groups without any layout copy."""
+
+    def __init__(self, t: torch.Tensor, hflip: Sequence[bool], vflip: Optional[Sequence[bool]] = None):
+        if t.dim() != 5 or t.shape[-1] != 4 or len(hflip) != t.shape[0]:
+            raise ValueError("NhwcViews: (G, B, H, W, 4) tensor and one flip flag per view")
+        self.t, self.hflip, self.vflip = t.contiguous(), list(hflip), list(vflip) if vflip is not None else [False] * t.shape[0]
+
+
 @torch.no_grad()
 def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False, hflip_views: Optional[Sequence[bool]] = None,
                       dropout_masks=None, seeds=None, vflip_views: Optional[Sequence[bool]] = None,
@@ -45,6 +56,19 @@ def predict_logits_2d(models: Sequence, data, n_pred: int = 1, tta: bool = False
     are kept per view (vx_bn_finalize_groups) -- the same numbers as one forward per view, an eighth of the launches."""
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(data, NhwcViews):
+        if not tta or dropout_masks is not None or any(getattr(m, "ssn", False) for m in models):
+            raise ValueError("predict_logits_2d: NhwcViews are the batched TTA views of deterministic / dropout members")
+        G, B, H, W, _ = data.t.shape
+        total = G * len(models)
+        C = models[0].num_classes
+        out = torch.empty((B * total, C, H, W), dtype=torch.float32, device=dev)
+        codes = [(1 if data.hflip[g] else 0) | (2 if data.vflip[g] else 0) for g in range(G)]
+        for mi, model in enumerate(models):
+            model.forward_samples(data.t.view(G * B, H, W, 4), 1, seeds=None if seeds is None else [seeds[mi] * 131], out=out,
+                                  slot_stride=total, slot_offset=mi * G, groups=G, group_flips=codes, softmax_out=softmax,
+                                  nhwc=True)
+        return out.view(B, total, C, H, W)
     views = list(data) if tta else [data]
     B, _, H, W = views[0].shape
     per_model = len(views) if tta else n_pred
@@ -95,18 +119,26 @@ class GraphedPredictor2D:
         self.models, self.tta = list(models), tta
         if any(getattr(m, "dropout_final", False) for m in self.models) and seeds is None:
             raise ValueError("GraphedPredictor2D: DROPOUT_FINAL members need explicit seeds (they are baked into the graph)")
-        ex = list(example) if tta else [example]
-        self.x = [v.detach().to(self.dev, torch.float32).clone() for v in ex]
-        self._kw = dict(n_pred=n_pred, tta=tta, hflip_views=hflip_views, vflip_views=vflip_views, seeds=seeds)
+        self._nhwc = isinstance(example, NhwcViews)
+        if self._nhwc:      # the views as ONE channels-last tensor (vx_tta_views_2d): self.x[0] is the graph's input -- write
+            # the next step's views straight into it (tta_views_8_device(..., out=gp.x[0])) and call gp() without arguments
+            self.x = [example.t.detach().to(self.dev, torch.float32).clone()]
+            data = NhwcViews(self.x[0], example.hflip, example.vflip)
+            self._kw = dict(n_pred=n_pred, tta=True, seeds=seeds)
+        else:
+            ex = list(example) if tta else [example]
+            self.x = [v.detach().to(self.dev, torch.float32).clone() for v in ex]
+            data = self.x if tta else self.x[0]
+            self._kw = dict(n_pred=n_pred, tta=tta, hflip_views=hflip_views, vflip_views=vflip_views, seeds=seeds)
         self._ssn = ssn
 
         fused = not keep_logits and not ssn
 
         def run():
             if fused:
-                pr = predict_logits_2d(self.models, self.x if tta else self.x[0], softmax=True, **self._kw)
+                pr = predict_logits_2d(self.models, data, softmax=True, **self._kw)
                 return None, process_output_2d(None, ssn=ssn, probs=pr)
-            lg = predict_logits_2d(self.models, self.x if tta else self.x[0], **self._kw)
+            lg = predict_logits_2d(self.models, data, **self._kw)
             return lg, process_output_2d(lg, ssn=ssn)
 
         side = torch.cuda.Stream(device=self.dev)
@@ -128,8 +160,13 @@ class GraphedPredictor2D:
                 m._hold_last = None
         torch.cuda.empty_cache()
 
-    def __call__(self, views) -> Dict[str, torch.Tensor]:
-        vs = list(views) if self.tta else [views]
+    def __call__(self, views=None) -> Dict[str, torch.Tensor]:
+        if views is None:                 # the caller wrote the inputs into self.x itself
+            self.graph.replay()
+            return self.out
+        if self._nhwc:
+            views = [views.t if isinstance(views, NhwcViews) else views]
+        vs = list(views) if (self.tta or self._nhwc) else [views]
         if len(vs) != len(self.x):
             raise ValueError("GraphedPredictor2D: %d views, captured with %d" % (len(vs), len(self.x)))
         for dst, v in zip(self.x, vs):

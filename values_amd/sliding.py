@@ -35,7 +35,7 @@ def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int
     _lib.require_gpu()
     if range_check != "off":
         if seeds is None:
-            seeds = pin_seeds(models, {}).get("seeds")
+            seeds = pin_seeds(models, {}, tta=tta).get("seeds")
         return guarded(models, lambda: predict_image_sliding(models, image, patch_size=patch_size, patch_overlap=patch_overlap,
                                                              n_pred=n_pred, tta=tta, patch_batch=patch_batch, compat=compat,
                                                              seeds=seeds, noise_fn=noise_fn,

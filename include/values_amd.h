@@ -85,6 +85,8 @@ typedef struct vx_config {
   int32_t s16_generic;     /* the tile kernel's GENERIC instance (run-time epilogue, one LDS image, two barriers per item) wherever a
                               specialised one (compile-time epilogue, double-buffered staggered schedule) would run: the reference
                               of tests/test_gpu_kernels.py::test_conv3d_k3_specialised_instances_equal_generic (bit for bit) */
+  int32_t s16_no_upcompose; /* the fused up-convolution evaluated per step by the staging waves (round 2) instead of composed into
+                               expand_1_1's weights (round 4, vx_conv3d_args.up_fused) */
   int32_t s16_no_upsplit;  /* expand_2_2 stores plain floats and the fused up-convolution splits them per step (round 2) */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
@@ -237,7 +239,23 @@ typedef struct vx_conv3d_args {
    * up_split -- up_in is such a tensor: the staging waves take the matrix operands as they are (each coarse voxel was split
    * by four waves per step before).  Same values, same bits. */
   int32_t out_split, up_split;
+  /* COMPOSED up-convolution (round 4; with up_in, optional): the output of vx_pack_conv3d_upfused for this layer's weights and
+   * the transposed conv's.  ConvTranspose3d(k = 2, s = 2) has no activation behind it (unet3D_module.py:157-190, 332-356), so
+   * conv(cat([up, skip])) = conv_skip(skip) + (W_up-half o U)(coarse) + bias terms: per output parity class (z & 1, y & 1)
+   * the up half of the 3x3x3 conv composed with the transposed conv is a 2 x 2 x 3 (x-pair) tap convolution over the 16
+   * COARSE channels -- K = 192 instead of 288 per x-pair row, and the staging waves copy the coarse tensor into LDS instead
+   * of evaluating the transposed conv per step.  The up bias enters through a table of the 27 border classes (a 3x3x3 tap
+   * outside the volume sees the zero padding of the concatenated tensor, not the bias).  Same function of the inputs;
+   * weights composed in float64 at pack time, so results differ from the two-stage evaluation by float32 rounding only. */
+  const float* up_fused;
 } vx_conv3d_args;
+int64_t vx_conv3d_upfused_packed_floats(void);
+/* w1_torch (8, 16, 3,3,3) + b1 (8): the decoder conv whose input channels [0, 8) are the up half; up_w_torch (16, 8, 2,2,2) +
+ * up_b (8): the transposed conv (torch layouts, device pointers) -> packed [4 classes][6 K-steps][hi | lo][64 lanes][8 halves]
+ * + bias table [27][8].  VX_E_SHAPE (reported through the returned code of the NEXT synchronising call: the check runs on the
+ * device) never happens; a composed weight beyond the fp16 range is clamped like vx_pack_conv3d_k3 clamps. */
+int vx_pack_conv3d_upfused(const float* w1_torch, const float* b1, const float* up_w_torch, const float* up_b, float* packed,
+                           vx_stream_t stream);
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
 int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
@@ -346,6 +364,8 @@ typedef struct vx_unet3d_weights {
   int32_t in_channels;     /* 0 or 1: conv_w[0] is the torch layout of a Cin == 1 layer (vx_conv3d_k3_c1); 2 .. 8: conv_w[0]
                               is PACKED for Cin = 8 (weights zero-padded), the input goes through vx_pack_input_cl8 */
   int32_t no_instancenorm; /* 1: do_instancenorm=False -- contract blocks are conv + LeakyReLU + Dropout (unet3D_module.py:238-243) */
+  const float* up_fused;   /* nullable: vx_pack_conv3d_upfused(expand_1_1, upscale2) -- the level-0 up-convolution composed into
+                              expand_1_1 (vx_conv3d_args.up_fused); NULL: evaluated per step by the staging waves (round 2) */
 } vx_unet3d_weights;
 
 typedef struct vx_unet3d_run {

@@ -614,7 +614,7 @@ def _hash_mask(seed, layer, n, c, d, h, w):
 
 
 def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, stats=False, xblk=0, head=None,
-              pre=None, out_xblk=0, up=None, in_pitch=None, presplit=False):
+              pre=None, out_xblk=0, up=None, in_pitch=None, presplit=False, compose=False, up_split=False):
     """one vx_conv3d_k3 launch on a channels-last (or x-blocked) device input; returns (out NCDHW cpu, stats, head)"""
     lib = _lib.load()
     assert lib.vx_conv3d_k3_prologue_ok(d, h, wd, cin, 8) == 1
@@ -634,6 +634,21 @@ def _xp8_conv(x_cl, cin, w, b, n, d, h, wd, *, act=0, drop=0, seed=0, layer=0, s
         uwp = torch.empty(lib.vx_convT_k2s2_packed_floats(16, 8), dtype=torch.float32, device=dev())
         _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(uwd), _lib.ptr(uwp), 16, 8, _lib.stream_ptr()), "packT")
         a.up_in, a.up_w, a.up_b, a.up_pitch = coarse.data_ptr(), uwp.data_ptr(), ubd.data_ptr(), coarse.shape[-1]
+        if up_split:        # the coarse tensor handed over as fp16 (hi, lo) pairs (vx_conv3d_args.out_split of the producing conv):
+            # vx_prenorm_split with mean 0, rstd 1 would apply a LeakyReLU -- build the pairs here instead
+            cs = coarse.clone()
+            v = cs[..., :16].reshape(-1, 4)
+            hi = v.half()
+            lo = ((v - hi.float()) * 2048.0).half()
+            cs[..., :16] = torch.cat([hi, lo], 1).view(torch.float32).reshape(cs[..., :16].shape)
+            a.up_in, a.up_split = cs.data_ptr(), 1
+            uwp = (uwp, cs)
+        if compose:         # the up-convolution composed into the conv's weights (vx_pack_conv3d_upfused)
+            uf = torch.empty(lib.vx_conv3d_upfused_packed_floats(), dtype=torch.float32, device=dev())
+            _lib.check(lib.vx_pack_conv3d_upfused(_lib.ptr(wdv), _lib.ptr(bd), _lib.ptr(uwd), _lib.ptr(ubd), _lib.ptr(uf),
+                                                  _lib.stream_ptr()), "vx_pack_conv3d_upfused")
+            a.up_fused = uf.data_ptr()
+            uwp = (uwp, uf)
     a.out_xblk, a.out_half = out_xblk, 1
     keep = [wdv, bd, wp, out]
     st = None
@@ -808,6 +823,26 @@ def test_conv3d_xp8_fused_upconvolution_matches_oracle(shape, xblk, pitch, pmode
     _, _, _, mxb = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None,
                              pre=pre, up=(cd, uw, ub + 4.5e4))
     assert mxb > 4e4
+    # Round 4: the up-convolution COMPOSED into the conv's weights (vx_pack_conv3d_upfused -> vx_conv3d_args.up_fused): per
+    # output parity class a 2 x 2 x 3-tap convolution over the 16 coarse channels, the up bias through a table of the 27
+    # border classes.  Same function, the same oracle, the same tolerance; with and without dropout, the coarse tensor as
+    # plain floats and as the fp16 pairs expand_2_2's epilogue hands over; and the knob that switches it off
+    got, _, _, mx = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=93, layer=15,
+                              xblk=xblk, in_pitch=8 if not xblk else None, pre=pre, up=(cd, uw, ub), compose=True)
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8w_kernel<2,1,%d,2," % (0 if pre is None else 1))
+    err = (got.double() - want).abs().max().item()
+    assert err < 4e-5, err
+    got, _, _, _ = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None,
+                             pre=pre, up=(cd, uw, ub), compose=True, up_split=True)
+    assert (got.double() - F.leaky_relu(ref, 0.01)).abs().max().item() < 4e-5
+    got1, _, _, _ = _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None,
+                              pre=pre, up=(cd, uw, ub), up_split=True)           # per-step evaluation on the pre-split tensor
+    assert (got1.double() - F.leaky_relu(ref, 0.01)).abs().max().item() < 4e-5
+    vxcfg.set(s16_no_upcompose=1)
+    _xp8_conv(xd, 16, wt, b, n, d, h, w, act=_lib.VX_ACT_LRELU, xblk=xblk, in_pitch=8 if not xblk else None, pre=pre,
+              up=(cd, uw, ub), compose=True)
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_xp8w_kernel<2,3,%d,1," % (0 if pre is None else 1))
+    vxcfg.set(s16_no_upcompose=0)
     # refused, not silently ignored, where the column kernel does not run
     vxcfg.set(s16_no_upfuse=1)
     with pytest.raises(_lib.VxError):

@@ -3,7 +3,7 @@
 late (4..7) waves (s_memtime stamps, VX_CONV_STAMPS build; nothing of this is in the product library).
 Build:  mkdir -p /tmp/stamps && cp values_amd/csrc/*.hip values_amd/csrc/*.h values_amd/csrc/*.cpp values_amd/csrc/Makefile /tmp/stamps ...
         (tools/build_stamps.sh does it)
-Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head[:up] ...]   with VX_S16_DBG / VX_XP_ABL (diagnostic build only) for phase ablation
+Usage:  python tools/stamp_s16.py [cin:cout:edge:act:drop:head[:up[:pre[:pool[:compose[:upsplit]]]]] ...]   with VX_S16_DBG / VX_XP_ABL (diagnostic build only) for phase ablation
         (up = 1: the fused up-convolution of conv3d_xp8.hip, the skip half from a plain 8-channel tensor)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -37,6 +37,12 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
         uwp = torch.empty(lib.vx_convT_k2s2_packed_floats(16, 8), dtype=torch.float32, device=dev)
         _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(uw), _lib.ptr(uwp), 16, 8, _lib.stream_ptr()), "packT")
         a.up_in, a.up_w, a.up_b, a.up_pitch = coarse.data_ptr(), uwp.data_ptr(), ub.data_ptr(), 16
+        if len(f) > 9 and f[9]:      # field 10: the up-convolution composed into the weights (round 4, vx_conv3d_args.up_fused)
+            uf = torch.empty(lib.vx_conv3d_upfused_packed_floats(), dtype=torch.float32, device=dev)
+            _lib.check(lib.vx_pack_conv3d_upfused(_lib.ptr(w), _lib.ptr(b), _lib.ptr(uw), _lib.ptr(ub), _lib.ptr(uf), _lib.stream_ptr()), "packU")
+            a.up_fused = uf.data_ptr()
+        if len(f) > 10 and f[10]:    # field 11: the coarse tensor arrives as fp16 pairs (the bits do not matter for timing)
+            a.up_split = 1
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = N, edge, edge, edge, cin, cout
     if pre:
         rep = 10 if (cin == 8 and N % 10 == 0) else 1

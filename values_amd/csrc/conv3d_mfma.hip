@@ -687,6 +687,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
       VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: up_in pitch %d (>= 16, multiple of 4 floats) / alignment", a.up_pitch);
     if ((int64_t)(a.D / 2 + 2) * (a.H / 2) * (a.W / 2) * a.up_pitch * 4 >= (1ll << 31))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: one coarse sample must stay below 2 GiB");
+    if (a.up_fused && !vx_aligned16(a.up_fused)) VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: up_fused alignment");
+  } else if (a.up_fused) {
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: up_fused (composed up-convolution weights) without up_in");
   }
   if (a.pool_out) {
     if (!a.pool_flags || !a.stats_partial) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: pool_out goes with pool_flags and stats_partial");

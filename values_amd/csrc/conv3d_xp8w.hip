@@ -60,6 +60,18 @@ template <int NCH, int EPI, int PRE, int UP, int NPW, int IN16 = 0>
 __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka) {
   static_assert(IN16 == 0 || (NCH == 1 && PRE == 0 && UP == 0), "fp16 input: one-chunk layers without a prologue");
   static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
+  // UP = 2 (round 4): the up-convolution COMPOSED into this conv's weights (vx_conv3d_args.up_fused).  The up half of the
+  // input never exists, not even in LDS: the image holds the skip chunk plus a rolling window of COARSE planes (18 x 6
+  // positions x 16 channels, 4 plane slots), and a consumer's K loop is 9 (kz, ky) steps over the skip chunk + 6 steps over
+  // the 2 x 2 x 3 coarse taps of its output parity class (z & 1, y & 1) -- 45 instead of 54 matrix instructions per row,
+  // and the staging waves copy one coarse plane per step instead of evaluating 24 small GEMMs.
+  constexpr int NIMG = UP == 2 ? 1 : NCH;                 // image chunks of fine planes in LDS
+  constexpr int CW = 18, CH = 6, CSL = 4;                 // coarse window: x positions, rows, plane slots
+  constexpr int CPL = CSL * CH * CW;                      // positions per (octet, precision) plane of the coarse image
+  constexpr int CSLOT_H = CH * CW * 8;                    // halves between two plane slots
+  constexpr int CIMG_H = UP == 2 ? 2 * 2 * CPL * 8 : 0;   // halves of the coarse image ([octet][precision][slot][row][x][8])
+  constexpr int WC_H = UP == 2 ? 4 * 6 * 2 * 64 * 8 : 0;  // halves of the composed weights ([class][step][hi | lo][lane][8])
+  constexpr int NWCH = UP == 2 ? 1 : NCH;                 // conv weight chunks held in LDS (UP = 2: the skip chunk's)
   constexpr int NW = 8, NTH = (NW + NPW) * 64;
   constexpr int TZ = 4 / NCH;
   constexpr int R = TZ;                       // column tiles (y-rows of one z-plane) per consumer wave
@@ -76,8 +88,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16* s_img = reinterpret_cast<_Float16*>(smem_raw);
-  _Float16* s_w = s_img + NCH * CHUNK_H;
-  float* s_red = reinterpret_cast<float*>(s_w + NCH * W_H);
+  _Float16* s_cimg = s_img + NIMG * CHUNK_H;
+  _Float16* s_w = s_cimg + CIMG_H;
+  _Float16* s_wc = s_w + NWCH * W_H;
+  float* s_btab = reinterpret_cast<float*>(s_wc + WC_H);            // UP = 2: bias of the 27 border classes, [27][8]
+  float* s_red = s_btab + (UP == 2 ? 27 * 8 : 0);
 
   const vx_conv3d_args& a = ka.a;
   // Fields a wave needs once per item or per column (the pooled output's pointers, the statistics buffer) are re-read from
@@ -99,9 +114,19 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
   // ---- weights: resident for the kernel's life ----
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.w_packed);
-    for (int i = tid; i < NCH * W_H / 8; i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.w_packed) + (UP == 2 ? W_H / 8 : 0);   // UP = 2: chunk 1 = the skip half
+    for (int i = tid; i < NWCH * W_H / 8; i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+    if constexpr (UP == 2) {
+      const f32x4* csrc = reinterpret_cast<const f32x4*>(a.up_fused);
+      for (int i = tid; i < WC_H / 8; i += NTH) reinterpret_cast<f32x4*>(s_wc)[i] = csrc[i];
+      for (int i = tid; i < 27 * 8; i += NTH) s_btab[i] = a.up_fused[WC_H / 2 + i];
+      // the coarse window starts as zeros: the first item of the workgroup reads plane -1 from the slot "before" step 0
+      // (later columns find the previous column's last step there: coarse plane D / 2, outside the volume = zeros)
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      for (int i = tid; i < CIMG_H / 8; i += NTH) reinterpret_cast<f32x4*>(s_cimg)[i] = z4;
+    }
   }
+  if constexpr (UP == 2) __syncthreads();      // (every wave, both roles) the zero fill before the first coarse plane lands
 
   // ---- the columns of this workgroup ----
   int vb = blockIdx.x;
@@ -199,7 +224,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       unit_geo(unit_of(i), lch, r, dzy, dy, pz);
       if (!LIN || i == 0) {
         u_soff[LIN ? 0 : i] = (dzy * rowf + (xpart(0, lch) - xpart(0, 0))) * ISZ;
-        u_lds[LIN ? 0 : i] = lch * CHUNK_H + r * HXP * 8;
+        u_lds[LIN ? 0 : i] = (UP == 2 ? 0 : lch) * CHUNK_H + r * HXP * 8;
       }
       if (unit_of(i) < NU) um_valid |= 1u << i;
       if (dy < 0) um_ylo |= 1u << i;
@@ -231,7 +256,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       unit_geo(hp >> 2, lch, r, dzy, dy, pz);
       const int dx = side ? 32 : -1, hx = dx + 1;
       h_voff = (unsigned)((dzy * rowf + xpart(dx, lch) + biasf) * ISZ);
-      h_lds = lch * CHUNK_H + (hx & 1) * PP * 8 + (r * HXP + (hx >> 1)) * 8 + qq * 4;
+      h_lds = (UP == 2 ? 0 : lch) * CHUNK_H + (hx & 1) * PP * 8 + (r * HXP + (hx >> 1)) * 8 + qq * 4;
       h_erel = (unsigned)((dzy * a.W + dx) * 8 + qq * 4);
       h_flags = (hp >= NH ? 1u : 0u) | (side ? 4u : 2u) | (dy < 0 ? 8u : 0u) | (dy >= 8 ? 16u : 0u) | (pz < TZ - 1 ? 32u : 64u) |
                 ((PRE != 0 && (NCH == 1 || lch == 1)) ? 128u : 0u);
@@ -244,18 +269,37 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // c % 18) of the 5 x 18 coarse positions whose fine row of parity u_ay lies in the staged 10 x 34 window).  Rows of
     // the product are (dx, co): lane (m, g) ends with channels 4 (g & 1) .. + 3 of the fine voxel x = 2 X + (g >> 1) --
     // the piece layout of the staged loads.
-    constexpr int UT = 24 / NPW;                        // column tiles per producer wave and step
+    constexpr int UT = UP == 1 ? 24 / NPW : 1;          // column tiles per producer wave and step
     const int u_cls = (pw * UT) / 6, u_t0 = (pw * UT) % 6;
     const int u_pz = u_cls >> 1, u_ay = u_cls & 1;
     const int Hc = a.H >> 1, Wc = a.W >> 1;
     const int urow = Wc * a.up_pitch;
     const int ubiasf = (Hc + 1) * urow + a.up_pitch;
-    unsigned u_voff[UP ? UT : 1];
-    int u_ldst[UP ? UT : 1];
+    unsigned u_voff[UP == 1 ? UT : 1];
+    int u_ldst[UP == 1 ? UT : 1];
     unsigned ub_always = 0, ub_xlo = 0, ub_xhi = 0, ub_ylo = 0, ub_yhi = 0, u_nowrite = 0;
     f16x4 u_ah = {0, 0, 0, 0}, u_al = {0, 0, 0, 0};
     f32x4 ubias4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (UP != 0) {
+    // UP = 2: this lane's pieces of a coarse plane (6 rows x 18 x 4 channel quads = 432 pieces of 16 bytes per step)
+    constexpr int CPT = UP == 2 ? (CH * CW * 4 + NPW * 64 - 1) / (NPW * 64) : 1;
+    unsigned c_voff[CPT];
+    int c_lds[CPT];
+    unsigned cb_always = 0, cb_xlo = 0, cb_xhi = 0, cb_ylo = 0, cb_yhi = 0;
+    if constexpr (UP == 2) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int pc = pw * 64 + lane + i * NPW * 64;
+        const int q = pc & 3, xi = (pc >> 2) % CW, ry = (pc >> 2) / CW;
+        c_voff[i] = (unsigned)((((ry - 1) * Wc + (xi - 1)) * a.up_pitch + q * 4 + ubiasf) * 4);
+        c_lds[i] = (((q >> 1) * 2) * CPL + ry * CW + xi) * 8 + (q & 1) * 4;
+        if (pc >= CH * CW * 4) cb_always |= 1u << i;
+        if (xi == 0) cb_xlo |= 1u << i;
+        if (xi == CW - 1) cb_xhi |= 1u << i;
+        if (ry == 0) cb_ylo |= 1u << i;
+        if (ry == CH - 1) cb_yhi |= 1u << i;
+      }
+    }
+    if constexpr (UP == 1) {
 #pragma unroll
       for (int i = 0; i < UT; ++i) {
         const int c = 16 * (u_t0 + i) + m;
@@ -289,7 +333,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // halves travel through float lanes of a wider vector -- the second dword was garbage; tools/micro/load_b64_narrow.hip)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 ibuf16[IN16 ? RPW : 1], hbuf16 = {0u, 0u};
-    f32x4 ubuf[UP ? UT : 1];
+    f32x4 ubuf[UP == 1 ? UT : 1];
+    f32x4 cbuf[CPT];
     unsigned p_ubad = 0;
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
     unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;   // bit i: row unit i of the staged step lies outside the volume
@@ -324,11 +369,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       cs_srd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<const char*>(a.in) + ((size_t)nin * in_sample - biasf) * ISZ), 0, VX_NUMREC, 0x00020000);
       if constexpr (UP != 0) {
-        unsigned ub = ub_always;
-        if (tx == 0) ub |= ub_xlo;
-        if (tx == ka.tiles_x - 1) ub |= ub_xhi;
-        if (ty == 0) ub |= ub_ylo;
-        if (ty == ka.tiles_y - 1) ub |= ub_yhi;
+        unsigned ub = UP == 2 ? cb_always : ub_always;
+        if (tx == 0) ub |= UP == 2 ? cb_xlo : ub_xlo;
+        if (tx == ka.tiles_x - 1) ub |= UP == 2 ? cb_xhi : ub_xhi;
+        if (ty == 0) ub |= UP == 2 ? cb_ylo : ub_ylo;
+        if (ty == ka.tiles_y - 1) ub |= UP == 2 ? cb_yhi : ub_yhi;
         cs_ub = ub;
         cs_usoff = (unsigned)(((ty * 4) * urow + tx * 16 * a.up_pitch) * 4);
         cs_usrd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.up_in + (size_t)n * up_sample - ubiasf), 0, VX_NUMREC, 0x00020000);
@@ -380,7 +425,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         }
         p_hbad = lbad;
       }
-      if constexpr (UP != 0) {
+      if constexpr (UP == 1) {
         unsigned ub = cs_ub;
         if (!have || (c.s == 0 && u_pz == 0) || (c.s == KZ && u_pz == 1)) ub = 0xFFFFFFFFu;
         const unsigned usoff = cs_usoff + (unsigned)((c.s * Hc) * urow * 4);
@@ -390,6 +435,18 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           ubuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)vo, (int)usoff, 0));
         }
         p_ubad = ub;
+      }
+      if constexpr (UP == 2) {
+        // step s of a column carries coarse plane s (item s - 1 = fine planes 2 s - 2, 2 s - 1 needs coarse s - 2 .. s);
+        // plane D / 2 (step KZ) lies outside: zeros -- which the NEXT column's first item reads as its plane -1
+        unsigned ub = cs_ub;
+        if (!have || c.s == KZ) ub = 0xFFFFFFFFu;
+        const unsigned usoff = cs_usoff + (unsigned)((c.s * Hc) * urow * 4);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          const unsigned vo = ((ub >> i) & 1u) ? VX_OOB : c_voff[i];
+          cbuf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)vo, (int)usoff, 0));
+        }
       }
       if constexpr (PRE != 0) p_e0 = cs_e0 + (unsigned)(((TZ * c.s) * a.H) * a.W) * 8u;
     };
@@ -426,7 +483,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       lo = __builtin_bit_cast(f16x4, (u32x2){d[2] & m01, d[3] & m23});
     };
 
-    auto commit = [&](int grp) {
+    auto commit = [&](int grp, int jstep) {      // jstep: running number of the step (all columns of the workgroup)
       const int gofs = grp * GRP_H;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f};
       const bool hashed = PRE != 0 && a.in_drop_mode == VX_DROP_HASH;
@@ -508,7 +565,28 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         *reinterpret_cast<f16x4*>(s_img + gofs + h_lds) = hi;
         *reinterpret_cast<f16x4*>(s_img + gofs + h_lds + PREC_H) = lo;
       }
-      if constexpr (UP != 0) {
+      if constexpr (UP == 2) {
+        // the step's coarse plane into slot jstep % 4 of the coarse window, as fp16 pairs (pre-split by the producing conv's
+        // epilogue, vx_conv3d_args.up_split, or split here: one piece per lane and step)
+        _Float16* cdst = s_cimg + (jstep & (CSL - 1)) * CSLOT_H;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          f16x4 hi, lo;
+          if (a.up_split) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 d = __builtin_bit_cast(u32x4, cbuf[i]);
+            hi = __builtin_bit_cast(f16x4, (u32x2){d[0], d[1]});
+            lo = __builtin_bit_cast(f16x4, (u32x2){d[2], d[3]});
+          } else {
+            split4(cbuf[i], hi, lo);
+          }
+          if (!((cb_always >> i) & 1u)) {
+            *reinterpret_cast<f16x4*>(cdst + c_lds[i]) = hi;
+            *reinterpret_cast<f16x4*>(cdst + c_lds[i] + CPL * 8) = lo;
+          }
+        }
+      }
+      if constexpr (UP == 1) {
         // the up half of the step: ConvTranspose3d(k = 2, s = 2) of the coarse voxels just loaded, three split products
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f16x4 ubh[UT], ubl[UT];
@@ -553,16 +631,17 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
     Cur cx = {0, 0}, cc = {0, 0}, cp = {0, 0};   // visible / to commit / to prefetch
     prefetch(cp); advance(cp);
-    commit(0);     advance(cc);                  // S_0 -> slot group 0
+    commit(0, 0);  advance(cc);                  // S_0 -> slot group 0
     prefetch(cp); advance(cp);
     int grp_x = 0;
+    int jrun = 0;                                // S_jrun is the visible step
     while (cx.ci < ncol_wg) {
       __syncthreads();
       XP_STAMP(0);
       int grp_c = grp_x + 1; if (grp_c == 3) grp_c = 0;               // group S_{j+1} goes into
       XP_WAIT_LOADS();
       XP_STAMP(3);
-      if (cc.ci < ncol_wg && !(XP_ABL & 4)) commit(grp_c);
+      if (cc.ci < ncol_wg && !(XP_ABL & 4)) commit(grp_c, jrun + 1);
       XP_STAMP(4);
       if (!(XP_ABL & 8)) prefetch(cp);
       XP_STAMP(5);
@@ -571,6 +650,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 #endif
       advance(cx); advance(cc); advance(cp);
       grp_x = grp_c;
+      ++jrun;
     }
     if (STATS) __syncthreads();
   } else {
@@ -586,6 +666,20 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
     // ---- epilogue constants: this lane stores voxel x = 2 m + (g >> 1) of row ly0 + r, channels 4 (g & 1) .. + 3 ----
     const int lx = 2 * m + (g >> 1), oc = (g & 1) * 4;
+    // ---- UP = 2: the composed coarse part.  K-step s, k-group g = coarse octet o = 4 s + g = ((czi 2 + cyi) 3 + cxi) 2 + oct:
+    // coarse tap (plane czi, row cyi, x cxi) relative to the output pair's class origin, channels 8 oct .. + 7.  czi = s / 3
+    // for every lane; the rest is this lane's offset into the coarse image (hi plane; row of the tile, plane slot on top)
+    int cofs[UP == 2 ? 6 : 1];
+    if constexpr (UP == 2) {
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const int o = 4 * s + g;
+        const int oct = o & 1, cxi = (o >> 1) % 3, cyi = (o / 6) & 1;
+        cofs[s] = ((oct * 2) * CPL + ((ly0 >> 1) + cyi) * CW + cxi + m) * 8;
+      }
+    }
+    int m_ci = -1, m_ty = 0;           // UP = 2: column of the bias classes below
+    int m_bofs = 0;                    //         byte offset of this lane's (x class, channel quad) within a table row
     unsigned ovoff[R], eoff[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -633,7 +727,110 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // rows requested as the products free their registers: 2.59 -> 2.52 ms on the two-chunk layer, 1-5 % SLOWER on the
     // one-chunk layers where the extra live rows spill; operands-in-registers rate of this instruction is 78 % of the
     // nominal peak and the plain loop already runs at 71 %)
-    auto multiply = [&](int rb) {
+    auto multiply = [&](int rb, int jstep, int ci, int k) {
+      if constexpr (UP == 2) {
+        // bias of the rows: b + sum over the 3x3x3 taps INSIDE the volume of W[up half] . up_b -- 27 border classes (z, y, x)
+        if (ci != m_ci) {
+          m_ci = ci;
+          int n_, tx_;
+          col_of(ci, n_, m_ty, tx_);
+          const int xc = (tx_ == 0 && lx == 0) ? 0 : ((tx_ == ka.tiles_x - 1 && lx == 31) ? 2 : 1);
+          m_bofs = (xc * 8 + oc) * 4;
+        }
+        const int z = k * TZ + lz;
+        const int zc = z == 0 ? 0 : (z == a.D - 1 ? 2 : 1);
+        const int pz = lz & 1;                                        // (items start at even z)
+        // slots of this wave's two coarse planes: item completed by step jstep reads the planes of steps jstep - 2 .. jstep
+        const _Float16* cb[2];
+        cb[0] = s_cimg + ((jstep - 2 + pz) & (CSL - 1)) * CSLOT_H;
+        cb[1] = s_cimg + ((jstep - 1 + pz) & (CSL - 1)) * CSLOT_H;
+        // the three fine planes of the skip chunk this wave's rows read
+        const _Float16* prow[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          int slot = rb + lz + kz;
+          if (slot >= NZ) slot -= NZ;
+          prow[kz] = s_img + bfrag0 + slot * (ZP * 8);
+        }
+        const _Float16* wsk = s_w + wslot * 8;
+        f32x4 b4[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int y = m_ty * 8 + ly0 + r;
+          const int yc = y == 0 ? 0 : (y == a.H - 1 ? 2 : 1);
+          b4[r] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_btab) + ((zc * 3 + yc) * 3) * 32 + m_bofs);
+        }
+        // ONE software pipeline of 15 K-steps (6 coarse, 9 (kz, ky) of the skip chunk), 6 matrix instructions each: the
+        // fragments of step t + 1 are requested behind the matrix instructions of step t and pinned there
+        // (sched_group_barrier) -- left alone hipcc sinks every ds_read to just before its consumer (ds_read; s_waitcnt
+        // lgkmcnt(0..2); v_mfma), one exposed LDS latency per matrix instruction pair.  On the per-step kernel the staging
+        // waves were the critical path and a denser matrix stream only took issue slots from them (round 3: -1..-6 %);
+        // with the up-convolution composed into the weights the MULTIPLYING waves are (stamps: 72 % of an item in this
+        // phase, the staging waves parked 31 %).
+        //   coarse step s: per row r its class' weights (hi, lo) + its coarse row (hi, lo): 8 reads
+        //   skip step (kz, ky): the weights (2 reads) + the image rows ky, ky + 1 of plane kz, of which row ky came with the
+        //   previous step: rows 0, 1 with (kz, 0), row ky + 1 later -- 14 reads per kz as in the plain loop
+        f16x8 cA[2][R][2], cB[2][R][2];          // coarse fragments, two sets
+        f16x8 sA[2][2];                          // skip weights, two sets
+        f16x8 sR[2][4][2];                       // skip image rows of plane kz (set kz & 1): [row][hi | lo]
+        auto load_coarse = [&](int cs_, int set) {
+          const _Float16* bp = cb[cs_ / 3] + cofs[cs_];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const _Float16* wp = s_wc + ((((pz * 2 + r) * 6 + cs_) * 2) * 64 + lane) * 8;
+            cA[set][r][0] = *reinterpret_cast<const f16x8*>(wp);
+            cA[set][r][1] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+            cB[set][r][0] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8);
+            cB[set][r][1] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8 + CPL * 8);
+          }
+        };
+        auto load_skip = [&](int kz, int ky) {    // what step (kz, ky) needs beyond what step (kz, ky - 1) left
+          const _Float16* wp = wsk + (kz * 3 + ky) * (2 * 32 * 8);
+          sA[(kz * 3 + ky) & 1][0] = *reinterpret_cast<const f16x8*>(wp);
+          sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+          for (int jr = (ky == 0 ? 0 : ky + 1); jr <= ky + 1; ++jr) {
+            sR[kz & 1][jr][0] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8);
+            sR[kz & 1][jr][1] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8 + PREC_H);
+          }
+        };
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        load_coarse(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * R, 0);
+#pragma unroll
+        for (int t = 0; t < 15; ++t) {
+          int nrd = 0;                            // reads requested during this step
+          if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = 4 * R; }
+          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = 2 + (q % 3 == 0 ? 4 : 2); }
+          if (t < 6) {
+            const int set = t & 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][0], t == 0 ? b4[r] : acc[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][1], t == 0 ? zero4 : accx[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][1], cB[set][r][0], accx[r], 0, 0, 0);
+            }
+          } else {
+            const int q = t - 6, kz = q / 3, ky = q % 3;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][0], acc[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
+              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][r + ky][0], accx[r], 0, 0, 0);
+            }
+          }
+          // pin: one read of the next step behind each of this step's matrix instructions
+          constexpr int NMF = 3 * R;
+          const int pairs = nrd < NMF ? nrd : NMF;
+#pragma unroll
+          for (int i = 0; i < NMF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < pairs) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          constexpr int EXTRA = 4 * R > NMF ? 4 * R - NMF : 1;     // (only a coarse step requests more reads than it multiplies)
+          if (t + 1 < 6 && 4 * R > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXTRA, 0);
+        }
+        return;
+      }
       if constexpr (POOLM) {
         // 2 rows x 2 planes per wave: per kz the three weight fragments stay in registers while the two planes' four rows
         // each pass through the same row registers (live: 24 + 32 VGPRs instead of 8 + 64 for both planes at once)
@@ -676,9 +873,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         return;
       }
 #pragma unroll
-      for (int chunk = 0; chunk < NCH; ++chunk) {
-        const _Float16* img = s_img + chunk * CHUNK_H + bfrag0;
-        const _Float16* wch = s_w + chunk * W_H + wslot * 8;
+      for (int chunk = (UP == 2 ? 1 : 0); chunk < NCH; ++chunk) {
+        const _Float16* img = s_img + (UP == 2 ? 0 : chunk) * CHUNK_H + bfrag0;
+        const _Float16* wch = s_w + (UP == 2 ? 0 : chunk) * W_H + wslot * 8;
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
           int slot = rb + lz + kz;
@@ -697,7 +894,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
             const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-              const bool fresh = chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
+              const bool fresh = UP != 2 && chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
               const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
               if constexpr (IN16 == 0) {
@@ -888,10 +1085,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (late) {
         if (prev_ci >= 0 && !(XP_ABL & 2)) { epilogue(prev_ci, prev_k); prev_ci = -1; }
         XP_STAMP(2);
-        if (comp) { if (!(XP_ABL & 1)) multiply(rb); prev_ci = cx.ci; prev_k = item_k; }
+        if (comp) { if (!(XP_ABL & 1)) multiply(rb, j, cx.ci, item_k); prev_ci = cx.ci; prev_k = item_k; }
         XP_STAMP(1);
       } else {
-        if (comp && !(XP_ABL & 1)) multiply(rb);
+        if (comp && !(XP_ABL & 1)) multiply(rb, j, cx.ci, item_k);
         XP_STAMP(1);
         if (comp && !(XP_ABL & 2)) epilogue(cx.ci, item_k);
         XP_STAMP(2);
@@ -937,7 +1134,9 @@ template <int NCH, int EPI, int PRE, int UP, int NPW, int IN16 = 0>
 static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
   constexpr int TZ = 4 / NCH, NZ = 3 * TZ, ZP = 170;
   constexpr int PP = ((NZ * ZP + 15) / 16) * 16;
-  constexpr size_t lds = (size_t)NCH * 2 * 2 * PP * 8 * 2 + (size_t)NCH * (9 * 2 * 32 * 8) * 2 + 8 * 16 * 2 * 4;
+  constexpr int NIMG = UP == 2 ? 1 : NCH;      // UP = 2: skip chunk + coarse window + composed weights + bias table
+  constexpr size_t lds = (size_t)NIMG * 2 * 2 * PP * 8 * 2 + (size_t)NIMG * (9 * 2 * 32 * 8) * 2 + 8 * 16 * 2 * 4 +
+                         (UP == 2 ? (size_t)(2 * 2 * 4 * 6 * 18 * 8) * 2 + (size_t)(4 * 6 * 2 * 64 * 8) * 2 + 27 * 8 * 4 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv3d_xp8w_kernel<NCH, EPI, PRE, UP, NPW, IN16>;
   static bool attr = false;
@@ -987,7 +1186,8 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (epi == 2 && a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_NONE) epi = 5;        // head without dropout (ensemble members)
   if (epi == 2 && !(a.act == VX_ACT_LRELU && a.drop_mode == VX_DROP_HASH)) return 1;   // other heads: general kernel
   if (epi == 1 && a.act != VX_ACT_LRELU) return 1;
-  const int up = a.up_in ? 1 : 0;
+  // 2: the up-convolution composed into the weights (vx_pack_conv3d_upfused), 1: evaluated per step by the staging waves
+  const int up = a.up_in ? ((a.up_fused && !vx_cfg().s16_no_upcompose) ? 2 : 1) : 0;
   // producer waves: 8 (two per SIMD) for the two-chunk layers, whose staging is the heavy side; 4 for the one-chunk layers:
   // their consumers hold R = 4 image rows + accumulators (134-161 VGPRs) and at 16 waves per workgroup (128-VGPR cap) EVERY
   // one-chunk instance spilled 5-30 VGPRs into its item loop (round-3 verdict; tools/check_spills.sh now fails the build on any
@@ -1010,9 +1210,82 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   XP8W_CASE(1, 5, 0, 0);
   XP8W_CASE(2, 1, 0, 0); XP8W_CASE(2, 1, 1, 0); XP8W_CASE(2, 3, 0, 0); XP8W_CASE(2, 3, 1, 0);
   XP8W_CASE(2, 1, 0, 1); XP8W_CASE(2, 1, 1, 1); XP8W_CASE(2, 3, 0, 1); XP8W_CASE(2, 3, 1, 1);
+  XP8W_CASE(2, 1, 0, 2); XP8W_CASE(2, 1, 1, 2); XP8W_CASE(2, 3, 0, 2); XP8W_CASE(2, 3, 1, 2);
 #undef XP8W_CASE
   if (up) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): no fused up-convolution for this epilogue (act=%d, drop_mode=%d, statistics=%d)",
                   a.act, a.drop_mode, a.stats_partial ? 1 : 0);
   if (a.pool_out) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): no pooled output for this epilogue");
   return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Composed up-convolution (vx_conv3d_args.up_fused): W_eff[class (pz, py)][coarse tap (czi, cyi, cxi)][ci][(dx, co)] =
+// sum over the 3x3x3 taps (kz, ky, kx) that land on that coarse voxel for this output parity of
+// sum_cu W1[co][cu][kz][ky][kx] U[ci][cu][sub-position of the fine voxel], in float64; split into fp16 (hi, lo 2^11) in the
+// A-fragment order of v_mfma_f32_16x16x32_f16: [class][step][hi | lo][lane (g 16 + m)][8 halves = channels 8 oct + j of octet
+// o = 4 step + g].  Behind it the bias table [27 border classes (zc, yc, xc)][8]: b1 + the up bias through the taps that lie
+// INSIDE the volume (a tap outside sees the zero padding of the concatenated tensor).
+namespace {
+__device__ __forceinline__ void up_tap(int parity, int k, int& coarse, int& sub) {
+  const int t = parity + k - 1;                 // fine offset from 2 Q: -1 .. 2
+  coarse = t < 0 ? -1 : t >> 1;                 // floor(t / 2)
+  sub = t - 2 * coarse;
+}
+__global__ void pack_upfused_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ uw,
+                                    const float* __restrict__ ub, float* __restrict__ out) {
+  constexpr int NWT = 4 * 6 * 64 * 8;
+  _Float16* oh = reinterpret_cast<_Float16*>(out);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NWT + 27 * 8; i += gridDim.x * blockDim.x) {
+    if (i < NWT) {
+      const int j = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % 6, cls = i / (512 * 6);
+      const int pz = cls >> 1, py = cls & 1, m = lane & 15, g = lane >> 4, dx = m >> 3, co = m & 7;
+      const int o = 4 * s + g, oct = o & 1, cxi = (o >> 1) % 3, cyi = (o / 6) & 1, czi = o / 12, ci = oct * 8 + j;
+      double acc = 0.0;
+      for (int kz = 0; kz < 3; ++kz) {
+        int cz, sz; up_tap(pz, kz, cz, sz);
+        if (cz + 1 - pz != czi) continue;
+        for (int ky = 0; ky < 3; ++ky) {
+          int cy, sy; up_tap(py, ky, cy, sy);
+          if (cy + 1 - py != cyi) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            int cx, sx; up_tap(dx, kx, cx, sx);
+            if (cx + 1 != cxi) continue;
+            for (int cu = 0; cu < 8; ++cu)
+              acc += (double)w1[(co * 16 + cu) * 27 + kz * 9 + ky * 3 + kx] * (double)uw[(ci * 8 + cu) * 8 + sz * 4 + sy * 2 + sx];
+          }
+        }
+      }
+      const double c = fmin(fmax(acc, -65504.0), 65504.0);
+      const _Float16 h = (_Float16)(float)c;
+      const _Float16 l = (_Float16)(float)((acc - (double)(float)h) * 2048.0);
+      oh[(((cls * 6 + s) * 2 + 0) * 64 + lane) * 8 + j] = h;
+      oh[(((cls * 6 + s) * 2 + 1) * 64 + lane) * 8 + j] = l;
+    } else {
+      const int t = i - NWT, co = t & 7, cls = t >> 3, xc = cls % 3, yc = (cls / 3) % 3, zc = cls / 9;
+      double acc = (double)b1[co];
+      for (int kz = 0; kz < 3; ++kz) {
+        if ((zc == 0 && kz == 0) || (zc == 2 && kz == 2)) continue;
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((yc == 0 && ky == 0) || (yc == 2 && ky == 2)) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            if ((xc == 0 && kx == 0) || (xc == 2 && kx == 2)) continue;
+            for (int cu = 0; cu < 8; ++cu) acc += (double)w1[(co * 16 + cu) * 27 + kz * 9 + ky * 3 + kx] * (double)ub[cu];
+          }
+        }
+      }
+      out[NWT + t] = (float)acc;              // floats behind the 2 NWT halves (= NWT floats) of the weights
+    }
+  }
+}
+}  // namespace
+
+extern "C" int64_t vx_conv3d_upfused_packed_floats(void) { return 4 * 6 * 64 * 8 + 27 * 8 + 8; }   // (+ 8: 16-byte multiple)
+
+extern "C" int vx_pack_conv3d_upfused(const float* w1_torch, const float* b1, const float* up_w_torch, const float* up_b,
+                                      float* packed, vx_stream_t stream) {
+  if (!w1_torch || !b1 || !up_w_torch || !up_b || !packed) VX_FAIL(VX_E_NULL, "vx_pack_conv3d_upfused: null pointer");
+  if (!vx_aligned16(packed)) VX_FAIL(VX_E_ALIGN, "vx_pack_conv3d_upfused: packed must be 16-byte aligned");
+  hipLaunchKernelGGL(pack_upfused_kernel, dim3(48), dim3(256), 0, (hipStream_t)stream, w1_torch, b1, up_w_torch, up_b, packed);
+  VX_CHECK_LAUNCH("vx_pack_conv3d_upfused");
+  return VX_OK;
 }

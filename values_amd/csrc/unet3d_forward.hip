@@ -156,7 +156,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
                   const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0,
                   const float* up_in = nullptr, int up_idx = 0, int up_pitch = 0) {
     vx_conv3d_args a = {};
-    if (up_in) { a.up_in = up_in; a.up_w = w->up_w[up_idx]; a.up_b = w->up_b[up_idx]; a.up_pitch = up_pitch; }
+    if (up_in) {
+      a.up_in = up_in; a.up_w = w->up_w[up_idx]; a.up_b = w->up_b[up_idx]; a.up_pitch = up_pitch;
+      a.up_fused = w->up_fused;      // (nullable) the up-convolution composed into expand_1_1's weights; vx_config.s16_no_upcompose
+    }
     a.head_out = nullptr; a.head_w = nullptr; a.head_b = nullptr; a.head_dst = nullptr; a.head_flip = nullptr; a.head_C = 0;
     if (fuse_head && wi == 17) {   // expand_1_2: the final 1x1x1 conv rides in its epilogue, B_0 is never stored
       a.head_out = r->logits; a.head_w = w->final_w; a.head_b = w->final_b; a.head_C = NC;

@@ -142,6 +142,15 @@ class UNet3D(nn.Module):
             keep += [packed, b, wt]
             w.up_w[i] = packed.data_ptr()
             w.up_b[i] = b.data_ptr()
+        # the level-0 up-convolution composed into expand_1_1's weights (vx_conv3d_args.up_fused): F = 8 networks on the
+        # split-fp16 family (the z-column kernel that takes it)
+        if self.initial_filter_size == 8 and _lib.get_config().conv_fp32 == 0:
+            uf = torch.empty(lib.vx_conv3d_upfused_packed_floats(), dtype=torch.float32, device=device)
+            _lib.check(lib.vx_pack_conv3d_upfused(_lib.ptr(sd["expand_1_1.0.weight"]), _lib.ptr(sd["expand_1_1.0.bias"]),
+                                                  _lib.ptr(sd["upscale2.weight"]), _lib.ptr(sd["upscale2.bias"]), _lib.ptr(uf), st),
+                       "vx_pack_conv3d_upfused")
+            keep.append(uf)
+            w.up_fused = uf.data_ptr()
         fw, fb = self._head_params(sd)
         keep += [fw, fb]
         w.final_w = fw.data_ptr()

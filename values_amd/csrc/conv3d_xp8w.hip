@@ -693,6 +693,19 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       }
       eoff[r] = (unsigned)(ovox * 8 + oc);
     }
+    // Round 4: ONE hash round per item serves the wave's R rows.  A row of 32 voxels x 8 channels is 8 keep-words (32 bits
+    // each: 4 voxels); lane i computes word i & 7 of row i >> 3, a row's lanes fetch theirs with ds_bpermute (1 instruction
+    // instead of a hash per row: the staging waves have shared theirs since round 3).  Word of (row r, lane) =
+    // ((voxel of the row's first element) >> 2) + (m >> 1); bit offset within it (lx & 3) * 8 + oc.  Same bits as
+    // vx_drop_bits4(key, element) per row; +0.3 % end to end (same box, twice).
+    unsigned hword_l;
+    {
+      const int rr_ = (lane >> 3) < R ? (lane >> 3) : 0;
+      const int tz_ = lz + (POOLM ? (rr_ >> 1) : 0), ty_ = ly0 + (POOLM ? (rr_ & 1) : rr_);
+      hword_l = (unsigned)((((tz_ * a.H + ty_) * a.W) >> 2) + (lane & 7));
+    }
+    const int hbp = 4 * (m >> 1);                                    // ds_bpermute byte address of this lane's word in row 0
+    const unsigned hsh = (unsigned)((lx & 3) * 8 + oc);
     const int out_voxf = a.out_xblk ? 16 : a.out_pitch;
     const size_t out_sample = (size_t)a.D * a.H * a.W * out_voxf;
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + oc);
@@ -936,6 +949,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       const unsigned osoff = a.out_xblk ? (unsigned)((((k * TZ) * a.H + e_ty * 8) * (2 * a.W * 8) + e_tx * 32 * 16) * 4)
                                         : vox0 * (unsigned)a.out_pitch * 4u;
       const unsigned e0 = vox0 * 8u;
+      const uint32_t hw_item = (EPI == 1 || EPI == 2 || EPI == 4) ? vx_mix32(((vox0 >> 2) + hword_l) ^ e_key) : 0u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
 #pragma unroll
@@ -950,7 +964,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if constexpr (POOLM) {
           // the block's dropout (applied after the InstanceNorm that is not known yet): maximum over the KEPT raw values
           uint32_t bits = 0xFu;
-          if (a.drop_mode == VX_DROP_HASH) bits = vx_drop_bits4(e_key, e0 + eoff[r]);
+          if (a.drop_mode == VX_DROP_HASH) bits = ((uint32_t)__builtin_amdgcn_ds_bpermute(hbp + 32 * r, (int)hw_item) >> hsh) & 0xFu;
           pl_any |= ~bits & 0xFu;
 #pragma unroll
           for (int j = 0; j < 4; ++j) pl_max[j] = fmaxf(pl_max[j], ((bits >> j) & 1u) ? v[j] : -INFINITY);
@@ -963,7 +977,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (EPI == 1 || EPI == 2) {
-          const uint32_t bits = vx_drop_bits4(e_key, e0 + eoff[r]);
+          const uint32_t bits = ((uint32_t)__builtin_amdgcn_ds_bpermute(hbp + 32 * r, (int)hw_item) >> hsh) & 0xFu;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
         }

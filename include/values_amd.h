@@ -448,6 +448,24 @@ typedef struct vx_affine_args {
 } vx_affine_args;
 int vx_affine_gather(const vx_affine_args* a, vx_stream_t stream);
 
+/* The SUM fusion of a HighResolutionModule output (hrnet_module.py:316-333: y = f_i0(x_0); y = y + f_ij(x_j) for j = 1 ..;
+ * relu) as ONE pass: out = act(T_0 + T_1 + ... ) added in that order, T_j = scale_j * G_j(x_j) + shift_j with G_j the
+ * identity (H, W == OH, OW) or the bilinear upsampling of vx_affine_gather, scale_j / shift_j nullable together (the
+ * identity term x_i).  Bit-identical to nterms chained vx_affine_gather passes (the same expressions in the same order); the
+ * chain re-read and re-wrote the full-resolution accumulator once per term. */
+typedef struct vx_fuse_term {
+  const float* x; int32_t x_pitch, H, W;
+  const float* scale; const float* shift;   /* nullable together; [G][C] rows when group_images > 0 */
+} vx_fuse_term;
+typedef struct vx_fuse_args {
+  vx_fuse_term term[4]; int32_t nterms;     /* 1 .. 4 */
+  float* out; int32_t out_pitch;
+  int32_t N, OH, OW, C;
+  int32_t act;                              /* VX_ACT_NONE | VX_ACT_RELU, applied to the sum */
+  int32_t group_images;
+} vx_fuse_args;
+int vx_fuse_sum(const vx_fuse_args* a, vx_stream_t stream);
+
 /* Final upsample of the class logits to the input size (hrnet_module.py:667-669) into the reference's NCHW layout:
  * image n -> slot dst[n] (nullable) of out [slots][C][OH][OW]; flip[n] bit 0 un-flips a HorizontalFlip TTA view
  * (test_2D.py:304-309), bit 1 a VerticalFlip one (8-view extension, BASELINE config 4). */

@@ -402,6 +402,23 @@ def _lib_mod():
     return _lib
 
 
+def test_multi_term_fusion_pass_gives_the_bits_of_the_term_by_term_chain(monkeypatch):
+    """vx_fuse_sum (round 4): all terms of a HighResolutionModule output (hrnet_module.py:316-333) summed in ONE pass, in the
+    reference's order, against the chain of vx_affine_gather passes it replaces -- bit for bit, W18 widths (padded channels,
+    4 branches, upsampled and strided terms), batched view groups included."""
+    from values_amd.predict2d import predict_logits_2d, tta_views_8
+    m, _ = _w18_full()
+    x = torch.from_numpy(formula_tensor((2, 3, 128, 192), tag=188, scale=1.5)).float().cuda()
+    views, hf, vf = tta_views_8(x, x * 1.01 + 0.02)
+    a = m(x)
+    av = predict_logits_2d([m], views[:4], tta=True, hflip_views=hf[:4], vflip_views=vf[:4])
+    monkeypatch.setenv("VX_HRNET_NO_MULTIFUSE", "1")
+    b = m(x)
+    bv = predict_logits_2d([m], views[:4], tta=True, hflip_views=hf[:4], vflip_views=vf[:4])
+    assert torch.equal(a, b) and torch.equal(av, bv)
+    assert torch.isfinite(a).all()
+
+
 def test_graphed_predictor_2d_replays_the_eager_bits():
     """GraphedPredictor2D: predict_logits_2d + process_output_2d captured into one hipGraph (branches on side streams
     inside the capture) -- the replay gives the eager path's bits, for new inputs too; wrong shapes are refused."""

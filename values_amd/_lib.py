@@ -71,6 +71,15 @@ class AffineArgs(C.Structure):
                 ("group_images", _i32)]
 
 
+class FuseTerm(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i32), ("H", _i32), ("W", _i32), ("scale", _p), ("shift", _p)]
+
+
+class FuseArgs(C.Structure):
+    _fields_ = [("term", FuseTerm * 4), ("nterms", _i32), ("out", _p), ("out_pitch", _i32),
+                ("N", _i32), ("OH", _i32), ("OW", _i32), ("C", _i32), ("act", _i32), ("group_images", _i32)]
+
+
 class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
@@ -143,6 +152,7 @@ SIGNATURES = {
     "vx_softmax_accumulate": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vx_aleatoric_sample": (_i, [_p, _p, _u32, _i, _i, _i, _i64, _p, _p, _p]),
     "vx_colorize_u8": (_i, [_p, _p, _i64, _p, _i, _p, _p]),
+    "vx_fuse_sum": (_i, [C.POINTER(FuseArgs), _p]),
     "vx_tta_views_2d": (_i, [_p, _i, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, _i, _i, _i, _i,
                              C.POINTER(C.c_int32), _p, _p]),
     "vx_select_workspace_bytes": (_i64, []),

@@ -160,6 +160,79 @@ extern "C" int vx_affine_gather(const vx_affine_args* ap, vx_stream_t stream) {
   return VX_OK;
 }
 
+// vx_fuse_sum: the terms of a SUM fusion in one pass (see the header); every term is evaluated with affine_gather_kernel's
+// expressions, the sum runs in term order -- the bits of the chained passes
+template <int NT>
+__global__ __launch_bounds__(256) void fuse_sum_kernel(vx_fuse_args a, int64_t total) {
+  const int C4 = a.C / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int c = (int)(r % C4) * 4; r /= C4;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH); r /= a.OH;
+    const int n = (int)r;
+    const size_t row = a.group_images > 0 ? (size_t)(n / a.group_images) * a.C : 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const vx_fuse_term& tm = a.term[t];
+      f32x4 v;
+      if (tm.H != a.OH || tm.W != a.OW) {
+        const float ry = (float)tm.H / (float)a.OH, rx = (float)tm.W / (float)a.OW;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bil_coord(oy, tm.H, ry, y0, y1, ly);
+        bil_coord(ox, tm.W, rx, x0, x1, lx);
+        const float* base = tm.x + (size_t)n * tm.H * tm.W * tm.x_pitch + c;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * tm.W + x0) * tm.x_pitch);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * tm.W + x1) * tm.x_pitch);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * tm.W + x0) * tm.x_pitch);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * tm.W + x1) * tm.x_pitch);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      } else {
+        v = *reinterpret_cast<const f32x4*>(tm.x + (((size_t)n * a.OH + oy) * a.OW + ox) * tm.x_pitch + c);
+      }
+      if (tm.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(tm.scale + row + c), sh = *reinterpret_cast<const f32x4*>(tm.shift + row + c);
+        v = v * sc + sh;
+      }
+      acc = t == 0 ? v : acc + v;
+    }
+    if (a.act == VX_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * a.out_pitch + c) = acc;
+  }
+}
+
+extern "C" int vx_fuse_sum(const vx_fuse_args* ap, vx_stream_t stream) {
+  if (!ap) VX_FAIL(VX_E_NULL, "vx_fuse_sum: null args");
+  const vx_fuse_args& a = *ap;
+  if (a.nterms < 1 || a.nterms > 4) VX_FAIL(VX_E_SHAPE, "vx_fuse_sum: 1 .. 4 terms, got %d", a.nterms);
+  if (!a.out || a.N <= 0 || a.OH <= 0 || a.OW <= 0 || a.C <= 0 || a.C % 4 || a.out_pitch % 4 || a.out_pitch < a.C)
+    VX_FAIL(VX_E_SHAPE, "vx_fuse_sum: bad output shape (C and the pitch are multiples of 4 floats)");
+  if (a.act != VX_ACT_NONE && a.act != VX_ACT_RELU) VX_FAIL(VX_E_DTYPE, "vx_fuse_sum: act must be none or relu");
+  for (int t = 0; t < a.nterms; ++t) {
+    const vx_fuse_term& tm = a.term[t];
+    if (!tm.x || tm.H <= 0 || tm.W <= 0 || tm.x_pitch % 4 || tm.x_pitch < a.C) VX_FAIL(VX_E_SHAPE, "vx_fuse_sum: term %d", t);
+    if ((tm.scale == nullptr) != (tm.shift == nullptr)) VX_FAIL(VX_E_NULL, "vx_fuse_sum: scale / shift of term %d must come together", t);
+  }
+  const int64_t total = (int64_t)a.N * a.OH * a.OW * (a.C / 4);
+  int64_t nb = (total + 255) / 256;
+  if (nb > (1 << 20)) nb = 1 << 20;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a.nterms) {
+    case 1: hipLaunchKernelGGL(fuse_sum_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
+    case 2: hipLaunchKernelGGL(fuse_sum_kernel<2>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
+    case 3: hipLaunchKernelGGL(fuse_sum_kernel<3>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
+    default: hipLaunchKernelGGL(fuse_sum_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
+  }
+  VX_CHECK_LAUNCH("vx_fuse_sum");
+  return VX_OK;
+}
+
 __global__ __launch_bounds__(256) void bilinear_nchw_kernel(const float* __restrict__ x, int x_pitch, int N, int H, int W,
                                                             int C, int OH, int OW, float* __restrict__ out,
                                                             const int32_t* __restrict__ dst, const int32_t* __restrict__ flip) {

@@ -512,7 +512,28 @@ class HighResolutionNet(nn.Module):
             return xs
         outs = []
         nb = mod.num_branches
+        multifuse = nb <= 4 and not os.environ.get("VX_HRNET_NO_MULTIFUSE")
         for i in range(len(mod.fuse_layers)):
+            if multifuse:
+                # Round 4: all terms of output i in ONE pass (vx_fuse_sum) -- the term-by-term chain below re-read and
+                # re-wrote the accumulator once per term (three passes over the full-resolution branch per stage-4 module)
+                terms = []
+                for j in range(nb):
+                    if j == i:
+                        terms.append((xs[j], None, None))
+                    elif j > i:
+                        q = f"{p}.fuse_layers.{i}.{j}"
+                        r = self._conv_bn(xs[j], q + ".0", q + ".1")
+                        terms.append(r)
+                    else:
+                        t = xs[j]
+                        r = None
+                        for k in range(i - j):
+                            q = f"{p}.fuse_layers.{i}.{j}.{k}"
+                            r = self._conv_bn(t, q + ".0", q + ".1") if r is None else self._conv_bn_after(r, q + ".0", q + ".1")
+                        terms.append(r)
+                outs.append(self._fuse(terms, xs[i]))
+                continue
             y: Optional[_Act] = None
             for j in range(nb):
                 last = j == nb - 1
@@ -541,6 +562,26 @@ class HighResolutionNet(nn.Module):
                     y = self._aff(term[0], term[1], term[2], relu=last, add=y, out=None if fresh else y, size=term[3])
             outs.append(y)
         return outs
+
+    def _fuse(self, terms, like: _Act) -> _Act:
+        """relu(T_0 + T_1 + ...) in term order, T = (raw, scale, shift) of a conv + BatchNorm (upsampled to `like`'s size where
+        it is smaller) or (x, None, None) for the identity term: vx_fuse_sum, one pass"""
+        lib = _lib.load()
+        out = _Act(torch.empty((like.N, like.H, like.W, like.C), dtype=torch.float32, device=like.t.device), like.C)
+        a = _lib.FuseArgs()
+        a.nterms = len(terms)
+        for k, (x, sc, sh) in enumerate(terms):
+            a.term[k].x = x.t.data_ptr(); a.term[k].x_pitch = x.pitch; a.term[k].H = x.H; a.term[k].W = x.W
+            if sc is not None:
+                a.term[k].scale = sc.data_ptr(); a.term[k].shift = sh.data_ptr()
+        a.out = out.t.data_ptr(); a.out_pitch = out.pitch
+        a.N, a.OH, a.OW, a.C = like.N, like.H, like.W, like.C
+        a.act = _lib.VX_ACT_RELU
+        if self._groups > 1:
+            a.group_images = like.N // self._groups
+        _lib.check(lib.vx_fuse_sum(C.byref(a), self._st), "vx_fuse_sum")
+        self._hold.append(out.t)
+        return out
 
     def _transition(self, ys: List[_Act], tname: str, layers) -> List[_Act]:
         n_prev = len(ys)

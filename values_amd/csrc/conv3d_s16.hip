@@ -824,6 +824,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
 #endif
 }
 
+// The instances of this file compile in THREE translation units (the Makefile builds conv3d_s16_cb8.o (a two-line source
+// defining S16_PART = 1) and conv3d_s16_nt2.o (S16_PART = 2)): the one-row-tile 16-channel-chunk instances + everything
+// host-side here, the 8-channel-chunk instances (x-pair included) and the two-row-tile ones there -- as one unit the file was
+// the longest compile of the library by a factor of three.
+#ifndef S16_PART
+#define S16_PART 0
+#endif
+#if S16_PART == 0
 // ---------------------------------------------------------------------------------------------
 // weight packing: torch (Cout, Cin, 3,3,3) fp32 -> [rowgroup][chunk][step][nt][hi | lo][lane 64][8 halves]
 __global__ void pack_conv3d_k3_s16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cin, int Cout, int CB,
@@ -883,6 +891,8 @@ int vx_pack_conv3d_k3_s16(const float* w_torch, float* w_packed, int Cin, int Co
   VX_CHECK_LAUNCH("vx_pack_conv3d_k3(s16)");
   return VX_OK;
 }
+
+#endif   // S16_PART == 0
 
 template <int CB, int NT, int TX, int TY, int TZ, int NW, int XP, int DB = 0, int EPI = 3>
 static int launch_s16(const ConvSArgs& ka_in, hipStream_t s) {
@@ -977,6 +987,19 @@ static int dispatch_s16(const ConvSArgs& ka, int tx, hipStream_t s) {
   return launch_s16<CB, NT, 4, 4, 4, 4, XP>(ka, s);
 }
 
+#if S16_PART == 2
+// the 16-channel-chunk instances with two row tiles per wave (this translation unit: conv3d_s16_nt2.o)
+int vx_conv3d_k3_s16_nt2(const ConvSArgs& ka, int tx, hipStream_t s) { return dispatch_s16<16, 2, 0>(ka, tx, s); }
+#elif S16_PART == 1
+// the 8-channel-chunk half of the dispatch (this translation unit: conv3d_s16_cb8.o)
+int vx_conv3d_k3_s16_cb8(const ConvSArgs& ka, int nt, int xp, int tx, hipStream_t s) {
+  if (xp) return dispatch_s16<8, 1, 1>(ka, tx, s);
+  if (nt == 1) return dispatch_s16<8, 1, 0>(ka, tx, s);
+  return dispatch_s16<8, 2, 0>(ka, tx, s);
+}
+#else
+int vx_conv3d_k3_s16_cb8(const ConvSArgs& ka, int nt, int xp, int tx, hipStream_t s);
+int vx_conv3d_k3_s16_nt2(const ConvSArgs& ka, int tx, hipStream_t s);
 // tiles = those of conv3d_mfma.hip's tile_config (tx columns per row: 16 / 8 / 4 by W, or by W / 2 for x-pair)
 // Tile of a layer: tx columns per row (16 / 8 / 4 by W, or by W / 2 for x-pair) as in conv3d_mfma.hip; large layers
 // (H >= 32) take 16 x 8 x 4 tiles = 4 column tiles per wave: the halo read per output voxel drops from 2.5x to 2.1x
@@ -1022,9 +1045,8 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s) {
   if (const char* e = getenv("VX_CONV_DBG_PTR")) ka.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   ka.ty8 = ty8;
-  if (c.XP) return dispatch_s16<8, 1, 1>(ka, tx, s);
   if (c.CB == 16 && c.NT == 1) return dispatch_s16<16, 1, 0>(ka, tx, s);
-  if (c.CB == 16 && c.NT == 2) return dispatch_s16<16, 2, 0>(ka, tx, s);
-  if (c.CB == 8 && c.NT == 1) return dispatch_s16<8, 1, 0>(ka, tx, s);
-  return dispatch_s16<8, 2, 0>(ka, tx, s);
+  if (c.CB == 16 && c.NT == 2) return vx_conv3d_k3_s16_nt2(ka, tx, s);
+  return vx_conv3d_k3_s16_cb8(ka, c.NT, c.XP, tx, s);
 }
+#endif   // S16_PART

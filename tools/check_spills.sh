@@ -4,6 +4,11 @@
 # Run by __graft_entry__.build() after make.  `tools/check_spills.sh -v` prints the whole table.
 set -e
 cd "$(dirname "$0")/../values_amd/csrc"
+# an object without its report (objects copied from elsewhere, reports cleaned): rebuild that object
+for src in *.hip; do
+  base="${src%.hip}"
+  if [ -f "$base.o" ] && [ ! -f "$base.rsrc" ]; then make -B "$base.o" > /dev/null; fi
+done
 ls *.rsrc >/dev/null 2>&1 || { echo "check_spills: no .rsrc reports (run make first)"; exit 1; }
 if [ "$1" = "-v" ]; then python3 ../../tools/rsrc_table.py *.rsrc; fi
 python3 ../../tools/rsrc_table.py --fail *.rsrc | grep "SCRATCH" || true

@@ -165,6 +165,29 @@ def test_no_gpu_fails_loudly():
         calculate_uncertainty(torch.zeros(2, 2, 4))
     with pytest.raises(_lib.VxError):
         UNet3D(num_classes=2)(torch.zeros(1, 1, 16, 16, 16))
+    # round 4's entry points: the device-built TTA views (no host fallback: the host restatement is a different function)
+    from values_amd.data import tta_views_2d_device, tta_views_8_device
+    with pytest.raises(_lib.VxError):
+        tta_views_2d_device(torch.zeros((4, 6, 3), dtype=torch.uint8), [0.5] * 3, [0.2] * 3)
+    with pytest.raises(_lib.VxError):
+        tta_views_8_device(torch.zeros(1, 3, 4, 6), torch.zeros(1, 3, 4, 6))
+
+
+def test_tta_view_codes_and_nhwc_views_container():
+    """host logic of the device TTA path: the view codes of vx_tta_views_2d for the reference's four views and config C4's
+    eight, the transform names test_2D.py un-flips by, the NhwcViews container's checks"""
+    import torch
+    from values_amd.data import TTA_2D_TRANSFORMS, TTA_2D_VIEW_CODES, TTA_8_VIEW_CODES, hflip_flags
+    from values_amd.predict2d import NhwcViews
+    assert TTA_2D_VIEW_CODES == [0, 1, 4, 1 | 4 | 16]
+    assert [bool(c & 1) for c in TTA_2D_VIEW_CODES] == hflip_flags(TTA_2D_TRANSFORMS)
+    assert [c & 3 for c in TTA_8_VIEW_CODES] == [0, 1, 2, 3, 0, 1, 2, 3] and all((c & 4) for c in TTA_8_VIEW_CODES[4:])
+    v = NhwcViews(torch.zeros(4, 2, 5, 6, 4), [False, True, False, True])
+    assert v.vflip == [False] * 4 and v.t.is_contiguous()
+    with pytest.raises(ValueError):
+        NhwcViews(torch.zeros(4, 2, 5, 6, 3), [False] * 4)
+    with pytest.raises(ValueError):
+        NhwcViews(torch.zeros(4, 2, 5, 6, 4), [False] * 3)
 
 
 def test_crop_indices_match_reference_fixture():

@@ -287,6 +287,38 @@ def cpu_baseline_leg(state_dict, T=10, budget_s=25.0):
                                     "sample": f"{n32} float32 no-grad passes ({t32:.3f} s/pass) + reduction ({t_red32:.2f} s)"}}
 
 
+def cpu_baseline_leg_2d(extra, state_dict, H, W, views=8, budget_s=25.0):
+    """C4's CPU baseline (kind 'port'): the oracle's HRNet restatement (oracle/hrnet_oracle.py, training-mode BatchNorm as the
+    reference runs it, float32 as test_2D.py does) on a BOUNDED sample -- ONE view of ONE image at the bench's size; an image
+    is `views` such forwards + the softmax / entropy reduction (timed on that one view's worth and scaled)."""
+    import numpy as np
+    import torch
+    from oracle import uncertainty_oracle as uo
+    from oracle.hrnet_oracle import hrnet_forward
+    ncpu = os.cpu_count() or 1
+    cores = min(32, ncpu)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().float() for k, v in state_dict.items()}
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn((1, 3, H, W), generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        lg = hrnet_forward(extra, sd, x)
+        t_view = time.perf_counter() - t0
+        if t_view < budget_s / 3:          # a second, warm pass where the budget allows
+            t0 = time.perf_counter()
+            lg = hrnet_forward(extra, sd, x)
+            t_view = time.perf_counter() - t0
+    sm = torch.softmax(lg, 1).numpy()                        # (1, C, H, W)
+    t0 = time.perf_counter()
+    uo.calculate_uncertainty(np.concatenate([sm, sm], 0))    # two views' worth of the reference's Python-loop reduction
+    t_red = (time.perf_counter() - t0) * views / 2.0
+    return {"value": round(1.0 / (views * t_view + t_red), 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"one of the {views} views of one {W}x{H} image through the float32 PyTorch-CPU restatement of HighResolutionNet "
+                      f"({t_view:.2f} s/view) + the reduction over two views scaled to {views} ({t_red:.2f} s); torch {torch.__version__} "
+                      f"CPU, {cores} of {ncpu} host threads"}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def kfd_gpu_count():
     """GPUs of this node as the kernel driver lists them: /sys/class/kfd/kfd/topology/nodes/*/properties, a node with
@@ -753,6 +785,9 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
                                      nhwc=True)
         # HBM-side bytes per launch (PMC passes around `--config C4 --roofline-only`: the same single-stream launches)
         roof["traffic"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg_2d(extra, model.state_dict(), H, W)
     line = {"metric": f"uncertainty-images/sec (HRNet-W{args.hrnet_width}, 1024x512, 8-view TTA)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -762,7 +797,7 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
                        "batching": "the 8 views of a step travel as one batch of 8 B images with BatchNorm statistics per view",
                        "launch": "one hipGraph replay per step (GraphedPredictor2D)" if gp is not None else "eager launches",
                        "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": cpu}
     line.update(summarise(times, B * world * args.steps, args.steps))
     if eager is not None:
         line["eager"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"]}

@@ -217,10 +217,10 @@ def test_product_never_imports_oracle():
                 if fn.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
                     txt = open(os.path.join(dirpath, fn)).read()
                     assert "import oracle" not in txt and "from oracle" not in txt, (sub, fn)
-    bench = open(os.path.join(ROOT, "bench.py")).read()          # bench.py: inside cpu_baseline_leg only
-    leg = bench.index("def cpu_baseline_leg")
-    nxt = bench.index("\ndef ", leg + 1)
-    outside = bench[:leg] + bench[nxt:]
+    bench = open(os.path.join(ROOT, "bench.py")).read()          # bench.py: inside the cpu_baseline legs only (C2's and C4's)
+    import re
+    outside = re.sub(r"\ndef cpu_baseline_leg\w*\(.*?(?=\n(?:def |# -{20}))", "\n", bench, flags=re.S)
+    assert outside.count("def cpu_baseline_leg") == 0 and len(outside) < len(bench)
     assert "from oracle" not in outside and "import oracle" not in outside
 
 

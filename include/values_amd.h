@@ -252,8 +252,10 @@ typedef struct vx_conv3d_args {
 int64_t vx_conv3d_upfused_packed_floats(void);
 /* w1_torch (8, 16, 3,3,3) + b1 (8): the decoder conv whose input channels [0, 8) are the up half; up_w_torch (16, 8, 2,2,2) +
  * up_b (8): the transposed conv (torch layouts, device pointers) -> packed [4 classes][6 K-steps][hi | lo][64 lanes][8 halves]
- * + bias table [27][8].  VX_E_SHAPE (reported through the returned code of the NEXT synchronising call: the check runs on the
- * device) never happens; a composed weight beyond the fp16 range is clamped like vx_pack_conv3d_k3 clamps. */
+ * + bias table [27][8] (vx_conv3d_upfused_packed_floats() floats, 16-byte aligned).  The composition runs on the device in
+ * float64; a composed weight beyond the fp16 range has its hi part clamped to +-65504 like vx_pack_conv3d_k3's, i.e. the
+ * consuming conv then produces inf / NaN loudly.  The B operands of the composed products are the COARSE tensor's values:
+ * its producer's range_flag is what guards them (the up values themselves are never formed). */
 int vx_pack_conv3d_upfused(const float* w1_torch, const float* b1, const float* up_w_torch, const float* up_b, float* packed,
                            vx_stream_t stream);
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */

@@ -90,8 +90,8 @@ typedef struct vx_config {
   int32_t s16_no_upsplit;  /* expand_2_2 stores plain floats and the fused up-convolution splits them per step (round 2) */
   int32_t s16_no_presplit; /* MC-dropout batches: contr_1_2 normalises the shared first-layer tensor on load for every sample
                               instead of reading the once-per-volume output of vx_prenorm_split */
-  int32_t s16_no_poolfuse2; /* levels 1-3: a separate normalise + pool pass over contr_l_2's output instead of the window maxima
-                              from its epilogue + vx_pool_finish (round 4) */
+  int32_t s16_no_poolfin;  /* a separate vx_pool_finish pass over contr_1_2's window maxima instead of contr_2_1 finishing them while it
+                              stages its tiles (round 4, vx_conv3d_args.in_pool_flags) */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
   int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of
@@ -248,6 +248,12 @@ typedef struct vx_conv3d_args {
    * outside the volume sees the zero padding of the concatenated tensor, not the bias).  Same function of the inputs;
    * weights composed in float64 at pack time, so results differ from the two-stage evaluation by float32 rounding only. */
   const float* up_fused;
+  /* POOL-FINISH on load (round 4; only where vx_conv3d_k3_poolfin_ok(Cin, Cout)): `in` is the pool_out of the previous block's
+   * second conv -- window maxima of RAW values [N][D][H][W][8] -- and in_pool_flags its any-dropped words [N][D][H][W][2];
+   * in_mean / in_rstd are that block's statistics ([N][8]) and in_drop_mode says whether the dropout's factor 2 applies.  The conv
+   * evaluates vx_pool_finish's arithmetic (same expressions, same order) while it stages its tiles: the pooled tensor is never
+   * written.  in_repeat / in_split / in_drop_seed are not used. */
+  const uint32_t* in_pool_flags;
 } vx_conv3d_args;
 int64_t vx_conv3d_upfused_packed_floats(void);
 /* w1_torch (8, 16, 3,3,3) + b1 (8): the decoder conv whose input channels [0, 8) are the up half; up_w_torch (16, 8, 2,2,2) +
@@ -262,6 +268,7 @@ int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
 int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
 int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_split (vx_prenorm_split's output) for this layer */
+int vx_conv3d_k3_poolfin_ok(int Cin, int Cout);                       /* 1 if vx_conv3d_k3 takes in_pool_flags for this layer */
 /* pooled[c] = any_dropped ? max(s f(m), 0) : s f(m) with f(m) = LeakyReLU((m - mean[n][c]) * rstd[n][c]), s = 2 with
  * dropout (drop_scale2 != 0) else 1: the MaxPool3d(2, 2) of Dropout(LeakyReLU(InstanceNorm(x))) from the window maxima and
  * flags vx_conv3d_k3 left in pool_out / pool_flags (bit-identical to pooling the normalised tensor: f is monotone). */

@@ -967,6 +967,36 @@ def test_conv3d_xp8_pooled_output_matches_oracle(shape, pmode, rep, vxcfg):
     if pmode:
         frac = (pfl.cpu() & 0xF).float().ne(0).float().mean().item()
         assert frac > 0.9                                            # 8 elements per window and channel: a drop almost surely
+    # --- Round 4: the NEXT block's first conv (8 -> 16 on the pooled grid) finishing the window maxima itself while it stages
+    # its tiles (vx_conv3d_args.in_pool_flags) = vx_pool_finish + the plain conv, bit for bit: output and statistics
+    assert lib.vx_conv3d_k3_poolfin_ok(8, 16) == 1 and lib.vx_conv3d_k3_poolfin_ok(8, 8) == 0 and lib.vx_conv3d_k3_poolfin_ok(16, 16) == 0
+    dp, hp, wq = d // 2, h // 2, w // 2
+    w2 = torch.from_numpy(formula_tensor((16, 8, 3, 3, 3), 344, scale=(1.0 / (27 * 8)) ** 0.5)).float().contiguous().to(dev())
+    b2 = torch.from_numpy(formula_tensor((16,), 345, scale=0.2)).float().to(dev())
+    wp2 = torch.empty(lib.vx_conv3d_k3_packed_floats(8, 16), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(w2), _lib.ptr(wp2), 8, 16, _lib.stream_ptr()), "pack")
+    nt2 = lib.vx_conv3d_k3_tiles_for(dp, hp, wq, 16)
+    dense = pooled[..., :8].contiguous()
+
+    def second(fused):
+        o2 = torch.full((n, dp, hp, wq, 16), -3.0, dtype=torch.float32, device=dev())
+        s2 = torch.zeros((n, nt2, 16, 2), dtype=torch.float32, device=dev())
+        a2 = _lib.ConvArgs()
+        a2.w_family = lib.vx_conv3d_k3_family(8, 16)
+        a2.in_ = (praw if fused else dense).data_ptr(); a2.w_packed = wp2.data_ptr(); a2.bias = b2.data_ptr(); a2.out = o2.data_ptr()
+        a2.in_pitch, a2.out_pitch, a2.out_coff = 8, 16, 0
+        a2.N, a2.D, a2.H, a2.W, a2.Cin, a2.Cout = n, dp, hp, wq, 8, 16
+        a2.stats_partial = s2.data_ptr()
+        if fused:
+            a2.in_mean, a2.in_rstd, a2.in_pool_flags = mean.data_ptr(), rstd.data_ptr(), pfl.data_ptr()
+            a2.in_drop_mode = _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE
+        _lib.check(lib.vx_conv3d_k3(C.byref(a2), _lib.stream_ptr()), "vx_conv3d_k3 (second)")
+        torch.cuda.synchronize()
+        return o2, s2
+    o_sep, s_sep = second(False)
+    o_fus, s_fus = second(True)
+    assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
+    assert torch.isfinite(o_fus).all()
     # refused where the z-column kernel does not run
     vxcfg.set(s16_no_xp8=1)
     with pytest.raises(_lib.VxError):

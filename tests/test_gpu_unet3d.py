@@ -713,7 +713,7 @@ def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():
     assert torch.equal(gd(x2)["logits"], predict_uncertainty([det], x2, n_pred=1)["logits"])
 
 
-@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfuse2=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1)])
+@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfin=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1)])
 def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     """The level-0 data-flow variants behind vx_config: a separate normalise pass for the skip half instead of expand_1_1
     normalising the raw tensor on load (s16_skip_raw=0), no normalise-on-load at all (s16_no_prenorm), the general tile
@@ -737,7 +737,7 @@ def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     # the un-shared first layer (per-sample src / flip: the TTA path) with dropout off
     det = make_model(do_dropout=False)
     a = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
-    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfuse2=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0)     # the defaults
+    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfin=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0)     # the defaults
     b = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
     assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5
 

@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
                 ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p),
                 ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
                 ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32),
-                ("out_split", _i32), ("up_split", _i32), ("up_fused", _p)]
+                ("out_split", _i32), ("up_split", _i32), ("up_fused", _p), ("in_pool_flags", _p)]
 
 
 class NormArgs(C.Structure):
@@ -84,7 +84,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw", "no_head_fusion", "s16_no_upfuse", "s16_no_poolfuse",
-        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfuse2", "c2s_no_wide", "c2s_no_oct")]
+        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -132,6 +132,7 @@ SIGNATURES = {
     "vx_conv3d_k3_upfuse_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_poolfuse_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_presplit_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_poolfin_ok": (_i, [_i, _i]),
     "vx_conv3d_upfused_packed_floats": (_i64, []),
     "vx_pack_conv3d_upfused": (_i, [_p, _p, _p, _p, _p, _p]),
     "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),

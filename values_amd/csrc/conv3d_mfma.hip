@@ -649,6 +649,12 @@ extern "C" int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout) 
   return Cin == 8 && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
+// in_pool_flags: the tile kernel's prologue on a dense 8-channel input (contr_2_1 of the F = 8 networks)
+extern "C" int vx_conv3d_k3_poolfin_ok(int Cin, int Cout) {
+  if (Cin != 8 || Cout <= 0 || Cout % 8) return 0;
+  return conv_config(Cin, Cout).S16 && vx_conv3d_s16_prologue_ok(Cin, Cout) ? 1 : 0;
+}
+
 extern "C" int vx_conv3d_k3_head_fusable(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
   const ConvCfg c = conv_config(Cin, Cout);
@@ -699,6 +705,12 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     if (!vx_aligned16(a.pool_out)) VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: pool_out alignment");
   }
   if (a.in_drop_mode != VX_DROP_NONE && a.in_drop_mode != VX_DROP_HASH) VX_FAIL(VX_E_DTYPE, "vx_conv3d_k3: in_drop_mode %d", a.in_drop_mode);
+  if (a.in_pool_flags) {
+    if (!a.in_mean) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: in_pool_flags goes with in_mean / in_rstd");
+    if (!vx_conv3d_k3_poolfin_ok(a.Cin, a.Cout) || a.in_xblk || a.in_pitch != 8 || a.in_split || a.up_in || a.in_repeat > 1)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: pool-finish on load takes a dense 8-channel tensor of window maxima (see "
+              "vx_conv3d_k3_poolfin_ok): %d -> %d, pitch %d", a.Cin, a.Cout, a.in_pitch);
+  }
   if (a.out && !a.out_xblk && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");
   if (a.in_xblk) {

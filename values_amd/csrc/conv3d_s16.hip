@@ -221,6 +221,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   // LDS (unet3D_module.py:231-237), as conv3d_xp8w.hip does for the full-resolution layers.  Run-time flag: the element
   // index of a piece is (soff + voff) / 4 - biasf because the tensor is dense (in_pitch == Cin), so it costs no table.
   const bool pre = !XP && a.in_mean != nullptr;
+  // pool-finish on load (round 4, vx_conv3d_args.in_pool_flags): the input is the previous block's window maxima of RAW values;
+  // statistics, LeakyReLU, the dropout's 2 and the zero of a dropped element are applied here with vx_pool_finish's expressions
+  // (the separate pass over the pooled tensor and the tensor itself disappear).  One flag word per 16-byte piece: the flags
+  // tensor is the input tensor's image at a quarter of every byte offset (dense 8-channel input).
+  // Only the instances the 8 -> 16 layer of a contract block runs on carry the code (one more buffer load per staged piece).
+  constexpr bool POOLFIN = CB == 8 && XP == 0 && NT == 1 && (EPI == 0 || EPI == 3);
+  const bool prepool = POOLFIN && pre && a.in_pool_flags != nullptr;
+  uint32_t fbuf[POOLFIN ? IN_IT : 1];
   const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
   f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
   unsigned p_bad = 0, p_e0 = 0, p_key = 0;
@@ -236,10 +244,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   // them at once after the barrier kept every wave of the workgroup in the load queue for 2 000 - 3 400 cycles per item
   // (72 KB through the CU's one address path) with the matrix pipe idle -- 15-25 % of the item (tools/stamp_s16.py)
   __amdgpu_buffer_rsrc_t pf_srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t pf_fsrd = pf_srd;
   unsigned pf_bad = 0xFFFFFFFFu, pf_soff = 0;
   auto pf_issue = [&](int it) {
     const unsigned vo = ((pf_bad >> it) & 1u) ? VX_OOB : voff[it];
     ibuf[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pf_srd, (int)vo, (int)pf_soff, 0));
+    if constexpr (POOLFIN)   // (no run-time branch around the load: without flags it is steered out of range)
+      fbuf[it] = __builtin_amdgcn_raw_buffer_load_b32(pf_fsrd, (int)((prepool && !((pf_bad >> it) & 1u)) ? (voff[it] >> 2) : VX_OOB),
+                                                      (int)(pf_soff >> 2), 0);
   };
   auto prefetch = [&](int tile_lin, int chunk, bool have, bool with_w, bool deferred = false) {
     int n, tx, ty, tz;
@@ -259,6 +271,9 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     const unsigned soff = (unsigned)((((tz * TZ) * a.H + ty * TY) * rowf + tx * TXV * voxf + coff) * 4);
     const int n_in = have ? n / in_rep : 0;
     pf_srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n_in * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
+    if (prepool)   // (in_sample and biasf are multiples of 8 floats here: the quarter offsets are exact)
+      pf_fsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in_pool_flags + ((ptrdiff_t)n_in * (ptrdiff_t)in_sample - biasf) / 4), 0, VX_NUMREC,
+                                                  0x00020000);
     pf_bad = bad;
     pf_soff = soff;
     if (!deferred) {
@@ -289,7 +304,20 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     for (int it = 0; it < IN_IT; ++it) {
       if (tid + it * NTH < NHALO * Q) {
         f16x4 hi, lo;
-        if (pre) {
+        if (prepool) {
+          f32x4 v = ibuf[it];
+          const uint32_t fl = fbuf[POOLFIN ? it : 0];
+          const float s2 = a.in_drop_mode == VX_DROP_HASH ? 2.f : 1.f;
+          const bool outside = (p_bad >> it) & 1u;             // zero padding belongs to the pooled, normalised tensor
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = (v[j] - p_mean[j]) * p_rstd[j];
+            float w = fmaxf(t, 0.01f * t) * s2;                // vx_pool_finish: normalise, LeakyReLU, then the dropout's 2
+            if ((fl >> j) & 1u) w = fmaxf(w, 0.f);              // a dropped element contributes 0 to the window
+            v[j] = outside ? 0.f : w;
+          }
+          ibuf[it] = v;
+        } else if (pre) {
           f32x4 v = ibuf[it];
           // dropout's factor 2 rides in the scale: 2 lrelu(t) = lrelu(2 t)
           const f32x4 sc = p_rstd * (a.in_drop_mode == VX_DROP_HASH ? 2.f : 1.f);

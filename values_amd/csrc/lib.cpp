@@ -60,7 +60,7 @@ static void cfg_from_env() {
   g_cfg.s16_generic = env_int("VX_S16_GENERIC", 0);
   g_cfg.s16_no_upcompose = env_int("VX_S16_NO_UPCOMPOSE", 0);
   g_cfg.s16_no_upsplit = env_int("VX_S16_NO_UPSPLIT", 0);
-  g_cfg.s16_no_poolfuse2 = env_int("VX_S16_NO_POOLFUSE2", 0);
+  g_cfg.s16_no_poolfin = env_int("VX_S16_NO_POOLFIN", 0);
   g_cfg.c2s_no_wide = env_int("VX_C2S_NO_WIDE", 0);
   g_cfg.c2s_no_oct = env_int("VX_C2S_NO_OCT", 0);
 }

@@ -151,6 +151,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   int st16_ = 0;                     // reduced-storage mode: 1 around expand_1_1's launch (fp16 output), 2 around expand_1_2's (fp16 input)
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
+  const uint32_t* pf_in_flags_ = nullptr;   // set around the contr_2_1 launch: vx_conv3d_args.in_pool_flags
+  bool poolfin_on_load_ = false;     // contr_2_1 reads contr_1_2's window maxima + flags and finishes them on load
+  const float* poolfin_raw_ = nullptr;
+  const uint32_t* poolfin_flags_ = nullptr;
   auto conv = [&](const float* in, int in_pitch, int wi, float* out, int out_pitch, int out_coff, const Level& L, int Cin,
                   int Cout, int act, int drop_layer, float* stats, int in_xblk, int pre_layer = -1, int pre_rep = 1,
                   const float* pre_mean = nullptr, const float* pre_rstd = nullptr, int out_xblk = 0, int n_samples = 0,
@@ -182,6 +186,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       a.in_drop_mode = dm; a.in_drop_seed = r->seed; a.in_drop_layer = (uint32_t)pre_layer;
       a.in_repeat = pre_rep;
       a.in_split = pre_split_ ? 1 : 0;
+      a.in_pool_flags = pf_in_flags_;
     }
     a.seed_dev = r->seed_dev;
     a.out_f16 = st16_ == 1 ? 1 : 0;
@@ -310,6 +315,12 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       }
     } else if (inorm) {
       ntiles = vx_conv3d_k3_tiles_for(L.D, L.H, L.W, C);
+      if (l == 1 && poolfin_on_load_) {
+        pf_in_flags_ = poolfin_flags_;
+        VX_STEP("poolfin+contr_2_1", conv(poolfin_raw_, C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats, 0, 1, 1, p.mean0,
+                                          p.rstd0));
+        pf_in_flags_ = nullptr;
+      } else
       VX_STEP(kConv[2 * l], conv(p.P[l], C / 2, 2 * l, p.A[l], C, 0, L, C / 2, C, VX_ACT_NONE, -1, p.stats, 0));
       VX_STEP(kFin[2 * l], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
       // contr_l_2 normalises the raw A_l on load (tile kernel prologue) -- or a pass rewrites A_l in place
@@ -343,7 +354,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       uint32_t* pfl = pool_flags_;
       pool_raw_ = nullptr; pool_flags_ = nullptr;
       VX_STEP(kFin[1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean0, p.rstd0, stream));
-      if (praw)
+      // Round 4: contr_2_1 finishes the window maxima itself while it stages its tiles (vx_conv3d_args.in_pool_flags): the pass
+      // over the pooled tensor, its launch and the tensor are gone
+      poolfin_on_load_ = praw && !vx_cfg().s16_no_poolfin && vx_conv3d_k3_poolfin_ok(C, 2 * C);
+      if (poolfin_on_load_) { poolfin_raw_ = praw; poolfin_flags_ = pfl; }
+      else if (praw)
         VX_STEP("poolfin:contr_1_2", vx_pool_finish(praw, pfl, p.mean0, p.rstd0, p.P[1], C, N, p.lv[1].nvox, dm == VX_DROP_HASH, stream));
       else
         VX_STEP("pool:contr_1_2", norm(p.CAT[0], C, nullptr, 0, 0, p.P[1], L, 1, 1, 0, xblk_of(L.W), p.mean0, p.rstd0));

@@ -287,6 +287,46 @@ def cpu_baseline_leg(state_dict, T=10, budget_s=25.0):
                                     "sample": f"{n32} float32 no-grad passes ({t32:.3f} s/pass) + reduction ({t_red32:.2f} s)"}}
 
 
+def cpu_baseline_leg_passes(state_dicts, passes_per_unit, reduce_T, dropout, unit, what, reduce_vox_scale=1, budget_s=20.0):
+    """cpu_baseline of configs C3 / C5 (kind 'port'), bounded like C2's: the oracle's float64 autograd-on forward of ONE 64^3
+    volume (patch) timed over a few passes -- one per entry of state_dicts, cycled -- and scaled to the `passes_per_unit`
+    forwards a unit (volume / image) takes, + the calculate_uncertainty restatement over reduce_T samples of a 64^3 buffer
+    (x reduce_vox_scale for an image of that many 64^3 volumes' worth of voxels).  Returns the cpu_baseline object."""
+    import numpy as np
+    import torch
+    from oracle import uncertainty_oracle as uo
+    from oracle.unet3d_oracle import DROPOUT_ORDER, unet3d_forward
+    ncpu = os.cpu_count() or 1
+    cores = min(8, ncpu)           # the thread count C2's leg finds fastest on the driver's boxes (oversubscription slows ATen's float64 conv3d)
+    torch.set_num_threads(cores)
+    sds = [{k: v.detach().cpu().double().requires_grad_(True) for k, v in sd.items()} for sd in state_dicts]
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn((1, 1, 64, 64, 64), generator=g, dtype=torch.float64)
+    shapes = [(8, 64), (8, 64), (16, 32), (16, 32), (32, 16), (32, 16), (64, 8), (64, 8), (64, 8), (64, 8), (64, 8),
+              (32, 16), (32, 16), (16, 32), (16, 32), (8, 64), (8, 64)]
+    t0 = time.perf_counter()
+    sms, done = [], 0
+    while done < passes_per_unit:
+        masks = None
+        if dropout:
+            masks = {nm: torch.rand((1, c, s_, s_, s_), generator=g) > 0.5 for nm, (c, s_) in zip(DROPOUT_ORDER, shapes)}
+        logits = unet3d_forward(sds[done % len(sds)], x, masks=masks)
+        sms.append(torch.softmax(logits, 1).detach().numpy()[0])
+        done += 1
+        if time.perf_counter() - t0 > budget_s * 0.6 and done >= 2:
+            break
+    t_pass = (time.perf_counter() - t0) / done
+    stack = np.stack((sms * reduce_T)[:reduce_T])
+    t0 = time.perf_counter()
+    uo.calculate_uncertainty(stack)
+    t_red = (time.perf_counter() - t0) * reduce_vox_scale
+    return {"value": round(1.0 / (passes_per_unit * t_pass + t_red), 6), "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"{done} float64 autograd-on forwards of one 64^3 volume ({t_pass:.2f} s/pass) scaled to the {passes_per_unit} "
+                      f"forwards of {what} + the T={reduce_T} entropy/MI reduction ({t_red:.2f} s"
+                      f"{'' if reduce_vox_scale == 1 else ', a 64^3 buffer timed, x' + str(reduce_vox_scale) + ' voxels'}); "
+                      f"torch {torch.__version__} CPU, {cores} of {ncpu} host threads"}
+
+
 def cpu_baseline_leg_2d(extra, state_dict, H, W, views=8, budget_s=25.0):
     """C4's CPU baseline (kind 'port'): the oracle's HRNet restatement (oracle/hrnet_oracle.py, training-mode BatchNorm as the
     reference runs it, float32 as test_2D.py does) on a BOUNDED sample -- ONE view of ONE image at the bench's size; an image
@@ -404,6 +444,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-batch64", action="store_true", help="C2: skip the side measurement at 64 volumes per step (value_at_64)")
     ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
                     help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
     ap.add_argument("--storage16", action="store_true",
@@ -571,6 +612,24 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
                 "note": "pinned host -> device input, maps device -> pinned host, copies on their own streams "
                         "(values_amd.HostPipeline), fill and drain of the 3-step pipeline included"}
 
+    # side object (never `value`; the bench keeps 32 volumes per step for comparability with rounds 1-4): the same step at 64
+    # volumes per GPU -- the 8^3 / 4^3 layers' launches amortise over twice the samples.  Workspace 47 MB per sample:
+    # 640 samples = 30 GB + 1.3 GB of logits, of the 288 GB.
+    at64 = None
+    if world == 1 and V == 32 and not args.no_batch64 and gp is None:
+        g64 = torch.Generator(device="cpu").manual_seed(777)
+        x64 = torch.randn((64, 1, S, S, S), generator=g64).to(dev)
+        loc64 = MapGatherPipeline(1, rank, depth=2)
+
+        def step64(i):
+            return loc64.submit(predict_uncertainty([model], x64, n_pred=T, seeds=[i], range_check="off"))
+        t64 = timed_regions(step64, loc64.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+        s64 = summarise(t64, 64 * args.steps, args.steps)
+        at64 = {"value": s64["value"], "ms_per_step": s64["ms_per_step"], "unit": "volumes/s", "volumes_per_gpu_per_step": 64,
+                "note": "the same step at 64 volumes (640 samples) per GPU; needs ~31 GB of HBM for workspace + logits"}
+        del x64
+        model.check_range()
+
     roof, detail, cpu, lat = None, None, None, None
     if rank == 0 and not args.no_roofline:
         roof, detail = roofline_leg(model, x, T)
@@ -599,6 +658,8 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
         ss = summarise(side, V * world * args.steps, args.steps)
         line["no_gather"] = {"value": ss["value"], "ms_per_step": ss["ms_per_step"],
                              "note": "same steps, maps left on the ranks that computed them"}
+    if at64 is not None:
+        line["value_at_64"] = at64
     if st16 is not None:
         line["storage16"] = st16
     if lat is not None:
@@ -669,6 +730,10 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
         vb = max(1, max((v1 - v0) for _, v0, v1 in ensemble_work_items(M, V, world)[rank]))
         roof, _ = roofline_leg(members[0], x[:vb], 1, chunks=[(0, vb)])
         roof["note"] = f"one member's forward over a {vb}-volume block; a step launches it once per (member, block) item"
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg_passes([m.state_dict() for m in members], M, M, False, "volumes/s",
+                                      f"one volume ({M} members, no dropout)")
     line = {"metric": "uncertainty-volumes/sec (64^3, 5-member deep ensemble)", "unit": "volumes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -676,7 +741,7 @@ def run_c3(args, world, rank, dev, barrier, reduce_max):
                                    "block) items dealt over the ranks, RCCL sum-reduce of sufficient statistics + finalize",
                        "volumes_per_step": V, "forwards_per_step": V * M,
                        "sharding": f"{M} members x volume blocks over {world} rank(s)"},
-            "roofline": roof, "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": cpu}
     line.update(summarise(times, V * args.steps, args.steps))
     return line
 
@@ -708,6 +773,10 @@ def run_c5(args, world, rank, dev, barrier, reduce_max):
         xp = torch.stack([im[:P, :P, :P] for im in imgs[:1]] * 16)[:, None].contiguous()
         roof, _ = roofline_leg(model, xp, T, chunks=[(0, 16)])
         roof["note"] = "one patch batch (16 patches of 64^3 x T = 20 samples per launch), as predict_image_sliding issues them"
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg_passes([model.state_dict()], 27 * T, T, True, "images/s",
+                                      f"one 128^3 image (27 patches x T={T})", reduce_vox_scale=8)
     line = {"metric": "uncertainty-images/sec (128^3 sliding window, T=20 MC-dropout)", "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -715,7 +784,7 @@ def run_c5(args, world, rank, dev, barrier, reduce_max):
                                    "patch, on-device softmax accumulation + count map, one uncertainty reduction per image",
                        "images_per_gpu_per_step": B, "patch_forwards_per_step": B * 27 * T,
                        "sharding": f"images over {world} rank(s)" if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": None}
+            "roofline": roof, "cpu_baseline": cpu}
     line.update(summarise(times, B * world * args.steps, args.steps))
     line["patch_volumes_per_s"] = round(line["value"] * 27, 1)       # comparable with C2's 64^3 volumes/s at T = 20
     return line

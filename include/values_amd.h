@@ -252,7 +252,8 @@ typedef struct vx_conv3d_args {
    * second conv -- window maxima of RAW values [N][D][H][W][8] -- and in_pool_flags its any-dropped words [N][D][H][W][2];
    * in_mean / in_rstd are that block's statistics ([N][8]) and in_drop_mode says whether the dropout's factor 2 applies.  The conv
    * evaluates vx_pool_finish's arithmetic (same expressions, same order) while it stages its tiles: the pooled tensor is never
-   * written.  in_repeat / in_split / in_drop_seed are not used. */
+   * written.  in_repeat / in_split / in_drop_seed are not used.  Only with the plain epilogue of a contract block's first conv
+   * (act NONE, no dropout, no head; Cout % 32 != 0): anything else is refused with VX_E_SHAPE. */
   const uint32_t* in_pool_flags;
 } vx_conv3d_args;
 int64_t vx_conv3d_upfused_packed_floats(void);

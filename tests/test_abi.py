@@ -254,3 +254,21 @@ def test_load_patch_and_tta_views(tmp_path):
     np.testing.assert_array_equal(views[1], views[0][:, :, ::-1])
     np.testing.assert_allclose(views[0][0, 0, 0], (img[0, 0, 0] / 255.0 - 0.485) / 0.229, rtol=1e-6)
     assert hflip_flags(tr) == [False, True, False, True]
+    # the host function against the oracle's restatement of the dataset branch over albumentations 1.3.0's published
+    # arithmetic (oracle/tta2d_oracle.py; the library itself is absent: parity unpinned), bit for bit: random images with both
+    # ends of the uint8 clip, float32 noise fields, a missing field
+    from oracle import tta2d_oracle
+    rng = np.random.default_rng(11)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for trial in range(4):
+        H, W = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        im = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        im[0, :] = 0; im[-1, :] = 255
+        g0 = (rng.standard_normal((H, W, 3)) * 40).astype(np.float32)
+        g1 = (rng.standard_normal((H, W, 3)) * 40).astype(np.float32) if trial != 2 else None
+        got, tr = tta_views_2d(im, mean, std, noise=g0, noise_flipped=g1)
+        want, tr_o = tta2d_oracle.tta_branch(im, mean, std, g0, g1)
+        assert tr == tr_o
+        for g in range(4):
+            assert got[g].dtype == np.float32 and got[g].shape == (3, H, W)
+            np.testing.assert_array_equal(got[g], want[g], err_msg=f"trial {trial} view {g}")

@@ -352,9 +352,12 @@ def test_batched_tta_views_equal_one_forward_per_view():
 def test_tta_views_2d_on_device_is_the_dataset_branch_bit_for_bit():
     """Row a17 (cityscapes_dataset.py:76-99): vx_tta_views_2d -- uint8 HWC image (+ the two noise fields, which are inputs:
     albumentations' generator is third-party) -> the four normalised views in ONE launch, flips as index arithmetic,
-    channels-last at the stem's pitch.  Bit-exact with values_amd.data.tta_views_2d (the host restatement the CPU suite
-    pins), batches of images, a missing field (the view degenerates to the clean one), the 8-view set of config C4; and
-    fed to the network through NhwcViews it gives the bits of the host-built views."""
+    channels-last at the stem's pitch.  The KERNEL is compared with oracle/tta2d_oracle.py (the branch restated over
+    albumentations 1.3.0's published Normalize / HorizontalFlip / GaussNoise arithmetic; the library is absent, so the row
+    stays "parity unpinned") bit for bit: batches of images, both ends of the uint8 clip, a missing field (the view
+    degenerates to the clean one), the 8-view set of config C4; the product's host function gives the same bits; and fed
+    to the network through NhwcViews the device-built views give the bits of the host-built ones."""
+    from oracle import tta2d_oracle
     from values_amd.data import TTA_2D_VIEW_CODES, hflip_flags, tta_views_2d, tta_views_2d_device, tta_views_8_device
     from values_amd.predict2d import NhwcViews, predict_logits_2d, tta_views_8
     rng = np.random.default_rng(5)
@@ -369,14 +372,17 @@ def test_tta_views_2d_on_device_is_the_dataset_branch_bit_for_bit():
     got = dv.cpu().numpy()
     assert (got[..., 3] == 0).all()
     for b in range(B):
-        ref, tr = tta_views_2d(imgs[b], mean, std, noise=n0[b], noise_flipped=n1[b])
+        ref, tr = tta2d_oracle.tta_branch(imgs[b], mean, std, n0[b], n1[b])          # the oracle, not product code
+        host, tr_h = tta_views_2d(imgs[b], mean, std, noise=n0[b], noise_flipped=n1[b])
+        assert tr == tr_h == names
         assert hflip_flags(tr) == hflip_flags(names) == [False, True, False, True]
         for g in range(4):
             np.testing.assert_array_equal(got[g, b, :, :, :3].transpose(2, 0, 1), ref[g], err_msg=f"view {g} image {b}")
+            np.testing.assert_array_equal(host[g], ref[g], err_msg=f"host view {g} image {b}")
     assert (got[2] != got[0]).any() and (got[3] != got[1]).any()
-    # a single (H, W, 3) image, no flipped-noise field: view 3 falls back to the clean flip, exactly as on the host
+    # a single (H, W, 3) image, no flipped-noise field: view 3 falls back to the clean flip, exactly as in the oracle
     dv1, _ = tta_views_2d_device(imgs[1], mean, std, noise=n0[1])
-    ref, _ = tta_views_2d(imgs[1], mean, std, noise=n0[1])
+    ref, _ = tta2d_oracle.tta_branch(imgs[1], mean, std, n0[1], None)
     for g in range(4):
         np.testing.assert_array_equal(dv1[g, 0, :, :, :3].cpu().numpy().transpose(2, 0, 1), ref[g])
     assert TTA_2D_VIEW_CODES == [0, 1, 4, 21]
@@ -386,8 +392,10 @@ def test_tta_views_2d_on_device_is_the_dataset_branch_bit_for_bit():
     noisy = x * 1.02 + 0.01
     views, hf, vf = tta_views_8(x, noisy)
     d8, hf2, vf2 = tta_views_8_device(x, noisy)
-    assert hf2 == hf and vf2 == vf
+    o8, ohf, ovf = tta2d_oracle.tta_views_8(x.cpu().numpy(), noisy.cpu().numpy())
+    assert hf2 == hf == ohf and vf2 == vf == ovf
     for g in range(8):
+        np.testing.assert_array_equal(d8[g][..., :3].permute(0, 3, 1, 2).cpu().numpy(), o8[g], err_msg=f"view {g}")
         assert torch.equal(d8[g][..., :3].permute(0, 3, 1, 2), views[g]), g
     # ... and through the network: one batched forward of the device-built views = the host-built ones, bit for bit
     a = predict_logits_2d([m2], NhwcViews(d8, hf2, vf2), tta=True)

@@ -997,6 +997,27 @@ def test_conv3d_xp8_pooled_output_matches_oracle(shape, pmode, rep, vxcfg):
     o_fus, s_fus = second(True)
     assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
     assert torch.isfinite(o_fus).all()
+    # refused where no instance carries the pool-finish code (round-4 advice): two row tiles per wave (8 -> 32), and an
+    # epilogue with activation + dropout (its compile-time instance ignores the flag words)
+    assert lib.vx_conv3d_k3_poolfin_ok(8, 32) == 0 and lib.vx_conv3d_k3_poolfin_ok(8, 24) == 1
+    a3 = _lib.ConvArgs()
+    o3 = torch.zeros((n, dp, hp, wq, 16), dtype=torch.float32, device=dev())
+    a3.w_family = lib.vx_conv3d_k3_family(8, 16)
+    a3.in_ = praw.data_ptr(); a3.w_packed = wp2.data_ptr(); a3.bias = b2.data_ptr(); a3.out = o3.data_ptr()
+    a3.in_pitch, a3.out_pitch, a3.out_coff = 8, 16, 0
+    a3.N, a3.D, a3.H, a3.W, a3.Cin, a3.Cout = n, dp, hp, wq, 8, 16
+    a3.in_mean, a3.in_rstd, a3.in_pool_flags = mean.data_ptr(), rstd.data_ptr(), pfl.data_ptr()
+    a3.act, a3.drop_mode, a3.drop_seed, a3.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 3, 2
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a3), _lib.stream_ptr()), "vx_conv3d_k3 (pool-finish + activation)")
+    w32 = torch.zeros(lib.vx_conv3d_k3_packed_floats(8, 32), dtype=torch.float32, device=dev())
+    o32 = torch.zeros((n, dp, hp, wq, 32), dtype=torch.float32, device=dev())
+    b32 = torch.zeros(32, dtype=torch.float32, device=dev())
+    a3.act, a3.drop_mode = _lib.VX_ACT_NONE, _lib.VX_DROP_NONE
+    a3.w_family = lib.vx_conv3d_k3_family(8, 32)
+    a3.w_packed, a3.bias, a3.out, a3.out_pitch, a3.Cout = w32.data_ptr(), b32.data_ptr(), o32.data_ptr(), 32, 32
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a3), _lib.stream_ptr()), "vx_conv3d_k3 (pool-finish, 8 -> 32)")
     # refused where the z-column kernel does not run
     vxcfg.set(s16_no_xp8=1)
     with pytest.raises(_lib.VxError):

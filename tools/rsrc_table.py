@@ -29,7 +29,32 @@ def parse(path):
     return rows
 
 
+def diagnostics(path):
+    """everything in a report that is NOT a resource-usage remark block: genuine -Wall diagnostics with their source-context and
+    caret lines intact.  A remark block = the `remark: ... [-Rpass-analysis=kernel-resource-usage]` line plus the indented
+    source-context lines (`  NN | ...`, `     | ^`) clang prints under it."""
+    in_remark = False
+    held = []                      # "In file included from ..." lines: they belong to whatever diagnostic follows them
+    for line in open(path, errors="replace"):
+        if "-Rpass-analysis=kernel-resource-usage" in line:
+            in_remark = True
+            held = []
+            continue
+        if in_remark and re.match(r"^\s*(\d+\s*)?\|", line):
+            continue
+        in_remark = False
+        if line.startswith("In file included from"):
+            held.append(line)
+            continue
+        sys.stdout.write("".join(held) + line)
+        held = []
+
+
 def main():
+    if "--diagnostics" in sys.argv:
+        for f in [a for a in sys.argv[1:] if not a.startswith("--")]:
+            diagnostics(f)
+        return
     fail = "--fail" in sys.argv
     files = [a for a in sys.argv[1:] if not a.startswith("--")]
     bad = 0

@@ -650,8 +650,10 @@ extern "C" int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout) 
 }
 
 // in_pool_flags: the tile kernel's prologue on a dense 8-channel input (contr_2_1 of the F = 8 networks)
+// (the code lives only in the instances an 8 -> 16 layer of a contract block runs on: 8-channel chunks, plain rows, ONE row
+// tile -- Cout % 32 == 0 takes two row tiles per wave and Cout == 8 the x-pair kernels, neither carries it)
 extern "C" int vx_conv3d_k3_poolfin_ok(int Cin, int Cout) {
-  if (Cin != 8 || Cout <= 0 || Cout % 8) return 0;
+  if (Cin != 8 || Cout <= 0 || Cout % 8 || Cout % 32 == 0) return 0;
   return conv_config(Cin, Cout).S16 && vx_conv3d_s16_prologue_ok(Cin, Cout) ? 1 : 0;
 }
 
@@ -710,6 +712,11 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     if (!vx_conv3d_k3_poolfin_ok(a.Cin, a.Cout) || a.in_xblk || a.in_pitch != 8 || a.in_split || a.up_in || a.in_repeat > 1)
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: pool-finish on load takes a dense 8-channel tensor of window maxima (see "
               "vx_conv3d_k3_poolfin_ok): %d -> %d, pitch %d", a.Cin, a.Cout, a.in_pitch);
+    // the first conv of a contract block: bias + statistics (an InstanceNorm follows) -- the only epilogue whose instances carry
+    // the pool-finish code; with an activation / dropout / head the launch would fall onto an instance that ignores the flag words
+    if (a.act != VX_ACT_NONE || a.drop_mode != VX_DROP_NONE || a.head_out || !a.out)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: pool-finish on load goes with the plain epilogue (no activation, no dropout, no head): "
+              "act=%d drop_mode=%d", a.act, a.drop_mode);
   }
   if (a.out && !a.out_xblk && (a.out_pitch < a.out_coff + a.Cout || a.out_pitch % 4 || a.out_coff % 4))
     VX_FAIL(VX_E_ALIGN, "vx_conv3d_k3: output pitch/offset must be multiples of 4 floats and cover the channels");

@@ -114,8 +114,13 @@ def tta_views_8_device(x, x_noisy, out=None):
     from . import _lib
     _lib.require_gpu()
     lib = _lib.load()
-    x = x.to(torch.float32).contiguous()
-    xn = x_noisy.to(x.device, torch.float32).contiguous()
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(x_noisy.shape) != tuple(x.shape):
+        raise ValueError(f"tta_views_8_device: x and x_noisy must be (B, 3, H, W) tensors of one shape, got {tuple(x.shape)} "
+                         f"and {tuple(x_noisy.shape)}")
+    # (a host tensor's pointer would reach the kernel as it is: move the inputs like tta_views_2d_device does)
+    dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    x = x.to(dev, torch.float32).contiguous()
+    xn = x_noisy.to(dev, torch.float32).contiguous()
     B, _, H, W = x.shape
     codes = [0, 1, 2, 3, 4, 5, 6, 7]
     if out is None:

@@ -232,9 +232,10 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
     def my_items():
         stats.zero_()
         for (m, lo, hi) in ensemble_work_items(len(models), V, world)[rank]:
-            # one dropout stream per (member, volume block): the block's first volume offsets the member's seed, as
-            # predict_image_sliding offsets by the patch batch -- volumes at the same in-block index do not share masks
-            kw = {"seeds": [(int(seeds[m]) + lo) & 0xFFFFFFFF]} if seeds is not None else {}
+            # one dropout stream per (member, volume block).  The block index enters through an odd-constant stride, as
+            # predict_logits decorrelates its chunks: UNet3D.next_seed() rises by ONE per call, so `seed + lo` made block
+            # lo = k of call c reuse the masks of block 0 of call c + k (round-4 advice)
+            kw = {"seeds": [(int(seeds[m]) + 0x9E3779B1 * lo) & 0xFFFFFFFF]} if seeds is not None else {}
             if tta:
                 kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
             logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,

@@ -223,7 +223,10 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
                 base = mi * per_model
                 src, flip, dst = _slot_indices(dev, v0, v1, n_total, base, per_model, tta)
                 if tta:
-                    model(xin, src=src, flip=flip, dst=dst, out=flat)
+                    # (a pinned seed reaches the TTA views too: a dropout member under tta=True then replays the same bits
+                    # in the range fallback's second run -- round-4 advice)
+                    kw = {"seed": (int(seeds[mi]) + 0x9E3779B1 * ci) & 0xFFFFFFFF} if seeds is not None else {}
+                    model(xin, src=src, flip=flip, dst=dst, out=flat, **kw)
                 else:
                     kw = {}
                     if dropout_masks is not None:

@@ -57,7 +57,7 @@ def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int
         x = torch.stack([img[c[0][0]:c[0][1], c[1][0]:c[1][1], c[2][0]:c[2][1]] for c in batch]).unsqueeze(1)
         kw = {}
         if seeds is not None:
-            kw["seeds"] = [s + b0 for s in seeds]
+            kw["seeds"] = [(int(s) + 0x9E3779B1 * b0) & 0xFFFFFFFF for s in seeds]   # (odd stride: see dist.ensemble_uncertainty_sharded)
         x_noise = noise_fn(x) if (tta and noise_fn is not None) else None
         logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise,
                                 n_aleatoric_samples=n_aleatoric_samples, **kw, **predict_kw)  # (B, T, C, P,P,P)

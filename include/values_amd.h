@@ -92,6 +92,9 @@ typedef struct vx_config {
                               instead of reading the once-per-volume output of vx_prenorm_split */
   int32_t s16_no_poolfin;  /* a separate vx_pool_finish pass over contr_1_2's window maxima instead of contr_2_1 finishing them while it
                               stages its tiles (round 4, vx_conv3d_args.in_pool_flags) */
+  int32_t s16_no_zc16;     /* the general tile kernels instead of the role-split z-column kernel (round 5, conv3d_zc16.hip) on the
+                              Cout == 16 layers with Cin in {8, 16} and W % 32 == 0; with it the forward also keeps the separate
+                              normalise + pool pass of the second contract block */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
   int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of
@@ -224,8 +227,8 @@ typedef struct vx_conv3d_args {
    * window: the maximum over the raw values the dropout KEEPS (drop_mode / drop_seed / drop_layer describe that dropout;
    * -inf when none is kept) and an any-dropped bit per channel.  vx_pool_finish turns them into the pooled tensor once the
    * statistics exist -- the full-resolution tensor is not read again. */
-  float* pool_out;      /* nullable: [N][D/2][H/2][W/2][8] raw window maxima */
-  uint32_t* pool_flags; /* [N][D/2][H/2][W/2][2]: bit j of word q = a dropped element of channel 4 q + j in the window */
+  float* pool_out;      /* nullable: [N][D/2][H/2][W/2][8] raw window maxima (layout 2 of vx_conv3d_k3_pool_layout: [N][D][H/2][W/2][16]) */
+  uint32_t* pool_flags; /* [N][D/2][H/2][W/2][2]: bit j of word q = a dropped element of channel 4 q + j in the window (layout 2: [..][4]) */
   /* PRE-SPLIT input (only with in_repeat > 1 where vx_conv3d_k3_prologue_ok): `in` is the output of vx_prenorm_split --
    * the shared raw tensor already normalised, activated and split into fp16 (hi, lo) pairs, ONCE per volume; the prologue
    * then only applies sample n's dropout bits (in_drop_*) while the tile is staged.  in_mean / in_rstd are not read. */
@@ -281,6 +284,16 @@ int vx_conv3d_k3_poolfin_ok(int Cin, int Cout);                       /* 1 if vx
 int vx_prenorm_split(float* x, const float* mean, const float* rstd, int N, int64_t nvox, float scale, vx_stream_t stream);
 int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd, float* out,
                    int out_pitch, int N, int64_t voxels_per_sample, int drop_scale2, vx_stream_t stream);
+/* The same for the 16-channel z-column kernel (round 5; vx_conv3d_k3_pool_layout(...) == 2): its epilogue pools the (y, x) half of
+ * every 2 x 2 x 2 window -- pool_raw [N][2 Dp][Hp Wp][16] window maxima of one z-plane each, pool_flags [N][2 Dp][Hp Wp][4] (bit j
+ * of word q: a dropped element of channel 4 q + j) -- and this pass takes the maximum / the OR over the z pair before the same
+ * arithmetic: out [N][Dp][Hp Wp][out_pitch >= 16].  Bit-identical to pooling the normalised tensor. */
+int vx_pool_finish_z(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd, float* out,
+                     int out_pitch, int N, int Dp, int64_t plane_voxels, int drop_scale2, vx_stream_t stream);
+/* layout of pool_out / pool_flags for a layer that takes them (vx_conv3d_k3_poolfuse_ok): 1 = [N][D/2][H/2][W/2][8] + [..][2]
+ * (the 8-channel z-column kernel: whole windows), 2 = [N][D][H/2][W/2][16] + [..][4] (the 16-channel one: the z pair is left to
+ * vx_pool_finish_z), 0 = no pooled output */
+int vx_conv3d_k3_pool_layout(int D, int H, int W, int Cin, int Cout);
 /* The decoder's concat buffer (torch.cat([up, skip], 1), unet3D_module.py:332-356) is never materialised as an
  * interleaved tensor: CAT[N][D][H][W/xb][2][xb][C] keeps the up half (s = 0, written by vx_convT_k2s2) and the
  * skip half (s = 1, written by vx_norm_act_drop_pool) as alternating DENSE blocks of xb voxels, so both producers

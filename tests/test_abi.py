@@ -94,7 +94,7 @@ def test_config_surface_is_the_documented_one(lib):
     for decl in re.findall(r"int32_t\s+([^;]+);", body):
         names += [n.strip() for n in decl.split(",")]
     assert names == [n for n, _ in _lib.Config._fields_]
-    assert len(names) <= 17, names
+    assert len(names) <= 18, names
     gone = {"conv_no_c8", "conv_no_xcd", "conv_per_cu", "s16_per_cu", "c8_per_cu", "convt_wgs", "s16_no_xp", "s16_no_db",
             "s16_no_db3", "s16_no_epi", "s16_no_ty8", "s16_no_wall", "c2s_no_nt5", "convt_no_mfma", "s16_range_check", "s16_pw",
             "s16_prio"}
@@ -102,7 +102,7 @@ def test_config_surface_is_the_documented_one(lib):
     blob = open(os.path.join(ROOT, "values_amd", "libvalues_amd.so"), "rb").read()
     for f in gone:
         assert ("VX_" + f.upper()).encode() + b"\0" not in blob, f
-    assert lib.vx_version() >= 400
+    assert lib.vx_version() >= 500
 
 
 def test_host_only_queries(lib, vxcfg):
@@ -115,9 +115,18 @@ def test_host_only_queries(lib, vxcfg):
         rows = -(-cout // (16 * nt)) * 16 * nt
         pieces = 32 if xp else 64           # x-pair blocks are [co >> 2][kx 4][co & 3] pieces, not one per lane
         return (rows // 16) * (cin // cb) * steps * 2 * pieces * 8 // 2
-    for cin, cout in ((16, 8), (24, 8), (16, 16), (32, 32), (128, 64)):
+    for cin, cout in ((16, 8), (24, 8), (32, 16), (32, 32), (128, 64)):
         assert lib.vx_conv3d_k3_packed_floats(cin, cout) == s16(cin, cout)
-    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (3, 8))] == [2, 1, 0]
+    # round 5, family 6 (Cout = 16, Cin in {8, 16}): the tile kernel's fragments followed by the z-column kernel's
+    # [15 or 9 K steps][hi | lo][64 lanes][8 halves] (conv3d_zc16.hip; which kernel runs depends on the volume's shape)
+    assert lib.vx_conv3d_k3_packed_floats(16, 16) == s16(16, 16) + 15 * 2 * 64 * 8 // 2
+    assert lib.vx_conv3d_k3_packed_floats(8, 16) == s16(8, 16) + 9 * 2 * 64 * 8 // 2
+    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (8, 16), (32, 16), (16, 32), (3, 8))] == [2, 6, 6, 1, 1, 0]
+    assert lib.vx_conv3d_k3_pool_layout(64, 64, 64, 8, 8) == 1 and lib.vx_conv3d_k3_pool_layout(32, 32, 32, 16, 16) == 2
+    assert lib.vx_conv3d_k3_pool_layout(16, 16, 16, 16, 16) == 0 and lib.vx_conv3d_k3_pool_layout(32, 32, 32, 32, 32) == 0
+    vxcfg.set(s16_no_zc16=1)
+    assert lib.vx_conv3d_k3_pool_layout(32, 32, 32, 16, 16) == 0 and lib.vx_conv3d_k3_family(16, 16) == 6   # the knob never changes the layout
+    vxcfg.set(s16_no_zc16=0)
     # 2D split-fp16 family = 10 + row tiles per workgroup (the packed layout is [row group][...][row tile])
     assert [lib.vx_conv2d_family(64, co, ks) for co, ks in ((64, 3), (720, 1), (64, 5))] == [12, 15, 0]
     # + 100 x the octets of the octet-granular K schedule for 3x3 layers of <= 8 or 17..24 REAL input channels (round 3)

@@ -1031,6 +1031,7 @@ def test_conv3d_tile_kernel_prologue_matches_oracle(cin, cout, shape, pmode, vxc
     resolution, unet3D_module.py:231-237): raw input + statistics + the producing block's dropout -> the conv of the
     normalised, activated, dropped tensor; ragged tiles, several channel chunks, with statistics of its own."""
     lib = _lib.load()
+    vxcfg.set(s16_no_zc16=1)       # (the first shape would otherwise take the z-column kernel of round 5: its own test below)
     n, d, h, w = shape
     assert lib.vx_conv3d_k3_prologue_ok(d, h, w, cin, cout) == 1
     raw = (torch.from_numpy(formula_tensor((n, cin, d, h, w), 351, scale=2.0)) + 0.3).float()
@@ -1069,3 +1070,180 @@ def test_conv3d_tile_kernel_prologue_matches_oracle(cin, cout, shape, pmode, vxc
     a.in_pitch = cin + 4
     with pytest.raises(_lib.VxError):
         _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the role-split z-column kernel of the Cout = 16 layers (conv3d_zc16.hip)
+def _zc16_launch(x_cl, cin, wp, bd, n, d, h, w, *, act=0, drop=0, seed=0, layer=0, stats=False, pre=None, out_xblk=0,
+                 pool=False, out_split=False, poolfin=None):
+    """one vx_conv3d_k3 launch (16 output channels) on a dense channels-last device input.
+    Returns (out device tensor, stats or None, (pool_raw, pool_flags) or None, kernel name)"""
+    lib = _lib.load()
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, 16)
+    out = torch.full((n, d, h, w, 32 if out_xblk else 16), -77.0, dtype=torch.float32, device=dev())
+    a.in_ = x_cl.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, (32 if out_xblk else 16), 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, 16
+    a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, seed, layer
+    a.out_xblk, a.out_half, a.out_split = out_xblk, 1, 1 if out_split else 0
+    st = None
+    if stats:
+        nt = lib.vx_conv3d_k3_tiles_for(d, h, w, 16)
+        st = torch.full((n, nt, 16, 2), 5.0, dtype=torch.float32, device=dev())
+        a.stats_partial = st.data_ptr()
+    pl = None
+    if pool:
+        pl = (torch.full((n, d, h // 2, w // 2, 16), 123.0, dtype=torch.float32, device=dev()),
+              torch.full((n, d, h // 2, w // 2, 4), -1, dtype=torch.int32, device=dev()))
+        a.pool_out, a.pool_flags = pl[0].data_ptr(), pl[1].data_ptr()
+    if pre is not None:
+        a.in_mean, a.in_rstd, a.in_repeat = pre[0].data_ptr(), pre[1].data_ptr(), 1
+        a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = pre[2], pre[3], pre[4]
+    if poolfin is not None:
+        a.in_mean, a.in_rstd, a.in_pool_flags, a.in_drop_mode = poolfin[0].data_ptr(), poolfin[1].data_ptr(), poolfin[2].data_ptr(), poolfin[3]
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    return out, st, pl, lib.vx_last_kernel_name().decode()
+
+
+def _pack16(cin, seed):
+    lib = _lib.load()
+    wt = torch.from_numpy(formula_tensor((16, cin, 3, 3, 3), seed, scale=(1.0 / (27 * cin)) ** 0.5)).float().contiguous()
+    b = torch.from_numpy(formula_tensor((16,), seed + 1, scale=0.2)).float().contiguous()
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, 16), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt.to(dev())), _lib.ptr(wp), cin, 16, _lib.stream_ptr()), "pack")
+    return wt, b, wp, b.to(dev())
+
+
+ZC16_SHAPES = [(2, 8, 16, 32), (1, 4, 8, 64), (3, 6, 24, 32)]
+
+
+@pytest.mark.parametrize("shape", ZC16_SHAPES)
+@pytest.mark.parametrize("cin", [16, 8])
+def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxcfg):
+    """conv3d_zc16.hip (round 5; unet3D_module.py:231-243, 263-267 at the levels below full resolution): bias + statistics,
+    LeakyReLU / ReLU, LeakyReLU + hash dropout (+ the pre-split hand-over, + the x-blocked concat output) against the float64
+    oracle, columns at every border class (1-3 columns in y, 1-2 in x, 2-4 items in z), several samples per workgroup; and the
+    knob that switches the kernel off gives the tile kernel's numbers."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_family(cin, 16) == 6
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 701, scale=1.5)).float()
+    wt, b, wp, bd = _pack16(cin, 702)
+    xd = cl(x).to(dev())
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    # --- bias + statistics (EPI 0)
+    out, st, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, stats=True)
+    assert kn == "conv3d_zc16_kernel<%d,0,0>" % cin, kn
+    got = ncdhw(out).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 4e-5, err
+    ssum = st.double().sum(1).cpu()
+    np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ssum[..., 1].numpy(), (got.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    # --- run-time activation (EPI 3)
+    for act, fn in ((_lib.VX_ACT_LRELU, lambda t: F.leaky_relu(t, 0.01)), (_lib.VX_ACT_RELU, F.relu)):
+        o2, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=act)
+        assert kn == "conv3d_zc16_kernel<%d,3,0>" % cin, kn
+        assert (ncdhw(o2).cpu().double() - fn(ref)).abs().max().item() < 4e-5
+    # --- LeakyReLU + hash dropout (EPI 1), plain / pre-split / x-blocked
+    keep = _hash_mask(77, 13, n, 16, d, h, w)
+    want = F.leaky_relu(ref, 0.01) * keep * 2.0
+    o3, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13)
+    assert kn == "conv3d_zc16_kernel<%d,1,0>" % cin, kn
+    assert (ncdhw(o3).cpu().double() - want).abs().max().item() < 4e-5
+    o4, _, _, _ = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13, out_split=True)
+    hl = o4.cpu().contiguous().view(torch.float16).view(n, d, h, w, 4, 2, 4).float()      # [quad][hi | lo][4]
+    back = (hl[..., 0, :] + hl[..., 1, :] / 2048.0).reshape(n, d, h, w, 16)
+    assert (back - o3.cpu()).abs().max().item() <= 1e-6 * max(1.0, o3.abs().max().item())
+    if w % 4 == 0:
+        o5, _, _, _ = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13, out_xblk=4)
+        blk = o5.cpu().view(n, d, h, w // 4, 2, 4, 16)
+        assert torch.equal(blk[:, :, :, :, 1].reshape(n, d, h, w, 16), o3.cpu())      # the skip half holds the output
+        assert (blk[:, :, :, :, 0] == -77.0).all()                                       # the up half is untouched
+    # --- the knob: the tile kernel on the same launch
+    vxcfg.set(s16_no_zc16=1)
+    o6, st6, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, stats=True)
+    assert kn.startswith("conv3d_k3_s16_kernel"), kn
+    assert (ncdhw(o6).cpu().double() - ref).abs().max().item() < 4e-5
+    assert (o6 - out).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("shape", ZC16_SHAPES)
+@pytest.mark.parametrize("pmode", [1, 0])
+def test_conv3d_zc16_prologue_and_pooled_output_match_oracle(shape, pmode, vxcfg):
+    """The second conv of a contract block on the z-column kernel (contr_2_2): normalise-on-load of the raw first conv
+    (InstanceNorm + LeakyReLU + hash dropout in the staging waves), its own statistics, the raw output into the x-blocked skip
+    half, and the (y, x) half of the block's MaxPool from the epilogue -- vx_pool_finish_z then gives MaxPool3d of the normalised,
+    dropped tensor BIT FOR BIT (unet3D_module.py:231-237, 303-310)."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_pool_layout(d, h, w, 16, 16) == 2 and lib.vx_conv3d_k3_poolfuse_ok(d, h, w, 16, 16) == 1
+    raw = (torch.from_numpy(formula_tensor((n, 16, d, h, w), 711, scale=2.0)) + 0.3).float()
+    wt, b, wp, bd = _pack16(16, 712)
+    mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    keep_in = _hash_mask(61, 4, n, 16, d, h, w) if pmode else torch.ones((n, 16, d, h, w), dtype=torch.float64)
+    xin = F.leaky_relu((raw.double() - mean.cpu().double().view(n, 16, 1, 1, 1)) * rstd.cpu().double().view(n, 16, 1, 1, 1), 0.01)
+    xin = xin * keep_in * (2.0 if pmode else 1.0)
+    ref = F.conv3d(xin, wt.double(), b.double(), padding=1)
+    xd = cl(raw).to(dev())
+    pre = (mean, rstd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 61, 4)
+    dmode = _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE
+    out, st, pl, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre, pool=True, drop=dmode, seed=57, layer=5, out_xblk=4)
+    assert kn == "conv3d_zc16_kernel<16,4,1>", kn
+    got_cl = out.view(n, d, h, w // 4, 2, 4, 16)[:, :, :, :, 1].reshape(n, d, h, w, 16).contiguous()
+    got = ncdhw(got_cl).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 4e-5, err
+    ssum = st.double().sum(1).cpu()
+    np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    # the prologue without the pooled epilogue (EPI 0) gives the same output bits
+    out0, _, _, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre)
+    assert kn == "conv3d_zc16_kernel<16,0,1>", kn
+    assert torch.equal(out0, got_cl)
+    # pooled tensor: statistics of the conv's own float32 output, then the z pair + the normalisation
+    mean2 = got.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd2 = (1.0 / torch.sqrt(got.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    pooled = torch.full((n, d // 2, h // 2, w // 2, 20), -9.0, dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pool_finish_z(_lib.ptr(pl[0]), _lib.ptr(pl[1]), _lib.ptr(mean2), _lib.ptr(rstd2), _lib.ptr(pooled), 20, n, d // 2,
+                                    (h // 2) * (w // 2), 1 if pmode else 0, _lib.stream_ptr()), "vx_pool_finish_z")
+    torch.cuda.synchronize()
+    keep = _hash_mask(57, 5, n, 16, d, h, w) if pmode else torch.ones((n, 16, d, h, w), dtype=torch.float64)
+    t = (got - mean2.cpu().view(n, 16, 1, 1, 1)) * rstd2.cpu().view(n, 16, 1, 1, 1)
+    t = torch.maximum(t, 0.01 * t) * (2.0 if pmode else 1.0) * keep.float()
+    want = F.max_pool3d(t, 2, 2)
+    assert torch.equal(ncdhw(pooled[..., :16]).cpu(), want)
+    assert (pooled[..., 16:] == -9.0).all()
+    if pmode:
+        assert (pl[1].cpu() & 0xF).float().ne(0).float().mean().item() > 0.5
+
+
+@pytest.mark.parametrize("pmode", [1, 0])
+def test_conv3d_zc16_pool_finish_on_load_is_pool_finish_then_conv(pmode, vxcfg):
+    """contr_2_1 on the z-column kernel: the previous block's window maxima + flags finished while the tiles are staged
+    (vx_conv3d_args.in_pool_flags) = vx_pool_finish + the plain launch, bit for bit (output and statistics)."""
+    lib = _lib.load()
+    n, d, h, w = 2, 8, 16, 32
+    rng = np.random.default_rng(3)
+    praw = torch.from_numpy(rng.standard_normal((n, d, h, w, 8)).astype(np.float32) * 2.0 + 0.2)
+    praw[0, 0, 0, :4] = -float("inf")                      # windows in which nothing was kept
+    pfl = torch.from_numpy(rng.integers(0, 16, size=(n, d, h, w, 2)).astype(np.int32))
+    pfl[0, 0, 0, :4] = 15
+    mean = torch.from_numpy(rng.standard_normal((n, 8)).astype(np.float32) * 0.3).to(dev())
+    rstd = torch.from_numpy((0.5 + rng.random((n, 8))).astype(np.float32)).to(dev())
+    prd, pfd = praw.to(dev()), pfl.to(dev())
+    dense = torch.empty((n, d, h, w, 8), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pool_finish(_lib.ptr(prd), _lib.ptr(pfd), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dense), 8, n, d * h * w,
+                                  1 if pmode else 0, _lib.stream_ptr()), "vx_pool_finish")
+    wt, b, wp, bd = _pack16(8, 722)
+    o_sep, s_sep, _, kn = _zc16_launch(dense, 8, wp, bd, n, d, h, w, stats=True)
+    assert kn == "conv3d_zc16_kernel<8,0,0>", kn
+    o_fus, s_fus, _, kn = _zc16_launch(prd, 8, wp, bd, n, d, h, w, stats=True,
+                                       poolfin=(mean, rstd, pfd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE))
+    assert kn == "conv3d_zc16_kernel<8,0,3>", kn
+    assert torch.isfinite(o_fus).all()
+    assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
+    ref = F.conv3d(ncdhw(dense).cpu().double(), wt.double(), b.double(), padding=1)
+    assert (ncdhw(o_fus).cpu().double() - ref).abs().max().item() < 4e-5

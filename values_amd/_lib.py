@@ -84,7 +84,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw", "no_head_fusion", "s16_no_upfuse", "s16_no_poolfuse",
-        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "c2s_no_wide", "c2s_no_oct")]
+        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "s16_no_zc16", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -136,6 +136,8 @@ SIGNATURES = {
     "vx_conv3d_upfused_packed_floats": (_i64, []),
     "vx_pack_conv3d_upfused": (_i, [_p, _p, _p, _p, _p, _p]),
     "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vx_pool_finish_z": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
+    "vx_conv3d_k3_pool_layout": (_i, [_i, _i, _i, _i, _i]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),

@@ -48,6 +48,12 @@ int vx_conv3d_k3_s16(const vx_conv3d_args& a, hipStream_t s);
 bool vx_conv3d_s16_head_fusable(int Cin, int Cout);
 bool vx_conv3d_xp8_applies(int D, int H, int W, int Cin, int Cout);
 int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s);   // 1 = not taken
+// conv3d_zc16.hip: the role-split z-column kernel of the Cout = 16 layers
+bool vx_conv3d_zc16_packs(int Cin, int Cout);
+bool vx_conv3d_zc16_applies(int D, int H, int W, int Cin, int Cout);
+int64_t vx_conv3d_zc16_packed_floats(int Cin, int Cout);
+int vx_pack_conv3d_zc16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
+int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_tiles, hipStream_t s);   // 1 = not taken
 void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz);
 
 struct ConvKArgs {
@@ -508,7 +514,9 @@ __global__ void pack_conv3d_k3_kernel(const float* __restrict__ w, float* __rest
 extern "C" int vx_conv3d_k3_family(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return 0;
   const ConvCfg c = conv_config(Cin, Cout);
-  if (c.S16) return vx_conv3d_s16_head_fusable(Cin, Cout) ? 2 : 1;   // head-fusable == x-pair packing
+  // 6: the tile kernel's fragments FOLLOWED BY the z-column kernel's (conv3d_zc16.hip: which of the two runs depends on the
+  // volume's shape, known only at launch)
+  if (c.S16) return vx_conv3d_s16_head_fusable(Cin, Cout) ? 2 : (vx_conv3d_zc16_packs(Cin, Cout) ? 6 : 1);   // head-fusable == x-pair packing
   if (c.C8) return 5;
   return c.XP ? 4 : 3;
 }
@@ -517,7 +525,7 @@ extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return -1;
   ConvCfg c = conv_config(Cin, Cout);
   if (c.C8) return (int64_t)27 * Cin * 8;
-  if (c.S16) return vx_conv3d_s16_packed_floats(Cin, Cout);
+  if (c.S16) return vx_conv3d_s16_packed_floats(Cin, Cout) + vx_conv3d_zc16_packed_floats(Cin, Cout);
   if (c.XP) return (int64_t)16 * Cin * 36;
   return (int64_t)conv_rows_padded(Cout, c.NT) * Cin * 27;
 }
@@ -528,7 +536,11 @@ extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin,
   if (total < 0) VX_FAIL(VX_E_SHAPE, "vx_pack_conv3d_k3: Cin=%d Cout=%d must be positive multiples of 8", Cin, Cout);
   ConvCfg c = conv_config(Cin, Cout);
   if (c.C8) return vx_pack_conv3d_k3_c8(w_torch, w_packed, Cin, (hipStream_t)stream);
-  if (c.S16) return vx_pack_conv3d_k3_s16(w_torch, w_packed, Cin, Cout, (hipStream_t)stream);
+  if (c.S16) {
+    const int rc = vx_pack_conv3d_k3_s16(w_torch, w_packed, Cin, Cout, (hipStream_t)stream);
+    if (rc != VX_OK || !vx_conv3d_zc16_packs(Cin, Cout)) return rc;
+    return vx_pack_conv3d_zc16(w_torch, w_packed + vx_conv3d_s16_packed_floats(Cin, Cout), Cin, Cout, (hipStream_t)stream);
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_conv3d_k3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_torch, w_packed, Cin,
@@ -639,8 +651,14 @@ extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
   return Cin == 16 && !vx_cfg().s16_no_upfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
+extern "C" int vx_conv3d_k3_pool_layout(int D, int H, int W, int Cin, int Cout) {
+  if (vx_cfg().s16_no_poolfuse) return 0;
+  if (Cin == 8 && vx_conv3d_xp8_applies(D, H, W, Cin, Cout)) return 1;
+  if (Cin == 16 && Cout == 16 && conv_config(Cin, Cout).S16 && vx_conv3d_zc16_applies(D, H, W, Cin, Cout)) return 2;
+  return 0;
+}
 extern "C" int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout) {
-  return Cin == 8 && !vx_cfg().s16_no_poolfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+  return vx_conv3d_k3_pool_layout(D, H, W, Cin, Cout) != 0 ? 1 : 0;
 }
 
 // in_split (vx_prenorm_split's fp16 pairs) is read by the z-column kernel's staging waves only: the tile kernel's prologue
@@ -756,6 +774,12 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
       a.in_drop_mode != VX_DROP_MASK) {
     // the full-resolution layers: z-column walk with a rolling LDS window (conv3d_xp8w.hip)
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
+    if (rc != 1) return rc;
+  }
+  if (c.S16 && vx_conv3d_zc16_applies(a.D, a.H, a.W, a.Cin, a.Cout)) {
+    // the Cout = 16 layers below full resolution: role-split z-column kernel (conv3d_zc16.hip); its weights follow the tile
+    // kernel's in the packed block (family 6)
+    const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
   const bool tile_pre = a.in_mean && c.S16 && vx_conv3d_s16_prologue_ok(a.Cin, a.Cout) && !a.in_xblk && a.in_pitch == a.Cin &&

@@ -347,6 +347,34 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
   }
 }
 
+// vx_pool_finish_z: the 16-channel z-column kernel leaves the (y, x) half of every window per z-plane (values_amd.h); one
+// thread = one 16-byte piece of a pooled voxel: maximum / OR over the z pair, then pool_finish_kernel's arithmetic
+__global__ __launch_bounds__(256) void pool_finish_z_kernel(const float* __restrict__ raw, const uint32_t* __restrict__ flags,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ out, int out_pitch, unsigned Dp, unsigned pv_plane, float s) {
+  const int n = blockIdx.y;
+  const unsigned pieces = Dp * pv_plane * 4u;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
+    const unsigned vox = i >> 2, q = i & 3u;
+    const unsigned zp = vox / pv_plane, r = vox - zp * pv_plane;
+    const size_t v0 = ((size_t)n * 2 * Dp + 2 * zp) * pv_plane + r, v1 = v0 + pv_plane;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(raw + v0 * 16 + q * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(raw + v1 * 16 + q * 4);
+    const uint32_t fl = flags[v0 * 4 + q] | flags[v1 * 4 + q];
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * 16 + q * 4);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * 16 + q * 4);
+    f32x4 t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tt = (fmaxf(a0[j], a1[j]) - mu[j]) * rs[j];
+      float v = fmaxf(tt, 0.01f * tt) * s;
+      if ((fl >> j) & 1u) v = fmaxf(v, 0.f);
+      t[j] = v;
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)n * Dp * pv_plane + vox) * out_pitch + q * 4) = t;
+  }
+}
+
 // vx_prenorm_split: one thread = one 16-byte piece, in place (values_amd.h)
 __global__ __launch_bounds__(256) void prenorm_split_kernel(float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned pieces, float scale) {
@@ -402,5 +430,23 @@ extern "C" int vx_pool_finish(const float* pool_raw, const uint32_t* pool_flags,
   hipLaunchKernelGGL(pool_finish_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags, mean,
                      rstd, out, out_pitch, pieces, drop_scale2 ? 2.f : 1.f);
   VX_CHECK_LAUNCH("vx_pool_finish");
+  return VX_OK;
+}
+
+extern "C" int vx_pool_finish_z(const float* pool_raw, const uint32_t* pool_flags, const float* mean, const float* rstd,
+                                float* out, int out_pitch, int N, int Dp, int64_t plane_voxels, int drop_scale2,
+                                vx_stream_t stream) {
+  if (!pool_raw || !pool_flags || !mean || !rstd || !out) VX_FAIL(VX_E_NULL, "vx_pool_finish_z: null pointer");
+  if (N <= 0 || Dp <= 0 || plane_voxels <= 0 || (int64_t)Dp * plane_voxels >= (1ll << 28)) VX_FAIL(VX_E_SHAPE, "vx_pool_finish_z: empty / too large");
+  if (out_pitch < 16 || out_pitch % 4 || !vx_aligned16(pool_raw) || !vx_aligned16(out))
+    VX_FAIL(VX_E_ALIGN, "vx_pool_finish_z: pitch %d / alignment", out_pitch);
+  if (N >= 65536) VX_FAIL(VX_E_SHAPE, "vx_pool_finish_z: N");
+  const unsigned pieces = (unsigned)(Dp * plane_voxels * 4);
+  unsigned bx = (pieces + 255u) / 256u;
+  if (bx > 64u) bx = 64u;
+  vx_note_kernel("pool_finish_z_kernel");
+  hipLaunchKernelGGL(pool_finish_z_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags, mean,
+                     rstd, out, out_pitch, (unsigned)Dp, (unsigned)plane_voxels, drop_scale2 ? 2.f : 1.f);
+  VX_CHECK_LAUNCH("vx_pool_finish_z");
   return VX_OK;
 }

@@ -270,6 +270,9 @@ int vx_pack_conv3d_upfused(const float* w1_torch, const float* b1, const float* 
                            vx_stream_t stream);
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
 int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
+/* 1 if vx_conv3d_k3 takes in_mean for the SKIP half of an x-blocked concat input (in_xblk = xblk) of this layer: the decoder's
+ * first conv of a level normalising the contract block's raw output on load (round 5: also the tile kernel, Cin % 32 == 0) */
+int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk);
 int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
 int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_split (vx_prenorm_split's output) for this layer */
 int vx_conv3d_k3_poolfin_ok(int Cin, int Cout);                       /* 1 if vx_conv3d_k3 takes in_pool_flags for this layer */

@@ -1247,3 +1247,54 @@ def test_conv3d_zc16_pool_finish_on_load_is_pool_finish_then_conv(pmode, vxcfg):
     assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
     ref = F.conv3d(ncdhw(dense).cpu().double(), wt.double(), b.double(), padding=1)
     assert (ncdhw(o_fus).cpu().double() - ref).abs().max().item() < 4e-5
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 8, 16, 32), 16), ((1, 5, 12, 20), 16), ((2, 4, 8, 8), 32)])
+@pytest.mark.parametrize("pmode", [1, 0])
+def test_conv3d_tile_kernel_prologue_on_the_skip_half_of_a_concat_input(shape, cout, pmode, vxcfg):
+    """Round 5 (expand_2_1 reading contr_2_2's RAW output from the x-blocked concat buffer, unet3D_module.py:231-237, 332-356):
+    the tile kernel normalises ONLY the chunks of the skip half on load -- statistics of the skip tensor, the dropout bits of its
+    dense element space recovered from the x-blocked load offset -- and leaves the up half as it is.  Ragged tiles, 32 and 64
+    concatenated channels."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    cs = cout                                   # channels per half (the decoder's first conv: 2 C -> C)
+    cin = 2 * cs
+    assert lib.vx_conv3d_k3_skip_prologue_ok(d, h, w, cin, cout, 4) == 1
+    up = torch.from_numpy(formula_tensor((n, cs, d, h, w), 731, scale=1.2)).float()
+    raw = (torch.from_numpy(formula_tensor((n, cs, d, h, w), 732, scale=2.0)) + 0.3).float()
+    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), 733, scale=(1.0 / (27 * cin)) ** 0.5)).float().contiguous()
+    b = torch.from_numpy(formula_tensor((cout,), 734, scale=0.2)).float().contiguous()
+    mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    keep = _hash_mask(61, 3, n, cs, d, h, w) if pmode else torch.ones((n, cs, d, h, w), dtype=torch.float64)
+    skip = F.leaky_relu((raw.double() - mean.cpu().double().view(n, cs, 1, 1, 1)) * rstd.cpu().double().view(n, cs, 1, 1, 1), 0.01)
+    skip = skip * keep * (2.0 if pmode else 1.0)
+    ref = F.leaky_relu(F.conv3d(torch.cat([up.double(), skip], 1), wt.double(), b.double(), padding=1), 0.01)
+    cat = torch.empty((n, d, h, w // 4, 2, 4, cs), dtype=torch.float32)
+    cat[:, :, :, :, 0] = cl(up).view(n, d, h, w // 4, 4, cs)
+    cat[:, :, :, :, 1] = cl(raw).view(n, d, h, w // 4, 4, cs)
+    catd = cat.to(dev())
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt.to(dev())), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+    bd = b.to(dev())
+    out = torch.full((n, d, h, w, cout), -77.0, dtype=torch.float32, device=dev())
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+    a.in_ = catd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+    a.act, a.in_xblk = _lib.VX_ACT_LRELU, 4
+    a.in_mean, a.in_rstd, a.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1
+    a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = (_lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE), 61, 3
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    assert lib.vx_last_kernel_name().decode().startswith("conv3d_k3_s16_kernel")
+    err = (ncdhw(out).cpu().double() - ref).abs().max().item()
+    assert err < 4e-5, err
+    # the same launch with the hash-dropout epilogue of the decoder (the compile-time instance the network runs)
+    a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_DROP_HASH, 9, 11
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    want = ref * _hash_mask(9, 11, n, cout, d, h, w) * 2.0
+    assert (ncdhw(out).cpu().double() - want).abs().max().item() < 8e-5

@@ -501,6 +501,22 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     # replaying the exported masks through VX_DROP_MASK (run-time epilogue instances) gives the same logits
     rep = predict_uncertainty([model], x.float().cuda(), n_pred=T, dropout_masks=[masks])
     assert (rep["logits"] - out["logits"]).abs().max().item() < 2e-5
+    # Round 5: the level-1 layers ran on the role-split z-column kernel (conv3d_zc16.hip) with the level-0 data flow (raw skip
+    # half, pooled epilogue + vx_pool_finish_z, expand_2_1 normalising on load); the knob that switches it off runs the round-4
+    # launches (tile kernels + the normalise / pool pass) on the same seeds: the same function, compared with the oracle too
+    from values_amd import _lib
+    import bench
+    names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert any(n.startswith("conv3d_zc16_kernel<16,4,1>") for n in names) and any(n.startswith("conv3d_zc16_kernel<8,0,3>") for n in names), names
+    assert any(n.startswith("pool_finish_z_kernel") for n in names) and len(names) <= 33
+    with _lib.config(s16_no_zc16=1):
+        alt = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+        names4 = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert not any("zc16" in n for n in names4)
+    assert np.abs(alt["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
+    assert (alt["logits"] - out["logits"]).abs().max().item() < 2e-5
+    for k in KEYS:
+        assert np.abs(alt[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
     # dropout off: the plain-epilogue instances, EPI = 0 / run-time activation
     det = make_model(do_dropout=False)
     with torch.no_grad():

@@ -138,6 +138,7 @@ SIGNATURES = {
     "vx_pool_finish": (_i, [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "vx_pool_finish_z": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
     "vx_conv3d_k3_pool_layout": (_i, [_i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_skip_prologue_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),

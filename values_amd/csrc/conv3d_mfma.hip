@@ -647,6 +647,16 @@ extern "C" int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout) 
   return conv_config(Cin, Cout).S16 && vx_conv3d_s16_prologue_ok(Cin, Cout) ? 1 : 0;
 }
 
+// in_mean on the SKIP half of an x-blocked concat input (the decoder's first conv reading a contract block's raw output)
+extern "C" int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk) {
+  if (Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 8 || (xblk != 1 && xblk != 2 && xblk != 4)) return 0;
+  if (Cin == 16 && vx_conv3d_xp8_applies(D, H, W, Cin, Cout)) return 1;      // (16 -> 8 at full resolution: the z-column kernel's prologue)
+  if (Cin % 32) return 0;
+  const ConvCfg c = conv_config(Cin, Cout);
+  const int csrc = Cin / 2;
+  return c.S16 && c.CB == 16 && vx_conv3d_s16_prologue_ok(Cin, Cout) && ((xblk * csrc) & (xblk * csrc - 1)) == 0 ? 1 : 0;
+}
+
 extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
   return Cin == 16 && !vx_cfg().s16_no_upfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
@@ -782,8 +792,13 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
-  const bool tile_pre = a.in_mean && c.S16 && vx_conv3d_s16_prologue_ok(a.Cin, a.Cout) && !a.in_xblk && a.in_pitch == a.Cin &&
-                        a.in_drop_mode != VX_DROP_MASK;
+  // the tile kernel's prologue: a dense input, or (round 5) the skip half of an x-blocked concat input whose halves are whole
+  // 16-channel chunks with xb * Cin / 2 a power of two (the element index of the dropout bits follows from the load offset)
+  const int csrc = a.Cin / 2;
+  const bool xblk_pre = a.in_xblk && c.CB == 16 && csrc % 16 == 0 && ((a.in_xblk * csrc) & (a.in_xblk * csrc - 1)) == 0 &&
+                        !a.in_pool_flags && !(a.in_repeat > 1);
+  const bool tile_pre = a.in_mean && c.S16 && vx_conv3d_s16_prologue_ok(a.Cin, a.Cout) &&
+                        ((!a.in_xblk && a.in_pitch == a.Cin) || xblk_pre) && a.in_drop_mode != VX_DROP_MASK;
   if ((a.in_mean && !tile_pre) || a.out_xblk || a.up_in || a.pool_out || a.in_split || a.in_f16 || a.out_f16)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);

@@ -221,6 +221,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   // LDS (unet3D_module.py:231-237), as conv3d_xp8w.hip does for the full-resolution layers.  Run-time flag: the element
   // index of a piece is (soff + voff) / 4 - biasf because the tensor is dense (in_pitch == Cin), so it costs no table.
   const bool pre = !XP && a.in_mean != nullptr;
+  // Round 5: the prologue on the SKIP half of an x-blocked concat input (expand_2_1 reading contr_2_2's raw output from the
+  // concat buffer): only the chunks of half 1 are normalised, the statistics have Csrc channels, and the element index of a piece
+  // (in the producing layer's dense [voxel][Csrc] space) follows from its float offset F in the buffer [..][W/xb][2][xb][Csrc]:
+  // E = (F >> (xs + 1) << xs) | (F & (2^xs - 1)) with 2^xs = xb * Csrc (the dispatch admits powers of two only)
+  const int pre_xs = (pre && xb) ? 31 - __builtin_clz((unsigned)(xb * Csrc)) : 0;
+  bool p_on = false;          // the staged item's chunk takes the prologue
   // pool-finish on load (round 4, vx_conv3d_args.in_pool_flags): the input is the previous block's window maxima of RAW values;
   // statistics, LeakyReLU, the dropout's 2 and the zero of a dropped element are applied here with vx_pool_finish's expressions
   // (the separate pass over the pooled tensor and the tensor itself disappear).  One flag word per 16-byte piece: the flags
@@ -284,9 +290,11 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
       p_bad = bad;
       p_e0 = (soff >> 2) - (unsigned)biasf;
       p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n);
+      p_on = !xb || (cper && chunk / cper == 1);
       // (n_in = 0 when the workgroup has run out of tiles: a valid address -- no branch around the loads, a join behind
       // one makes the compiler wait for every load in flight)
-      const size_t mo = (size_t)n_in * a.Cin + chunk * CB + (tid % Q) * 4;
+      const size_t mo = xb ? (size_t)n_in * Csrc + (cper ? chunk % cper : 0) * CB + (tid % Q) * 4
+                           : (size_t)n_in * a.Cin + chunk * CB + (tid % Q) * 4;
       p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + mo);
       p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + mo);
     }
@@ -317,12 +325,16 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
             v[j] = outside ? 0.f : w;
           }
           ibuf[it] = v;
-        } else if (pre) {
+        } else if (pre && p_on) {
           f32x4 v = ibuf[it];
           // dropout's factor 2 rides in the scale: 2 lrelu(t) = lrelu(2 t)
           const f32x4 sc = p_rstd * (a.in_drop_mode == VX_DROP_HASH ? 2.f : 1.f);
           uint32_t bits = 0xFu;
-          if (a.in_drop_mode == VX_DROP_HASH) bits = vx_drop_bits4(p_key, p_e0 + (voff[it] >> 2));
+          if (a.in_drop_mode == VX_DROP_HASH) {
+            unsigned e = p_e0 + (voff[it] >> 2);
+            if (xb) e = ((e >> (pre_xs + 1)) << pre_xs) | (e & ((1u << pre_xs) - 1u));
+            bits = vx_drop_bits4(p_key, e);
+          }
           if ((p_bad >> it) & 1u) bits = 0u;             // zero padding belongs to the normalised tensor
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

@@ -24,6 +24,7 @@ struct Plan {
   float *A[4], *B[4], *CAT[4], *P[5], *C0, *C1;
   float *stats, *mean, *rstd;
   float *mean0, *rstd0;   // level-0 skip statistics: kept until the decoder normalises the skip half itself
+  float *meanS[4], *rstdS[4];   // (round 5) the same for the levels whose second contract conv leaves its RAW output in the skip half
   size_t bytes;
 };
 
@@ -66,6 +67,10 @@ static void make_plan(Plan& p, int N, int D, int H, int W, int F, char* base) {
   p.rstd = carve((size_t)N * p.lv[3].C);
   p.mean0 = carve((size_t)N * p.lv[0].C);
   p.rstd0 = carve((size_t)N * p.lv[0].C);
+  for (int l = 0; l < 4; ++l) {
+    p.meanS[l] = l == 0 ? p.mean0 : carve((size_t)N * p.lv[l].C);
+    p.rstdS[l] = l == 0 ? p.rstd0 : carve((size_t)N * p.lv[l].C);
+  }
   p.bytes = off;
 }
 }  // namespace
@@ -194,9 +199,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.out_split = osplit_ ? 1 : 0;       // expand_2_2 hands B_1 to the fused up-convolution as fp16 pairs
     a.up_split = (up_in && usplit_) ? 1 : 0;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
-    if (pool_raw_ && wi == 1) {   // contr_1_2 also leaves the window maxima of its block's MaxPool (dropout layer 1)
+    if (pool_raw_ && (wi & 1) && wi < 8) {   // contr_l_2 also leaves the window maxima of its block's MaxPool (dropout layer 2 l + 1 = wi)
       a.pool_out = pool_raw_; a.pool_flags = pool_flags_;
-      a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = 1;
+      a.drop_mode = dm; a.drop_seed = r->seed; a.drop_layer = (uint32_t)wi;
     }
     return vx_conv3d_k3(&a, stream);
   };
@@ -264,6 +269,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // fp16; needs the z-column kernels on both and the fused head
   const bool st16 = vx_cfg().storage16 && dm != VX_DROP_MASK && F == 8 && fuse_head && vx_cfg().conv_fp32 == 0 &&
                     vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F) && dm == VX_DROP_HASH;
+  bool skip_raw[4] = {false, false, false, false};   // level l: the skip half of CAT_l holds contr_l_2's RAW output (decoder normalises on load)
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
   const int ICH = w->in_channels > 1 ? w->in_channels : 1;
@@ -364,6 +370,28 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
         VX_STEP("pool:contr_1_2", norm(p.CAT[0], C, nullptr, 0, 0, p.P[1], L, 1, 1, 0, xblk_of(L.W), p.mean0, p.rstd0));
       continue;
     }
+    // Round 5 (levels below full resolution on the 16-channel z-column kernel, conv3d_zc16.hip): the level-0 data flow -- the
+    // second conv writes its RAW output straight into the skip half, leaves the (y, x) half of the block's MaxPool
+    // (window maxima of the kept raw values + any-dropped bits) next to it, vx_pool_finish_z produces P_{l+1} from a quarter
+    // of the voxels once the statistics exist, and the decoder's first conv of the level normalises the skip half on load.
+    // The normalise + pool pass over the whole tensor (0.25 ms per 320 samples at level 1) is gone.
+    if (l >= 1 && dm != VX_DROP_MASK && !vx_cfg().s16_no_prenorm && vx_cfg().s16_skip_raw &&
+        vx_conv3d_k3_pool_layout(L.D, L.H, L.W, C, C) == 2 && vx_conv3d_k3_skip_prologue_ok(L.D, L.H, L.W, 2 * C, C, xblk_of(L.W))) {
+      // B_l is free until the decoder: window maxima [N][D][H/2][W/2][C] + flag words [N][D][H/2][W/2][C/4]
+      pool_raw_ = p.B[l];
+      pool_flags_ = reinterpret_cast<uint32_t*>(p.B[l] + (size_t)N * (L.nvox / 4) * C);
+      VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.CAT[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep, nullptr,
+                                     nullptr, xblk_of(L.W)));
+      float* praw = pool_raw_;
+      uint32_t* pfl = pool_flags_;
+      pool_raw_ = nullptr; pool_flags_ = nullptr;
+      VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.meanS[l], p.rstdS[l], stream));
+      VX_STEP(l == 1 ? "poolfin:contr_2_2" : (l == 2 ? "poolfin:contr_3_2" : "poolfin:contr_4_2"),
+              vx_pool_finish_z(praw, pfl, p.meanS[l], p.rstdS[l], p.P[l + 1], C, N, L.D / 2, (int64_t)(L.H / 2) * (L.W / 2),
+                               dm == VX_DROP_HASH, stream));
+      skip_raw[l] = true;
+      continue;
+    }
     VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.B[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep));
     VX_STEP(kFin[2 * l + 1], vx_instnorm_finalize(p.stats, N, ntiles, C, L.nvox, 1e-5f, p.mean, p.rstd, stream));
     VX_STEP(kNorm[2 * l + 1], norm(p.B[l], C, p.CAT[l], 2 * C, C, p.P[l + 1], L, 2 * l + 1, 1, xblk_of(L.W)));
@@ -391,6 +419,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     else if (up_in)
       VX_STEP("upscale2+expand_1_1", conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr,
                                           xblk_of(L.W), -1, 1, nullptr, nullptr, 0, 0, up_in, 3, 2 * C));
+    else if (skip_raw[l])   // the skip half of CAT_l is contr_l_2's raw output: InstanceNorm + LeakyReLU + dropout layer 2 l + 1 on load
+      VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 2 * l + 1, 1,
+                              p.meanS[l], p.rstdS[l]));
     else
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W)));
     st16_ = (l == 0 && st16) ? 2 : 0;

@@ -95,6 +95,8 @@ typedef struct vx_config {
   int32_t s16_no_zc16;     /* the general tile kernels instead of the role-split z-column kernel (round 5, conv3d_zc16.hip) on the
                               Cout == 16 layers with Cin in {8, 16} and W % 32 == 0; with it the forward also keeps the separate
                               normalise + pool pass of the second contract block */
+  int32_t s16_no_halves;   /* expand_2_1 as ONE launch of the tile kernel over the x-blocked concat buffer instead of two launches of the
+                              16-channel z-column kernel over its halves (round 5, vx_conv3d_args.acc_in, vx_unet3d_weights.split_w) */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
   int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of
@@ -258,6 +260,13 @@ typedef struct vx_conv3d_args {
    * written.  in_repeat / in_split / in_drop_seed are not used.  Only with the plain epilogue of a contract block's first conv
    * (act NONE, no dropout, no head; Cout % 32 != 0): anything else is refused with VX_E_SHAPE. */
   const uint32_t* in_pool_flags;
+  /* PARTIAL SUMS (round 5; the 16-channel z-column kernel with an activation epilogue, vx_conv3d_k3_acc_ok): acc_in
+   * [N][D][H][W][acc_pitch] (channels [0, Cout)) is added to the conv's result BEFORE the activation / dropout, and `bias` is
+   * NOT added (it is part of the partial sums).  A conv over a channel concatenation = the sum of the convs over its parts: the
+   * decoder's first conv of level 1 runs as conv(skip half) + bias -> partial, then conv(up half) + partial -> activation
+   * (unet3D_module.py:332-356 without the concatenated tensor).  acc_in may alias `out` (every lane reads the pieces it writes). */
+  const float* acc_in;
+  int32_t acc_pitch;
 } vx_conv3d_args;
 int64_t vx_conv3d_upfused_packed_floats(void);
 /* w1_torch (8, 16, 3,3,3) + b1 (8): the decoder conv whose input channels [0, 8) are the up half; up_w_torch (16, 8, 2,2,2) +
@@ -273,6 +282,7 @@ int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx
 /* 1 if vx_conv3d_k3 takes in_mean for the SKIP half of an x-blocked concat input (in_xblk = xblk) of this layer: the decoder's
  * first conv of a level normalising the contract block's raw output on load (round 5: also the tile kernel, Cin % 32 == 0) */
 int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk);
+int vx_conv3d_k3_acc_ok(int D, int H, int W, int Cin, int Cout);      /* 1 if vx_conv3d_k3 takes acc_in for this layer */
 int vx_conv3d_k3_poolfuse_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes pool_out for this layer */
 int vx_conv3d_k3_presplit_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_split (vx_prenorm_split's output) for this layer */
 int vx_conv3d_k3_poolfin_ok(int Cin, int Cout);                       /* 1 if vx_conv3d_k3 takes in_pool_flags for this layer */
@@ -392,6 +402,11 @@ typedef struct vx_unet3d_weights {
   int32_t no_instancenorm; /* 1: do_instancenorm=False -- contract blocks are conv + LeakyReLU + Dropout (unet3D_module.py:238-243) */
   const float* up_fused;   /* nullable: vx_pack_conv3d_upfused(expand_1_1, upscale2) -- the level-0 up-convolution composed into
                               expand_1_1 (vx_conv3d_args.up_fused); NULL: evaluated per step by the staging waves (round 2) */
+  /* (round 5) nullable: expand_2_1's weights as TWO packed 16 -> 16 convs, [0] = input channels [0, 16) (the up half), [1] =
+   * channels [16, 32) (the skip half), each vx_pack_conv3d_k3(16, 16) of the contiguous slice: the layer then runs as two
+   * launches of the 16-channel z-column kernel (vx_conv3d_args.acc_in) without a concatenated tensor.  F = 8 networks only. */
+  const float* split_w[2];
+  int32_t split_family;    /* vx_conv3d_k3_family(16, 16) at pack time */
 } vx_unet3d_weights;
 
 typedef struct vx_unet3d_run {

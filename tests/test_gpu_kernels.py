@@ -1135,7 +1135,7 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
     # --- bias + statistics (EPI 0)
     out, st, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, stats=True)
-    assert kn == "conv3d_zc16_kernel<%d,0,0>" % cin, kn
+    assert kn == "conv3d_zc16_kernel<%d,0,0,0>" % cin, kn
     got = ncdhw(out).cpu()
     err = (got.double() - ref).abs().max().item()
     assert err < 4e-5, err
@@ -1145,13 +1145,13 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     # --- run-time activation (EPI 3)
     for act, fn in ((_lib.VX_ACT_LRELU, lambda t: F.leaky_relu(t, 0.01)), (_lib.VX_ACT_RELU, F.relu)):
         o2, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=act)
-        assert kn == "conv3d_zc16_kernel<%d,3,0>" % cin, kn
+        assert kn == "conv3d_zc16_kernel<%d,3,0,0>" % cin, kn
         assert (ncdhw(o2).cpu().double() - fn(ref)).abs().max().item() < 4e-5
     # --- LeakyReLU + hash dropout (EPI 1), plain / pre-split / x-blocked
     keep = _hash_mask(77, 13, n, 16, d, h, w)
     want = F.leaky_relu(ref, 0.01) * keep * 2.0
     o3, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13)
-    assert kn == "conv3d_zc16_kernel<%d,1,0>" % cin, kn
+    assert kn == "conv3d_zc16_kernel<%d,1,0,0>" % cin, kn
     assert (ncdhw(o3).cpu().double() - want).abs().max().item() < 4e-5
     o4, _, _, _ = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13, out_split=True)
     hl = o4.cpu().contiguous().view(torch.float16).view(n, d, h, w, 4, 2, 4).float()      # [quad][hi | lo][4]
@@ -1192,7 +1192,7 @@ def test_conv3d_zc16_prologue_and_pooled_output_match_oracle(shape, pmode, vxcfg
     pre = (mean, rstd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 61, 4)
     dmode = _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE
     out, st, pl, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre, pool=True, drop=dmode, seed=57, layer=5, out_xblk=4)
-    assert kn == "conv3d_zc16_kernel<16,4,1>", kn
+    assert kn == "conv3d_zc16_kernel<16,4,1,0>", kn
     got_cl = out.view(n, d, h, w // 4, 2, 4, 16)[:, :, :, :, 1].reshape(n, d, h, w, 16).contiguous()
     got = ncdhw(got_cl).cpu()
     err = (got.double() - ref).abs().max().item()
@@ -1201,7 +1201,7 @@ def test_conv3d_zc16_prologue_and_pooled_output_match_oracle(shape, pmode, vxcfg
     np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
     # the prologue without the pooled epilogue (EPI 0) gives the same output bits
     out0, _, _, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre)
-    assert kn == "conv3d_zc16_kernel<16,0,1>", kn
+    assert kn == "conv3d_zc16_kernel<16,0,1,0>", kn
     assert torch.equal(out0, got_cl)
     # pooled tensor: statistics of the conv's own float32 output, then the z pair + the normalisation
     mean2 = got.double().mean((2, 3, 4)).float().contiguous().to(dev())
@@ -1239,10 +1239,10 @@ def test_conv3d_zc16_pool_finish_on_load_is_pool_finish_then_conv(pmode, vxcfg):
                                   1 if pmode else 0, _lib.stream_ptr()), "vx_pool_finish")
     wt, b, wp, bd = _pack16(8, 722)
     o_sep, s_sep, _, kn = _zc16_launch(dense, 8, wp, bd, n, d, h, w, stats=True)
-    assert kn == "conv3d_zc16_kernel<8,0,0>", kn
+    assert kn == "conv3d_zc16_kernel<8,0,0,0>", kn
     o_fus, s_fus, _, kn = _zc16_launch(prd, 8, wp, bd, n, d, h, w, stats=True,
                                        poolfin=(mean, rstd, pfd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE))
-    assert kn == "conv3d_zc16_kernel<8,0,3>", kn
+    assert kn == "conv3d_zc16_kernel<8,0,3,0>", kn
     assert torch.isfinite(o_fus).all()
     assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
     ref = F.conv3d(ncdhw(dense).cpu().double(), wt.double(), b.double(), padding=1)
@@ -1298,3 +1298,62 @@ def test_conv3d_tile_kernel_prologue_on_the_skip_half_of_a_concat_input(shape, c
     torch.cuda.synchronize()
     want = ref * _hash_mask(9, 11, n, cout, d, h, w) * 2.0
     assert (ncdhw(out).cpu().double() - want).abs().max().item() < 8e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 32), (1, 4, 24, 64)])
+@pytest.mark.parametrize("pmode", [1, 0])
+def test_conv3d_zc16_partial_sums_two_launches_are_the_conv_over_the_concatenation(shape, pmode, vxcfg):
+    """expand_2_1 without a concatenated tensor (vx_conv3d_args.acc_in): conv(cat([up, skip])) = conv_skip(normalised skip) + bias
+    -> partial sums, then conv_up(up) + partial -> LeakyReLU -> dropout, IN PLACE -- against the float64 conv over the 32
+    concatenated channels (unet3D_module.py:332-356, 263-267)."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_acc_ok(d, h, w, 16, 16) == 1 and lib.vx_conv3d_k3_acc_ok(d, h, 16, 16, 16) == 0
+    up = torch.from_numpy(formula_tensor((n, 16, d, h, w), 741, scale=1.2)).float()
+    raw = (torch.from_numpy(formula_tensor((n, 16, d, h, w), 742, scale=2.0)) + 0.3).float()
+    wt = torch.from_numpy(formula_tensor((16, 32, 3, 3, 3), 743, scale=(1.0 / (27 * 32)) ** 0.5)).float().contiguous()
+    b = torch.from_numpy(formula_tensor((16,), 744, scale=0.2)).float().contiguous()
+    mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    keep_in = _hash_mask(61, 3, n, 16, d, h, w) if pmode else torch.ones((n, 16, d, h, w), dtype=torch.float64)
+    skip = F.leaky_relu((raw.double() - mean.cpu().double().view(n, 16, 1, 1, 1)) * rstd.cpu().double().view(n, 16, 1, 1, 1), 0.01)
+    skip = skip * keep_in * (2.0 if pmode else 1.0)
+    ref = F.leaky_relu(F.conv3d(torch.cat([up.double(), skip], 1), wt.double(), b.double(), padding=1), 0.01)
+    if pmode:
+        ref = ref * _hash_mask(9, 14, n, 16, d, h, w) * 2.0
+    bd = b.to(dev())
+    packed = []
+    for half in range(2):
+        part = wt[:, 16 * half:16 * half + 16].contiguous().to(dev())
+        pk = torch.empty(lib.vx_conv3d_k3_packed_floats(16, 16), dtype=torch.float32, device=dev())
+        _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(part), _lib.ptr(pk), 16, 16, _lib.stream_ptr()), "pack")
+        packed.append(pk)
+    upd, rawd = cl(up).to(dev()), cl(raw).to(dev())
+    out = torch.full((n, d, h, w, 16), -77.0, dtype=torch.float32, device=dev())
+
+    def args(x, pk):
+        a = _lib.ConvArgs()
+        a.w_family = lib.vx_conv3d_k3_family(16, 16)
+        a.in_ = x.data_ptr(); a.w_packed = pk.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+        a.in_pitch, a.out_pitch, a.out_coff = 16, 16, 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, 16, 16
+        return a
+    a1 = args(rawd, packed[1])
+    a1.in_mean, a1.in_rstd, a1.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1
+    a1.in_drop_mode, a1.in_drop_seed, a1.in_drop_layer = (_lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE), 61, 3
+    _lib.check(lib.vx_conv3d_k3(C.byref(a1), _lib.stream_ptr()), "vx_conv3d_k3 (skip half)")
+    assert lib.vx_last_kernel_name().decode() == "conv3d_zc16_kernel<16,3,1,0>"
+    a2 = args(upd, packed[0])
+    a2.act = _lib.VX_ACT_LRELU
+    if pmode:
+        a2.drop_mode, a2.drop_seed, a2.drop_layer = _lib.VX_DROP_HASH, 9, 14
+    a2.acc_in, a2.acc_pitch = out.data_ptr(), 16
+    _lib.check(lib.vx_conv3d_k3(C.byref(a2), _lib.stream_ptr()), "vx_conv3d_k3 (up half)")
+    torch.cuda.synchronize()
+    assert lib.vx_last_kernel_name().decode() == ("conv3d_zc16_kernel<16,1,0,1>" if pmode else "conv3d_zc16_kernel<16,3,0,1>")
+    err = (ncdhw(out).cpu().double() - ref).abs().max().item()
+    assert err < 8e-5, err
+    # refused where the z-column kernel does not run
+    vxcfg.set(s16_no_zc16=1)
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a2), _lib.stream_ptr()), "vx_conv3d_k3")

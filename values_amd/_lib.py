@@ -34,7 +34,8 @@ class ConvArgs(C.Structure):
                 ("in_repeat", _i32), ("out_xblk", _i32), ("out_half", _i32), ("range_flag", _p), ("seed_dev", _p),
                 ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
                 ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32),
-                ("out_split", _i32), ("up_split", _i32), ("up_fused", _p), ("in_pool_flags", _p)]
+                ("out_split", _i32), ("up_split", _i32), ("up_fused", _p), ("in_pool_flags", _p),
+                ("acc_in", _p), ("acc_pitch", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -84,7 +85,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw", "no_head_fusion", "s16_no_upfuse", "s16_no_poolfuse",
-        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "s16_no_zc16", "c2s_no_wide", "c2s_no_oct")]
+        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "s16_no_zc16", "s16_no_halves", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -95,7 +96,7 @@ class UncOutputs(C.Structure):
 class UNet3DWeights(C.Structure):
     _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
                 ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32), ("conv_family", _i32 * 18),
-                ("in_channels", _i32), ("no_instancenorm", _i32), ("up_fused", _p)]
+                ("in_channels", _i32), ("no_instancenorm", _i32), ("up_fused", _p), ("split_w", _p * 2), ("split_family", _i32)]
 
 
 class UNet3DRun(C.Structure):
@@ -139,6 +140,7 @@ SIGNATURES = {
     "vx_pool_finish_z": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
     "vx_conv3d_k3_pool_layout": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_skip_prologue_ok": (_i, [_i, _i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_acc_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),

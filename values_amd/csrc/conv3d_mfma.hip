@@ -647,6 +647,10 @@ extern "C" int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout) 
   return conv_config(Cin, Cout).S16 && vx_conv3d_s16_prologue_ok(Cin, Cout) ? 1 : 0;
 }
 
+extern "C" int vx_conv3d_k3_acc_ok(int D, int H, int W, int Cin, int Cout) {
+  return Cin == 16 && Cout == 16 && conv_config(Cin, Cout).S16 && vx_conv3d_zc16_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
 // in_mean on the SKIP half of an x-blocked concat input (the decoder's first conv reading a contract block's raw output)
 extern "C" int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk) {
   if (Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 8 || (xblk != 1 && xblk != 2 && xblk != 4)) return 0;
@@ -803,6 +807,8 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the input prologue / concat output / fused up-convolution are only available where "
             "vx_conv3d_k3_prologue_ok(D, H, W, Cin, Cout), with hash or no dropout (got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (a.up_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: up_split goes with the fused up-convolution (up_in)");
+  if (a.acc_in) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: partial sums (acc_in) are taken where vx_conv3d_k3_acc_ok (got %dx%dx%d, %d -> %d)",
+                        a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16) return vx_conv3d_k3_s16(a, s);
   if (a.out_split) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: out_split is an epilogue of the split-fp16 tile kernel");
   if (c.XP) return dispatch_tile_xp<8>(ka, t, s);

@@ -59,9 +59,13 @@ struct Zc16Args {
 // any-dropped bits of every 2 x 2 window of a z-plane; conv3d_xp8w.hip EPI 4 explains the monotonicity argument; the z
 // pair is finished by vx_pool_finish_z, which reads a quarter of the tensor's voxels).  PRE: 0 none, 1 InstanceNorm +
 // LeakyReLU + dropout of the producing block on load (CIN = 16), 3 pool-finish on load (CIN = 8: vx_conv3d_args.in_pool_flags).
-template <int CIN, int EPI, int PRE>
+// ACC: partial sums (vx_conv3d_args.acc_in) are added before the activation instead of the bias; a multiplying wave requests its
+// item's pieces when it starts the item's matrix loop and uses them in the item's epilogue (no branch around the loads, and
+// nothing else of that wave is in flight but the previous item's stores).
+template <int CIN, int EPI, int PRE, int ACC = 0>
 __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
   static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
+  static_assert(ACC == 0 || EPI == 1 || EPI == 3, "partial sums go with the activation epilogues");
   static_assert(PRE == 0 || (PRE == 1 && CIN == 16) || (PRE == 3 && CIN == 8), "prologues: normalise-on-load for 16, pool-finish for 8 channels");
   constexpr int NW = 8, NPW = 4, NTH = (NW + NPW) * 64;
   constexpr int TZ = 2, R = 4;
@@ -435,10 +439,24 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     const bool f_relu = EPI == 3 && a.act == VX_ACT_RELU;
 
     f32x4 acc[R], accx[R];
+    f32x4 accin[ACC ? R : 1];
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned avoff0 = ACC ? (unsigned)((((lz * a.H + ly0) * a.W + lx) * a.acc_pitch + oc) * 4) : 0u;
+    const unsigned arow = ACC ? (unsigned)(a.W * a.acc_pitch * 4) : 0u;
+    const size_t acc_sample = (size_t)a.D * a.H * a.W * (ACC ? a.acc_pitch : 0);
 
-    // the multiply phase of the item whose first input plane (z0 - 1) sits in slot rb
-    auto multiply = [&](int rb) {
+    // the multiply phase of the item whose first input plane (z0 - 1) sits in slot rb (item k of column ci)
+    auto multiply = [&](int rb, int ci, int k) {
+      if constexpr (ACC != 0) {
+        int n_, ty_, tx_;
+        col_of(ci, n_, ty_, tx_);
+        const unsigned asoff = (unsigned)(((k * TZ) * a.H + ty_ * 8) * a.W + tx_ * 32) * (unsigned)a.acc_pitch * 4u;
+        const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(const_cast<float*>(kernarg()->a.acc_in) + (size_t)n_ * acc_sample), 0, VX_NUMREC, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          accin[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrd, (int)avoff0, (int)(asoff + (unsigned)r * arow), 0));
+      }
       int sl[3];
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
           for (int r = 0; r < R; ++r) {
             const bool fresh = ph == 0 && ky == 0;      // the bias is the first product's C operand
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? (ACC ? zero : bias4) : acc[r], 0, 0, 0);
             accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
             accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
           }
@@ -500,6 +518,10 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaf(accx[r][j], 1.0f / 2048.f, acc[r][j]);
+        if constexpr (ACC != 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += accin[r][j];
+        }
         if (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
@@ -619,10 +641,10 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       if (late) {
         if (prev_ci >= 0 && !(ZC_ABL & 2)) { epilogue(prev_ci, prev_k); prev_ci = -1; }
         ZC_STAMP(2);
-        if (comp) { if (!(ZC_ABL & 1)) multiply(rb); prev_ci = cx.ci; prev_k = item_k; }
+        if (comp) { if (!(ZC_ABL & 1)) multiply(rb, cx.ci, item_k); prev_ci = cx.ci; prev_k = item_k; }
         ZC_STAMP(1);
       } else {
-        if (comp && !(ZC_ABL & 1)) multiply(rb);
+        if (comp && !(ZC_ABL & 1)) multiply(rb, cx.ci, item_k);
         ZC_STAMP(1);
         if (comp && !(ZC_ABL & 2)) epilogue(cx.ci, item_k);
         ZC_STAMP(2);
@@ -701,12 +723,12 @@ int vx_pack_conv3d_zc16(const float* w_torch, float* w_packed, int Cin, int Cout
   return VX_OK;
 }
 
-template <int CIN, int EPI, int PRE>
+template <int CIN, int EPI, int PRE, int ACC = 0>
 static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   constexpr int PP = ((6 * 340 + 15) / 16) * 16;
   constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 15 : 9) * 2048 + 8 * 16 * 2 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3d_zc16_kernel<CIN, EPI, PRE>;
+  auto kern = conv3d_zc16_kernel<CIN, EPI, PRE, ACC>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -715,7 +737,7 @@ static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   }
   int gx = 256;                // one persistent workgroup per CU
   if (gx > ka.ncols) gx = ka.ncols;
-  static const char* kname = vx_kname("conv3d_zc16_kernel<%d,%d,%d>", CIN, EPI, PRE);   // as rocprofv3 prints it
+  static const char* kname = vx_kname("conv3d_zc16_kernel<%d,%d,%d,%d>", CIN, EPI, PRE, ACC);   // as rocprofv3 prints it
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(768), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(zc16)");
@@ -756,6 +778,13 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
   else if (a.drop_mode == VX_DROP_HASH) { if (a.act != VX_ACT_LRELU) return 1; epi = 1; }
   else epi = 3;
   if (a.out_split && a.stats_partial) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): out_split goes with the activation epilogues");
+  if (a.acc_in) {
+    if (a.Cin != 16 || pre != 0 || a.stats_partial || a.acc_pitch < 16 || a.acc_pitch % 4 || !vx_aligned16(a.acc_in))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): partial sums (acc_in) go with 16 -> 16, no prologue, an activation epilogue, a "
+              "16-byte aligned tensor of pitch >= 16 (pitch %d)", a.acc_pitch);
+    if (epi == 1) return launch_zc16<16, 1, 0, 1>(ka, s);
+    return launch_zc16<16, 3, 0, 1>(ka, s);
+  }
 #define ZC16_CASE(C_, E_, P_) if (a.Cin == C_ && epi == E_ && pre == P_) return launch_zc16<C_, E_, P_>(ka, s)
   ZC16_CASE(16, 0, 0); ZC16_CASE(16, 0, 1); ZC16_CASE(16, 4, 0); ZC16_CASE(16, 4, 1);
   ZC16_CASE(16, 1, 0); ZC16_CASE(16, 1, 1); ZC16_CASE(16, 3, 0); ZC16_CASE(16, 3, 1);

@@ -225,11 +225,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     return vx_norm_act_drop_pool_bcast(&a, x_repeat, stream);
   };
   auto convT = [&](const float* in, int ui, float* out, int out_pitch, const Level& Lin, int Cin, int Cout, int act,
-                   int drop_layer) {
+                   int drop_layer, bool dense = false) {
     vx_convT_args a = {};
     a.range_flag = r->range_flag;
     a.seed_dev = r->seed_dev;
-    a.out_xblk = xblk_of(2 * Lin.W); a.out_half = 0;
+    a.out_xblk = dense ? 0 : xblk_of(2 * Lin.W); a.out_half = 0;
     a.in = in; a.in_pitch = Cin; a.w_packed = w->up_w[ui]; a.bias = w->up_b[ui];
     a.out = out; a.out_pitch = out_pitch; a.out_coff = 0;
     a.N = N; a.D = Lin.D; a.H = Lin.H; a.W = Lin.W; a.Cin = Cin; a.Cout = Cout;
@@ -270,6 +270,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   const bool st16 = vx_cfg().storage16 && dm != VX_DROP_MASK && F == 8 && fuse_head && vx_cfg().conv_fp32 == 0 &&
                     vx_conv3d_k3_prologue_ok(p.lv[0].D, p.lv[0].H, p.lv[0].W, F, F) && dm == VX_DROP_HASH;
   bool skip_raw[4] = {false, false, false, false};   // level l: the skip half of CAT_l holds contr_l_2's RAW output (decoder normalises on load)
+  // level l: CAT_l is used as TWO DENSE tensors (up = first half of the buffer, skip = second) and expand_l_1 runs as two
+  // launches of the 16-channel z-column kernel over them (vx_conv3d_args.acc_in) -- level 1 of the F = 8 networks
+  bool halves[4] = {false, false, false, false};
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
   const int ICH = w->in_channels > 1 ? w->in_channels : 1;
@@ -380,6 +383,12 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       // B_l is free until the decoder: window maxima [N][D][H/2][W/2][C] + flag words [N][D][H/2][W/2][C/4]
       pool_raw_ = p.B[l];
       pool_flags_ = reinterpret_cast<uint32_t*>(p.B[l] + (size_t)N * (L.nvox / 4) * C);
+      halves[l] = l == 1 && C == 16 && w->split_w[0] && w->split_w[1] && !vx_cfg().s16_no_halves &&
+                  w->split_family == vx_conv3d_k3_family(16, 16) && vx_conv3d_k3_acc_ok(L.D, L.H, L.W, C, C);
+      if (halves[l])
+        VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.CAT[l] + (size_t)N * L.nvox * C, C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0,
+                                       pre_layer, pre_rep));
+      else
       VX_STEP(kConv[2 * l + 1], conv(in2, C, 2 * l + 1, p.CAT[l], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep, nullptr,
                                      nullptr, xblk_of(L.W)));
       float* praw = pool_raw_;
@@ -419,6 +428,25 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     else if (up_in)
       VX_STEP("upscale2+expand_1_1", conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr,
                                           xblk_of(L.W), -1, 1, nullptr, nullptr, 0, 0, up_in, 3, 2 * C));
+    else if (halves[l]) {
+      // conv(cat([up, skip])) = conv_up(up) + conv_skip(skip) + bias, as two launches of the 16-channel z-column kernel over the two
+      // DENSE halves: (1) the skip half, normalised on load (InstanceNorm + LeakyReLU + dropout layer 2 l + 1), + bias -> partial
+      // sums in A_l; (2) the up half + the partial sums -> LeakyReLU -> dropout -> A_l in place.  The tile kernel's launch over the
+      // x-blocked buffer paid 0.17 ms for the prologue in waves that also multiply (1.02 ms; the two launches: see DESIGN 5e).
+      vx_conv3d_args a1 = {};
+      a1.in = p.CAT[l] + (size_t)N * L.nvox * C; a1.w_packed = w->split_w[1]; a1.bias = w->conv_b[wi]; a1.out = p.A[l];
+      a1.in_pitch = C; a1.out_pitch = C; a1.N = N; a1.D = L.D; a1.H = L.H; a1.W = L.W; a1.Cin = C; a1.Cout = C;
+      a1.act = VX_ACT_NONE; a1.drop_mode = VX_DROP_NONE; a1.w_family = w->split_family;
+      a1.in_mean = p.meanS[l]; a1.in_rstd = p.rstdS[l]; a1.in_drop_mode = dm; a1.in_drop_seed = r->seed; a1.in_drop_layer = (uint32_t)(2 * l + 1);
+      a1.in_repeat = 1; a1.seed_dev = r->seed_dev; a1.out_half = 1;
+      VX_STEP("expand_2_1(skip half)", vx_conv3d_k3(&a1, stream));
+      vx_conv3d_args a2 = {};
+      a2.in = p.CAT[l]; a2.w_packed = w->split_w[0]; a2.bias = w->conv_b[wi]; a2.out = p.A[l];
+      a2.in_pitch = C; a2.out_pitch = C; a2.N = N; a2.D = L.D; a2.H = L.H; a2.W = L.W; a2.Cin = C; a2.Cout = C;
+      a2.act = VX_ACT_LRELU; a2.drop_mode = dm; a2.drop_seed = r->seed; a2.drop_layer = (uint32_t)dl; a2.w_family = w->split_family;
+      a2.acc_in = p.A[l]; a2.acc_pitch = C; a2.seed_dev = r->seed_dev; a2.range_flag = r->range_flag; a2.out_half = 1;
+      VX_STEP("expand_2_1(up half)", vx_conv3d_k3(&a2, stream));
+    }
     else if (skip_raw[l])   // the skip half of CAT_l is contr_l_2's raw output: InstanceNorm + LeakyReLU + dropout layer 2 l + 1 on load
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 2 * l + 1, 1,
                               p.meanS[l], p.rstdS[l]));
@@ -431,7 +459,8 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     st16_ = 0;
     osplit_ = false;
-    if (l > 1 || (l == 1 && !fuse_up)) VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], C, L, C, C / 2, VX_ACT_NONE, -1));
+    if (l > 1 || (l == 1 && !fuse_up))
+      VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], halves[l - 1] ? C / 2 : C, L, C, C / 2, VX_ACT_NONE, -1, halves[l - 1]));
   }
   // ---------------- head ----------------
   if (!fuse_head)

@@ -151,6 +151,15 @@ class UNet3D(nn.Module):
                        "vx_pack_conv3d_upfused")
             keep.append(uf)
             w.up_fused = uf.data_ptr()
+            # (round 5) expand_2_1 as two 16 -> 16 convs over the halves of its input (vx_unet3d_weights.split_w)
+            w2 = sd["expand_2_1.0.weight"]
+            for hidx in range(2):
+                part = w2[:, 16 * hidx:16 * (hidx + 1)].contiguous()
+                pk = torch.empty(lib.vx_conv3d_k3_packed_floats(16, 16), dtype=torch.float32, device=device)
+                _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(part), _lib.ptr(pk), 16, 16, st), "vx_pack_conv3d_k3 (expand_2_1 half)")
+                keep += [part, pk]
+                w.split_w[hidx] = pk.data_ptr()
+            w.split_family = lib.vx_conv3d_k3_family(16, 16)
         fw, fb = self._head_params(sd)
         keep += [fw, fb]
         w.final_w = fw.data_ptr()

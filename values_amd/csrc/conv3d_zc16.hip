@@ -89,6 +89,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
   unsigned char* s_img = smem_raw;
   unsigned char* s_w = smem_raw + IMG_B;
   float* s_red = reinterpret_cast<float*>(smem_raw + IMG_B + W_B);     // [NW][16][2]
+  float* s_bias = s_red + NW * 16 * 2;                                 // [16]: re-read per item (4 registers less across the epilogue)
 
   const vx_conv3d_args& a = ka.a;
   auto kernarg = [&]() {      // fields used once per item / column are re-read where they are used (conv3d_xp8w.hip)
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(ka.w);
     for (int i = tid; i < W_B / 16; i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+    if (tid < 16) s_bias[tid] = a.bias[tid];
   }
   // the image starts as zeros: a zero-weight k-group (Cin = 16: steps 12..14; Cin = 8: the fourth group) multiplies whatever
   // sits at the position it reads, which must be finite from the first item on
@@ -430,11 +432,8 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       const int rr_ = (lane >> 3) < R ? (lane >> 3) : 0;
       hword_l = (unsigned)((((lz * a.H + ly0 + rr_) * a.W + x0) >> 1) + (lane & 7));
     }
-    const int hbp = 4 * (m >> 1);
-    const unsigned hsh = (unsigned)((m & 1) * 16 + oc);
     const int out_voxf = a.out_xblk ? 32 : a.out_pitch;
     const size_t out_sample = (size_t)a.D * a.H * a.W * out_voxf;
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + oc);
     const bool f_lrelu = EPI == 3 ? a.act == VX_ACT_LRELU : EPI == 1;
     const bool f_relu = EPI == 3 && a.act == VX_ACT_RELU;
 
@@ -457,6 +456,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         for (int r = 0; r < R; ++r)
           accin[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrd, (int)avoff0, (int)(asoff + (unsigned)r * arow), 0));
       }
+      const f32x4 bias4 = *reinterpret_cast<const f32x4*>(s_bias + oc);
       int sl[3];
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
@@ -465,6 +465,62 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         sl[kz] = s_ * PLN_B;
       }
       constexpr int NPH = CIN == 16 ? 5 : 3;
+#ifndef ZC_NO_PIPE
+      if constexpr (!POOL)      // (the pooling instance holds 8 statistics registers + its window state across the loop: 168 + scratch)
+      // ONE software pipeline over the NSTEP K-steps, 12 matrix instructions each.  Left alone hipcc sinks every ds_read_b128 to
+      // just before its consumer (ds_read; s_waitcnt lgkmcnt(0..1); v_mfma: an exposed LDS latency per weight pair and per row
+      // group -- ~1 500 of ~4 400 cycles per item in the ISA of the first version).  Here every step requests, behind its own matrix
+      // instructions and pinned there (sched_group_barrier), exactly six fragments of LATER steps:
+      //   step (phase p, ky = 0): the weights of (p, 1) + rows 4, 5 of phase p          (needed at ky = 1 / ky = 2)
+      //   step (p, 1):            the weights of (p, 2) + rows 0, 1 of phase p + 1
+      //   step (p, 2):            the weights of (p + 1, 0) + rows 2, 3 of phase p + 1
+      // -- 0.5 reads per matrix instruction, uniformly; at most 8 row fragments + 2 weight pairs live (112 VGPRs with the
+      // accumulators).
+      {
+        const unsigned char* rowp[NPH];
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          if (ph < 3) rowp[ph] = s_img + bP + sl[ph];
+          else if (ph == 3) rowp[ph] = s_img + bQ + ((g >> 1) ? sl[1] : sl[0]);
+          else rowp[ph] = s_img + bQ + sl[2];
+        }
+        f16x8 rh[NPH][R + 2], rl[NPH][R + 2], wh[NSTEP], wl[NSTEP];
+        auto ld_row = [&](int ph, int jr) {
+          rh[ph][jr] = *reinterpret_cast<const f16x8*>(rowp[ph] + jr * ROW_B);
+          rl[ph][jr] = *reinterpret_cast<const f16x8*>(rowp[ph] + jr * ROW_B + PREC_B);
+        };
+        auto ld_w = [&](int t) {
+          wh[t] = *reinterpret_cast<const f16x8*>(wlane + t * 2048);
+          wl[t] = *reinterpret_cast<const f16x8*>(wlane + t * 2048 + 1024);
+        };
+        ld_w(0);
+#pragma unroll
+        for (int jr = 0; jr < R; ++jr) ld_row(0, jr);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 + 2 * R, 0);      // (+ the bias vector)
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+          const int ph = t / 3, ky = t % 3;
+          int nrd = 0;
+          if (t + 1 < NSTEP) { ld_w(t + 1); nrd += 2; }
+          if (ky == 0) { ld_row(ph, R); ld_row(ph, R + 1); nrd += 4; }
+          else if (ph + 1 < NPH) { ld_row(ph + 1, 2 * (ky - 1)); ld_row(ph + 1, 2 * (ky - 1) + 1); nrd += 4; }
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const bool fresh = t == 0;      // the bias is the first product's C operand
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], rh[ph][r + ky], fresh ? (ACC ? zero : bias4) : acc[r], 0, 0, 0);
+            accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], rl[ph][r + ky], fresh ? zero : accx[r], 0, 0, 0);
+            accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], rh[ph][r + ky], accx[r], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 3 * R; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        return;
+      }
+#endif
 #pragma unroll
       for (int ph = 0; ph < NPH; ++ph) {
         const unsigned char* row0;
@@ -507,12 +563,21 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       const unsigned vox0 = (unsigned)(((k * TZ) * a.H + e_ty * 8) * a.W + e_tx * 32);
       const unsigned osoff = a.out_xblk ? (unsigned)((((k * TZ) * a.H + e_ty * 8) * (2 * a.W * 16) + e_tx * 32 * 32) * 4)
                                         : vox0 * (unsigned)a.out_pitch * 4u;
+      const int hbp = 4 * (m >> 1);                               // (recomputed per item: two registers less across the matrix loop)
+      const unsigned hsh = (unsigned)((m & 1) * 16 + oc);
       const bool e_hash = (EPI == 1) || (EPI == 4 && a.drop_mode == VX_DROP_HASH);
       const uint32_t hw_item = e_hash ? vx_mix32(((vox0 >> 1) + hword_l) ^ e_key) : 0u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * 4), 0, VX_NUMREC, 0x00020000);
       float pl_max[4];
       uint32_t pl_any = 0u;
+      __amdgpu_buffer_rsrc_t psrd = osrd, fsrd = osrd;
+      if constexpr (POOL) {
+        const auto kp = kernarg();
+        const size_t pvs = (size_t)a.D * (a.H >> 1) * (a.W >> 1);      // pooled (y, x) voxels per sample
+        psrd = __builtin_amdgcn_make_buffer_rsrc((void*)(kp->a.pool_out + (size_t)e_n * pvs * 16), 0, VX_NUMREC, 0x00020000);
+        fsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(kp->a.pool_flags + (size_t)e_n * pvs * 4), 0, VX_NUMREC, 0x00020000);
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling)
@@ -567,21 +632,24 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         if constexpr (POOL) {
           if (r & 1) {
             // a row pair is complete.  The x-neighbour (same channels) is the adjacent lane: quad_perm [1, 0, 3, 2]; even lanes
-            // store the window of their z-plane: pool_out [N][D][H/2][W/2][16], pool_flags [N][D][H/2][W/2][4]
-            const auto kp = kernarg();
+            // store the window of their z-plane: pool_out [N][D][H/2][W/2][16], pool_flags [N][D][H/2][W/2][4] (the flag word of a
+            // 16-byte piece sits at a quarter of the piece's byte offset); odd lanes are steered out of the descriptor's range
             const int Hp = a.H >> 1, Wp = a.W >> 1;
-            f32x4 mx;
+            u32x4 mx;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(pl_max[j]), 0xB1, 0xF, 0xF, true);
-              mx[j] = fmaxf(pl_max[j], __int_as_float(o));
+              mx[j] = __float_as_uint(fmaxf(pl_max[j], __int_as_float(o)));
             }
             const uint32_t oany = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pl_any, 0xB1, 0xF, 0xF, true);
-            if (!(m & 1)) {
-              const size_t pv = (((size_t)e_n * a.D + (k * TZ + lz)) * Hp + ((e_ty * 8 + ly0) >> 1) + (r >> 1)) * Wp + ((e_tx * 32 + lx) >> 1);
-              *reinterpret_cast<f32x4*>(kp->a.pool_out + pv * 16 + oc) = mx;
-              kp->a.pool_flags[pv * 4 + g] = pl_any | oany;
-            }
+            // lane part: ((lz Hp + ly0 / 2) Wp + lx / 2) 64 + 16 g bytes; scalar part: item, column, row pair
+            const unsigned pvo = (m & 1) ? VX_OOB : (unsigned)((((lz * Hp + (ly0 >> 1)) * Wp + (lx >> 1)) * 16 + oc) * 4);
+            const unsigned pso = (unsigned)(((((k * TZ) * Hp + e_ty * 4 + (r >> 1)) * Wp) + e_tx * 16) * 64);
+            __builtin_amdgcn_raw_buffer_store_b128(mx, psrd, (int)pvo, (int)pso, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(pl_any | oany, fsrd, (int)((m & 1) ? VX_OOB : (pvo >> 2)), (int)(pso >> 2), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 3" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -726,7 +794,7 @@ int vx_pack_conv3d_zc16(const float* w_torch, float* w_packed, int Cin, int Cout
 template <int CIN, int EPI, int PRE, int ACC = 0>
 static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   constexpr int PP = ((6 * 340 + 15) / 16) * 16;
-  constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 15 : 9) * 2048 + 8 * 16 * 2 * 4;
+  constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 15 : 9) * 2048 + 8 * 16 * 2 * 4 + 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv3d_zc16_kernel<CIN, EPI, PRE, ACC>;
   static bool attr = false;

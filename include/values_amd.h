@@ -278,7 +278,12 @@ int64_t vx_conv3d_upfused_packed_floats(void);
 int vx_pack_conv3d_upfused(const float* w1_torch, const float* b1, const float* up_w_torch, const float* up_b, float* packed,
                            vx_stream_t stream);
 int vx_conv3d_k3_prologue_ok(int D, int H, int W, int Cin, int Cout); /* 1 if vx_conv3d_k3 takes in_mean for this layer */
-int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* 1 if vx_conv3d_k3 takes up_in for this layer */
+int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout);   /* != 0 if vx_conv3d_k3 takes up_in for this layer: 1 the form
+   above (16 -> 8 at full resolution); 2 (round 5, the 16-channel z-column kernel): ALL 16 input channels are
+   ConvTranspose3d(32 -> 16, k = 2, s = 2)(up_in) + up_b, evaluated while the tiles are staged -- `in` is not read, up_in is
+   [N][D/2][H/2][W/2][up_pitch >= 32], up_w the output of vx_pack_convT_zc16, up_split as above; combines with acc_in */
+int64_t vx_convT_zc16_packed_floats(void);
+int vx_pack_convT_zc16(const float* w_torch /* (32, 16, 2,2,2) */, float* packed, vx_stream_t stream);
 /* 1 if vx_conv3d_k3 takes in_mean for the SKIP half of an x-blocked concat input (in_xblk = xblk) of this layer: the decoder's
  * first conv of a level normalising the contract block's raw output on load (round 5: also the tile kernel, Cin % 32 == 0) */
 int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk);
@@ -407,6 +412,7 @@ typedef struct vx_unet3d_weights {
    * launches of the 16-channel z-column kernel (vx_conv3d_args.acc_in) without a concatenated tensor.  F = 8 networks only. */
   const float* split_w[2];
   int32_t split_family;    /* vx_conv3d_k3_family(16, 16) at pack time */
+  const float* up3_zc16;   /* nullable: vx_pack_convT_zc16(upscale3): the up half's launch evaluates the transposed conv itself */
 } vx_unet3d_weights;
 
 typedef struct vx_unet3d_run {

@@ -1135,7 +1135,7 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
     # --- bias + statistics (EPI 0)
     out, st, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, stats=True)
-    assert kn == "conv3d_zc16_kernel<%d,0,0,0>" % cin, kn
+    assert kn == "conv3d_zc16_kernel<%d,0,0,0,0>" % cin, kn
     got = ncdhw(out).cpu()
     err = (got.double() - ref).abs().max().item()
     assert err < 4e-5, err
@@ -1145,13 +1145,13 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     # --- run-time activation (EPI 3)
     for act, fn in ((_lib.VX_ACT_LRELU, lambda t: F.leaky_relu(t, 0.01)), (_lib.VX_ACT_RELU, F.relu)):
         o2, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=act)
-        assert kn == "conv3d_zc16_kernel<%d,3,0,0>" % cin, kn
+        assert kn == "conv3d_zc16_kernel<%d,3,0,0,0>" % cin, kn
         assert (ncdhw(o2).cpu().double() - fn(ref)).abs().max().item() < 4e-5
     # --- LeakyReLU + hash dropout (EPI 1), plain / pre-split / x-blocked
     keep = _hash_mask(77, 13, n, 16, d, h, w)
     want = F.leaky_relu(ref, 0.01) * keep * 2.0
     o3, _, _, kn = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13)
-    assert kn == "conv3d_zc16_kernel<%d,1,0,0>" % cin, kn
+    assert kn == "conv3d_zc16_kernel<%d,1,0,0,0>" % cin, kn
     assert (ncdhw(o3).cpu().double() - want).abs().max().item() < 4e-5
     o4, _, _, _ = _zc16_launch(xd, cin, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13, out_split=True)
     hl = o4.cpu().contiguous().view(torch.float16).view(n, d, h, w, 4, 2, 4).float()      # [quad][hi | lo][4]
@@ -1192,7 +1192,7 @@ def test_conv3d_zc16_prologue_and_pooled_output_match_oracle(shape, pmode, vxcfg
     pre = (mean, rstd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 61, 4)
     dmode = _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE
     out, st, pl, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre, pool=True, drop=dmode, seed=57, layer=5, out_xblk=4)
-    assert kn == "conv3d_zc16_kernel<16,4,1,0>", kn
+    assert kn == "conv3d_zc16_kernel<16,4,1,0,0>", kn
     got_cl = out.view(n, d, h, w // 4, 2, 4, 16)[:, :, :, :, 1].reshape(n, d, h, w, 16).contiguous()
     got = ncdhw(got_cl).cpu()
     err = (got.double() - ref).abs().max().item()
@@ -1201,7 +1201,7 @@ def test_conv3d_zc16_prologue_and_pooled_output_match_oracle(shape, pmode, vxcfg
     np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
     # the prologue without the pooled epilogue (EPI 0) gives the same output bits
     out0, _, _, kn = _zc16_launch(xd, 16, wp, bd, n, d, h, w, stats=True, pre=pre)
-    assert kn == "conv3d_zc16_kernel<16,0,1,0>", kn
+    assert kn == "conv3d_zc16_kernel<16,0,1,0,0>", kn
     assert torch.equal(out0, got_cl)
     # pooled tensor: statistics of the conv's own float32 output, then the z pair + the normalisation
     mean2 = got.double().mean((2, 3, 4)).float().contiguous().to(dev())
@@ -1239,10 +1239,10 @@ def test_conv3d_zc16_pool_finish_on_load_is_pool_finish_then_conv(pmode, vxcfg):
                                   1 if pmode else 0, _lib.stream_ptr()), "vx_pool_finish")
     wt, b, wp, bd = _pack16(8, 722)
     o_sep, s_sep, _, kn = _zc16_launch(dense, 8, wp, bd, n, d, h, w, stats=True)
-    assert kn == "conv3d_zc16_kernel<8,0,0,0>", kn
+    assert kn == "conv3d_zc16_kernel<8,0,0,0,0>", kn
     o_fus, s_fus, _, kn = _zc16_launch(prd, 8, wp, bd, n, d, h, w, stats=True,
                                        poolfin=(mean, rstd, pfd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE))
-    assert kn == "conv3d_zc16_kernel<8,0,3,0>", kn
+    assert kn == "conv3d_zc16_kernel<8,0,3,0,0>", kn
     assert torch.isfinite(o_fus).all()
     assert torch.equal(o_sep, o_fus) and torch.equal(s_sep, s_fus)
     ref = F.conv3d(ncdhw(dense).cpu().double(), wt.double(), b.double(), padding=1)
@@ -1342,7 +1342,7 @@ def test_conv3d_zc16_partial_sums_two_launches_are_the_conv_over_the_concatenati
     a1.in_mean, a1.in_rstd, a1.in_repeat = mean.data_ptr(), rstd.data_ptr(), 1
     a1.in_drop_mode, a1.in_drop_seed, a1.in_drop_layer = (_lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE), 61, 3
     _lib.check(lib.vx_conv3d_k3(C.byref(a1), _lib.stream_ptr()), "vx_conv3d_k3 (skip half)")
-    assert lib.vx_last_kernel_name().decode() == "conv3d_zc16_kernel<16,3,1,0>"
+    assert lib.vx_last_kernel_name().decode() == "conv3d_zc16_kernel<16,3,1,0,0>"
     a2 = args(upd, packed[0])
     a2.act = _lib.VX_ACT_LRELU
     if pmode:
@@ -1350,10 +1350,62 @@ def test_conv3d_zc16_partial_sums_two_launches_are_the_conv_over_the_concatenati
     a2.acc_in, a2.acc_pitch = out.data_ptr(), 16
     _lib.check(lib.vx_conv3d_k3(C.byref(a2), _lib.stream_ptr()), "vx_conv3d_k3 (up half)")
     torch.cuda.synchronize()
-    assert lib.vx_last_kernel_name().decode() == ("conv3d_zc16_kernel<16,1,0,1>" if pmode else "conv3d_zc16_kernel<16,3,0,1>")
+    assert lib.vx_last_kernel_name().decode() == ("conv3d_zc16_kernel<16,1,0,1,0>" if pmode else "conv3d_zc16_kernel<16,3,0,1,0>")
     err = (ncdhw(out).cpu().double() - ref).abs().max().item()
     assert err < 8e-5, err
     # refused where the z-column kernel does not run
     vxcfg.set(s16_no_zc16=1)
     with pytest.raises(_lib.VxError):
         _lib.check(lib.vx_conv3d_k3(C.byref(a2), _lib.stream_ptr()), "vx_conv3d_k3")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 32), (1, 4, 24, 64)])
+@pytest.mark.parametrize("split", [0, 1])
+def test_conv3d_zc16_fused_upconvolution_matches_oracle(shape, split, vxcfg):
+    """upscale3 inside expand_2_1's up-half launch (vx_conv3d_k3_upfuse_ok == 2): the 16 input channels are
+    ConvTranspose3d(32 -> 16, k = 2, s = 2) of the coarse tensor, evaluated by the staging waves (plain and pre-split coarse
+    tensor), with and without partial sums, LeakyReLU + hash dropout -- against the float64 oracle
+    (unet3D_module.py:157-190, 263-267, 332-356); every border class of the coarse window (first / last column tile in x and y,
+    first / last step in z)."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_upfuse_ok(d, h, w, 16, 16) == 2
+    coarse = torch.from_numpy(formula_tensor((n, 32, d // 2, h // 2, w // 2), 751, scale=1.3)).float()
+    uw = torch.from_numpy(formula_tensor((32, 16, 2, 2, 2), 752, scale=(1.0 / 32) ** 0.5)).float().contiguous()
+    ub = torch.from_numpy(formula_tensor((16,), 753, scale=0.3)).float().contiguous()
+    wt, b, wp, bd = _pack16(16, 754)
+    part = torch.from_numpy(formula_tensor((n, 16, d, h, w), 755, scale=0.7)).float()
+    up = F.conv_transpose3d(coarse.double(), uw.double(), ub.double(), stride=2)
+    conv = F.conv3d(up, wt.double(), None, padding=1)
+    keep = _hash_mask(9, 14, n, 16, d, h, w)
+    uwp = torch.empty(lib.vx_convT_zc16_packed_floats(), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_convT_zc16(_lib.ptr(uw.to(dev())), _lib.ptr(uwp), _lib.stream_ptr()), "vx_pack_convT_zc16")
+    ubd = ub.to(dev())
+    cd = cl(coarse).to(dev())
+    if split:
+        v = cd.reshape(-1, 4)
+        hi = v.half()
+        lo = ((v - hi.float()) * 2048.0).half()
+        cd = torch.cat([hi, lo], 1).view(torch.float32).reshape(cd.shape).contiguous()
+    for acc in (0, 1):
+        out = cl(part).to(dev()).contiguous() if acc else torch.full((n, d, h, w, 16), -77.0, dtype=torch.float32, device=dev())
+        a = _lib.ConvArgs()
+        a.w_family = lib.vx_conv3d_k3_family(16, 16)
+        a.in_ = cd.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+        a.in_pitch, a.out_pitch, a.out_coff = 16, 16, 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, 16, 16
+        a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 9, 14
+        a.up_in, a.up_w, a.up_b, a.up_pitch, a.up_split = cd.data_ptr(), uwp.data_ptr(), ubd.data_ptr(), 32, split
+        if acc:
+            a.acc_in, a.acc_pitch = out.data_ptr(), 16
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3 (fused up-convolution)")
+        torch.cuda.synchronize()
+        assert lib.vx_last_kernel_name().decode() == "conv3d_zc16_kernel<16,1,0,%d,1>" % acc
+        pre_act = conv + (part.double() if acc else b.double().view(1, 16, 1, 1, 1))
+        ref = F.leaky_relu(pre_act, 0.01) * keep * 2.0
+        err = (ncdhw(out).cpu().double() - ref).abs().max().item()
+        assert err < 8e-5, (acc, err)
+    vxcfg.set(s16_no_upfuse=1)
+    assert lib.vx_conv3d_k3_upfuse_ok(d, h, w, 16, 16) == 0
+    with pytest.raises(_lib.VxError):
+        _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")

@@ -507,13 +507,18 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     from values_amd import _lib
     import bench
     names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
-    assert any(n.startswith("conv3d_zc16_kernel<16,4,1,0>") for n in names) and any(n.startswith("conv3d_zc16_kernel<8,0,3,0>") for n in names), names
-    assert any(n.startswith("pool_finish_z_kernel") for n in names) and len(names) <= 34
-    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1>") for n in names), names       # expand_2_1 as two launches over its halves
+    assert any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names) and any(n.startswith("conv3d_zc16_kernel<8,0,3,0,0>") for n in names), names
+    assert any(n.startswith("pool_finish_z_kernel") for n in names) and len(names) <= 33
+    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names), names       # expand_2_1 as two launches over its halves, upscale3 inside
+    assert not any(n.startswith("convT_k2s2_mfma_kernel<32,") for n in names), names           # (no upscale3 launch)
+    with _lib.config(s16_no_upfuse=1):       # ... separate upscale launches (upscale2 and upscale3)
+        sep = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    assert np.abs(sep["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
+    assert (sep["logits"] - out["logits"]).abs().max().item() < 3e-5
     with _lib.config(s16_no_halves=1):       # ... or as one launch of the tile kernel over the x-blocked buffer (skip half normalised on load)
         one = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
         names1 = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
-    assert not any(n.startswith("conv3d_zc16_kernel<16,1,0,1>") for n in names1) and len(names1) == len(names) - 1
+    assert not any(n.startswith("conv3d_zc16_kernel<16,1,0,1,") for n in names1) and len(names1) == len(names)    # (+ upscale3, - one half)
     assert np.abs(one["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
     assert (one["logits"] - out["logits"]).abs().max().item() < 2e-5
     with _lib.config(s16_no_zc16=1):

@@ -96,7 +96,7 @@ class UncOutputs(C.Structure):
 class UNet3DWeights(C.Structure):
     _fields_ = [("conv_w", _p * 18), ("conv_b", _p * 18), ("up_w", _p * 4), ("up_b", _p * 4),
                 ("final_w", _p), ("final_b", _p), ("F", _i32), ("num_classes", _i32), ("conv_family", _i32 * 18),
-                ("in_channels", _i32), ("no_instancenorm", _i32), ("up_fused", _p), ("split_w", _p * 2), ("split_family", _i32)]
+                ("in_channels", _i32), ("no_instancenorm", _i32), ("up_fused", _p), ("split_w", _p * 2), ("split_family", _i32), ("up3_zc16", _p)]
 
 
 class UNet3DRun(C.Structure):
@@ -141,6 +141,8 @@ SIGNATURES = {
     "vx_conv3d_k3_pool_layout": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_skip_prologue_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "vx_conv3d_k3_acc_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_convT_zc16_packed_floats": (_i64, []),
+    "vx_pack_convT_zc16": (_i, [_p, _p, _p]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),

@@ -662,7 +662,12 @@ extern "C" int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int C
 }
 
 extern "C" int vx_conv3d_k3_upfuse_ok(int D, int H, int W, int Cin, int Cout) {
-  return Cin == 16 && !vx_cfg().s16_no_upfuse && vx_conv3d_xp8_applies(D, H, W, Cin, Cout) ? 1 : 0;
+  if (vx_cfg().s16_no_upfuse) return 0;
+  if (Cin == 16 && vx_conv3d_xp8_applies(D, H, W, Cin, Cout)) return 1;
+  // 2 (round 5): the 16-channel z-column kernel evaluates ConvTranspose3d(32 -> 16) for ALL 16 of its input channels (`in` is not
+  // read; up_w = vx_pack_convT_zc16, up_pitch >= 32) -- the up half of a decoder conv that runs over its halves (acc_in)
+  if (Cin == 16 && Cout == 16 && conv_config(Cin, Cout).S16 && vx_conv3d_zc16_applies(D, H, W, Cin, Cout)) return 2;
+  return 0;
 }
 
 extern "C" int vx_conv3d_k3_pool_layout(int D, int H, int W, int Cin, int Cout) {

@@ -62,9 +62,16 @@ struct Zc16Args {
 // ACC: partial sums (vx_conv3d_args.acc_in) are added before the activation instead of the bias; a multiplying wave requests its
 // item's pieces when it starts the item's matrix loop and uses them in the item's epilogue (no branch around the loads, and
 // nothing else of that wave is in flight but the previous item's stores).
-template <int CIN, int EPI, int PRE, int ACC = 0>
+// UP: the 16 input channels are ConvTranspose3d(32 -> 16, k = 2, s = 2)(up_in) + up_b, EVALUATED BY THE STAGING WAVES while they
+// stage (conv3d_xp8w.hip UP = 1 at this kernel's geometry): a fine voxel depends on ONE coarse voxel, so the planes of a step are
+// 8 sub-position classes (dz, dy, dx) x [16 co] x [85 coarse voxels] x [32 ci] small GEMMs -- one v_mfma_f32_16x16x32_f16 (x 3:
+// split products) per 16 coarse voxels, 12 tiles per staging wave and step, B operands straight from global memory (pre-split
+// by the producing conv's epilogue: vx_conv3d_args.up_split), results split and written where staged loads would have gone.
+// The transposed conv's launch, its 0.67 GB write and the conv's read of it disappear (unet3D_module.py:157-190, 332-356).
+template <int CIN, int EPI, int PRE, int ACC = 0, int UP = 0>
 __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
   static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
+  static_assert(UP == 0 || (CIN == 16 && PRE == 0), "the fused up-convolution produces the 16 input channels itself");
   static_assert(ACC == 0 || EPI == 1 || EPI == 3, "partial sums go with the activation epilogues");
   static_assert(PRE == 0 || (PRE == 1 && CIN == 16) || (PRE == 3 && CIN == 8), "prologues: normalise-on-load for 16, pool-finish for 8 channels");
   constexpr int NW = 8, NPW = 4, NTH = (NW + NPW) * 64;
@@ -154,6 +161,146 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     // so the global row offset is a running scalar add and the LDS row offset an immediate; the 2 halo voxels per row (x = -1,
     // x = 32) are gathered into HIT extra iterations of the per-lane form (one each for waves 3, 2, 1).
     const int pw = wave - NW;
+    if constexpr (UP != 0) {
+      // ---- fused up-convolution: this wave's plane and y-parity class (fixed for the kernel's life), both x-parities ----
+      // plane u_pz of the step is fine plane 2 s - 1 + u_pz: odd -> dz = 1 of coarse plane s - 1, even -> dz = 0 of coarse plane s
+      const int u_pz = pw >> 1, u_dy = pw & 1, u_dz = 1 - u_pz;
+      const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
+      const int up = a.up_pitch;
+      const int urow = Wc * up;
+      const int ubiasf = (Hc + 1) * urow + up;                      // keeps (Z = -1, Y = -1, X = -1) offsets non-negative
+      // column tile t (6 per class): coarse voxel c = 16 t + m of the class' 5 x 17 window -> (Yi, Xi); the dx = 1 class reads one
+      // coarse voxel to the left and writes one fine position to the left of the dx = 0 class
+      unsigned t_voff[6];
+      int t_lds[6];
+      unsigned tb_always = 0, tb_x0lo = 0, tb_x1lo = 0, tb_x0hi = 0, tb_ylo = 0, tb_yhi = 0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int c = 16 * t + m;
+        const int Yi = c / 17, Xi = c % 17;
+        // dx = 0; coarse plane s - 1 + u_pz: the (u_pz - 1) planes ride here (inside ubiasf's margin), s and the column origin are scalars
+        t_voff[t] = (unsigned)((((((u_pz - 1) * Hc + Yi - u_dy) * Wc) + Xi) * up + 8 * g + ubiasf) * 4);
+        const int hy = 2 * Yi + (u_dy ? 0 : 1), hx = 2 * Xi + 1;
+        t_lds[t] = (g >> 1) * OCT_B + ((u_pz * HY + hy) * HX + hx) * 16 + (g & 1) * 8;
+        if (c >= 85) tb_always |= 1u << t;
+        if (Xi == 16) tb_x0hi |= 1u << t;                      // dx = 0: X = Xc0 + 16 (outside in the last column tile)
+        if (Xi == 0) tb_x1lo |= 1u << t;                       // dx = 1: X = Xc0 - 1 (outside in the first)
+        if (u_dy == 1 && Yi == 0) tb_ylo |= 1u << t;           // Y = Yc0 - 1
+        if (u_dy == 0 && Yi == 4) tb_yhi |= 1u << t;           // Y = Yc0 + 4
+      }
+      (void)tb_x0lo;
+      // A operands: [class (dz, dy, dx)][hi | lo][lane][8 halves]: row m = co, k = ci 8 g .. 8 g + 7 (vx_pack_convT_zc16)
+      f16x8 u_ah[2], u_al[2];
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const f16x8* wp = reinterpret_cast<const f16x8*>(a.up_w) + (size_t)((((u_dz * 2 + u_dy) * 2 + dx) * 2) * 64 + lane);
+        u_ah[dx] = wp[0];
+        u_al[dx] = wp[64];
+      }
+      const f32x4 ubias4 = *reinterpret_cast<const f32x4*>(a.up_b + 4 * g);
+      const size_t up_sample = (size_t)Dc * Hc * urow;
+      f32x4 ubuf[2][6][2];                 // [dx][tile][piece]: ci 8 g .. + 3, 8 g + 4 .. + 7 of the tile's coarse voxel
+      unsigned p_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+      bool cs_have = false;
+      unsigned cs_bad0 = 0xFFFFFFFFu, cs_bad1 = 0xFFFFFFFFu, cs_usoff = 0;
+      __amdgpu_buffer_rsrc_t cs_usrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.up_in, 0, 0, 0x00020000);
+      auto column_state = [&](int ci) {
+        const bool have = ci < ncol_wg;
+        int n = 0, ty = 0, tx = 0;
+        if (have) col_of(ci, n, ty, tx);
+        cs_have = have;
+        unsigned b0 = tb_always, b1 = tb_always;
+        if (tx == 0) b1 |= tb_x1lo;
+        if (tx == ka.tiles_x - 1) b0 |= tb_x0hi;
+        if (ty == 0) { b0 |= tb_ylo; b1 |= tb_ylo; }
+        if (ty == ka.tiles_y - 1) { b0 |= tb_yhi; b1 |= tb_yhi; }
+        cs_bad0 = b0; cs_bad1 = b1;
+        cs_usoff = (unsigned)(((ty * 4) * urow + tx * 16 * up) * 4);
+        cs_usrd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.up_in + (size_t)n * up_sample - ubiasf), 0, VX_NUMREC, 0x00020000);
+      };
+      auto prefetch = [&](const Cur& c) {
+        if (c.s == 0) column_state(c.ci);
+        unsigned b0 = cs_bad0, b1 = cs_bad1;
+        // coarse plane Z = s - 1 + u_pz: -1 at step 0 (u_pz = 0), Dc at step KZ (u_pz = 1)
+        if (!cs_have || (c.s == 0 && u_pz == 0) || (c.s == KZ && u_pz == 1)) { b0 = 0xFFFFFFFFu; b1 = 0xFFFFFFFFu; }
+        const unsigned usoff = cs_usoff + (unsigned)((c.s * Hc) * urow * 4);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const unsigned v0 = ((b0 >> t) & 1u) ? VX_OOB : t_voff[t];
+          const unsigned v1 = ((b1 >> t) & 1u) ? VX_OOB : t_voff[t] - (unsigned)(up * 4);
+          ubuf[0][t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)v0, (int)usoff, 0));
+          ubuf[0][t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)v0, (int)usoff, 16));
+          ubuf[1][t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)v1, (int)usoff, 0));
+          ubuf[1][t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs_usrd, (int)v1, (int)usoff, 16));
+        }
+        p_bad[0] = b0; p_bad[1] = b1;
+      };
+      auto commit = [&](int grp) {
+        const int gofs = grp * GRP_B;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            f16x8 bh, bl;
+            if (a.up_split) {          // the producer of the coarse tensor stored fp16 pairs per piece: [hi0 hi1 hi2 hi3 | lo0 .. lo3]
+              const u32x4 d0 = __builtin_bit_cast(u32x4, ubuf[dx][t][0]), d1 = __builtin_bit_cast(u32x4, ubuf[dx][t][1]);
+              bh = __builtin_bit_cast(f16x8, (u32x4){d0[0], d0[1], d1[0], d1[1]});
+              bl = __builtin_bit_cast(f16x8, (u32x4){d0[2], d0[3], d1[2], d1[3]});
+            } else {
+              f16x4 h0, l0, h1, l1;
+              vx_split4(ubuf[dx][t][0], h0, l0);
+              vx_split4(ubuf[dx][t][1], h1, l1);
+              const u32x2 a0 = __builtin_bit_cast(u32x2, h0), a1 = __builtin_bit_cast(u32x2, h1);
+              const u32x2 c0 = __builtin_bit_cast(u32x2, l0), c1 = __builtin_bit_cast(u32x2, l1);
+              bh = __builtin_bit_cast(f16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+              bl = __builtin_bit_cast(f16x8, (u32x4){c0[0], c0[1], c1[0], c1[1]});
+              // vx_split4 writes the lo halves from inline assembly: no wait states before a matrix instruction that reads them
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("s_nop 7" ::: "memory");
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(u_ah[dx], bh, ubias4, 0, 0, 0);
+            f32x4 dxs = __builtin_amdgcn_mfma_f32_16x16x32_f16(u_ah[dx], bl, zero, 0, 0, 0);
+            dxs = __builtin_amdgcn_mfma_f32_16x16x32_f16(u_al[dx], bh, dxs, 0, 0, 0);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(dxs[j], 1.0f / 2048.f, d[j]);     // (compiler-visible: the first reader of a matrix result)
+            if ((p_bad[dx] >> t) & 1u) v = zero;             // outside the volume: the conv's zero padding, not the bias
+            rmax = vx_max3abs(vx_max3abs(rmax, v[0], v[1]), v[2], v[3]);
+            f16x4 hi, lo;
+            vx_split4(v, hi, lo);
+            if (!((tb_always >> t) & 1u)) {
+              unsigned char* dst = s_img + gofs + t_lds[t] - dx * 16;
+              *reinterpret_cast<f16x4*>(dst) = hi;
+              *reinterpret_cast<f16x4*>(dst + PREC_B) = lo;
+            }
+          }
+        }
+      };
+      Cur cx = {0, 0}, cc = {0, 0}, cp = {0, 0};
+      prefetch(cp); advance(cp);
+      commit(0);    advance(cc);
+      prefetch(cp); advance(cp);
+      int grp_x = 0;
+      while (cx.ci < ncol_wg) {
+        __syncthreads();
+        ZC_STAMP(0);
+        int grp_c = grp_x + 1; if (grp_c == 3) grp_c = 0;
+        ZC_WAIT_LOADS();
+        ZC_STAMP(3);
+        if (cc.ci < ncol_wg && !(ZC_ABL & 4)) commit(grp_c);
+        ZC_STAMP(4);
+        if (!(ZC_ABL & 8)) prefetch(cp);
+        ZC_STAMP(5);
+#ifdef VX_CONV_STAMPS
+        ++st_iters;
+#endif
+        advance(cx); advance(cc); advance(cp);
+        grp_x = grp_c;
+      }
+    } else {
     constexpr int UPR = CIN == 16 ? 2 : 1;          // units per row
     constexpr int NU = TZ * HY * UPR;               // row units of a step
     constexpr int RPW = NU / NPW;                   // 10 (Cin = 16) / 5 (Cin = 8)
@@ -401,6 +548,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       advance(cx); advance(cc); advance(cp);
       grp_x = grp_c;
     }
+    }   // UP == 0
     if (STATS) __syncthreads();
   } else {
     // =============================================== MULTIPLYING ===============================================
@@ -791,12 +939,33 @@ int vx_pack_conv3d_zc16(const float* w_torch, float* w_packed, int Cin, int Cout
   return VX_OK;
 }
 
-template <int CIN, int EPI, int PRE, int ACC = 0>
+// ConvTranspose3d(32 -> 16, k = 2, s = 2) for the fused evaluation: torch (32, 16, 2, 2, 2) -> [class (dz, dy, dx)][hi | lo][lane][8 halves],
+// lane (m, g): row m = co, k = ci 8 g .. 8 g + 7 (the A operand of v_mfma_f32_16x16x32_f16)
+__global__ void pack_convT_zc16_kernel(const float* __restrict__ w, _Float16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 8 * 2 * 64 * 8) return;
+  const int j = i & 7, lane = (i >> 3) & 63, hl = (i >> 9) & 1, cls = i >> 10;
+  const int co = lane & 15, ci = 8 * (lane >> 4) + j;
+  const float v = w[(ci * 16 + co) * 8 + cls];
+  const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+  const _Float16 h = (_Float16)c;
+  out[i] = hl == 0 ? h : (_Float16)((v - (float)h) * 2048.f);
+}
+extern "C" int64_t vx_convT_zc16_packed_floats(void) { return 8 * 2 * 64 * 8 / 2; }
+extern "C" int vx_pack_convT_zc16(const float* w_torch, float* packed, vx_stream_t stream) {
+  if (!w_torch || !packed) VX_FAIL(VX_E_NULL, "vx_pack_convT_zc16: null pointer");
+  if (!vx_aligned16(packed)) VX_FAIL(VX_E_ALIGN, "vx_pack_convT_zc16: packed must be 16-byte aligned");
+  hipLaunchKernelGGL(pack_convT_zc16_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w_torch, reinterpret_cast<_Float16*>(packed));
+  VX_CHECK_LAUNCH("vx_pack_convT_zc16");
+  return VX_OK;
+}
+
+template <int CIN, int EPI, int PRE, int ACC = 0, int UP = 0>
 static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   constexpr int PP = ((6 * 340 + 15) / 16) * 16;
   constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 15 : 9) * 2048 + 8 * 16 * 2 * 4 + 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3d_zc16_kernel<CIN, EPI, PRE, ACC>;
+  auto kern = conv3d_zc16_kernel<CIN, EPI, PRE, ACC, UP>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -805,7 +974,7 @@ static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   }
   int gx = 256;                // one persistent workgroup per CU
   if (gx > ka.ncols) gx = ka.ncols;
-  static const char* kname = vx_kname("conv3d_zc16_kernel<%d,%d,%d,%d>", CIN, EPI, PRE, ACC);   // as rocprofv3 prints it
+  static const char* kname = vx_kname("conv3d_zc16_kernel<%d,%d,%d,%d,%d>", CIN, EPI, PRE, ACC, UP);   // as rocprofv3 prints it
   vx_note_kernel(kname);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(768), lds, s, ka);
   VX_CHECK_LAUNCH("vx_conv3d_k3(zc16)");
@@ -814,7 +983,10 @@ static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
 
 // 1 = not taken (the caller uses the general tile kernel)
 int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_tiles, hipStream_t s) {
-  if (a.in_xblk || a.up_in || a.head_out || a.in_split || a.in_f16 || a.out_f16 || (a.in_repeat > 1)) return 1;
+  if (a.in_xblk || a.head_out || a.in_split || a.in_f16 || a.out_f16 || (a.in_repeat > 1)) return 1;
+  if (a.up_in && (a.Cin != 16 || a.in_mean || a.stats_partial || a.up_pitch < 32 || a.up_pitch % 4 || a.up_fused))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): the fused up-convolution (32 coarse channels -> the conv's 16 input channels) goes with an "
+            "activation epilogue, no prologue, up_pitch >= 32 (got %d), up_w packed by vx_pack_convT_zc16", a.up_pitch);
   if (a.drop_mode == VX_DROP_MASK || a.in_drop_mode == VX_DROP_MASK) return 1;
   if (!a.out || (!a.out_xblk && a.in_pitch != a.Cin)) return 1;
   Zc16Args ka;
@@ -850,8 +1022,17 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
     if (a.Cin != 16 || pre != 0 || a.stats_partial || a.acc_pitch < 16 || a.acc_pitch % 4 || !vx_aligned16(a.acc_in))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): partial sums (acc_in) go with 16 -> 16, no prologue, an activation epilogue, a "
               "16-byte aligned tensor of pitch >= 16 (pitch %d)", a.acc_pitch);
+    if (a.up_in) {
+      if (epi == 1) return launch_zc16<16, 1, 0, 1, 1>(ka, s);
+      return launch_zc16<16, 3, 0, 1, 1>(ka, s);
+    }
     if (epi == 1) return launch_zc16<16, 1, 0, 1>(ka, s);
     return launch_zc16<16, 3, 0, 1>(ka, s);
+  }
+  if (a.up_in) {
+    if (epi == 1) return launch_zc16<16, 1, 0, 0, 1>(ka, s);
+    if (epi == 3) return launch_zc16<16, 3, 0, 0, 1>(ka, s);
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): no fused up-convolution for this epilogue");
   }
 #define ZC16_CASE(C_, E_, P_) if (a.Cin == C_ && epi == E_ && pre == P_) return launch_zc16<C_, E_, P_>(ka, s)
   ZC16_CASE(16, 0, 0); ZC16_CASE(16, 0, 1); ZC16_CASE(16, 4, 0); ZC16_CASE(16, 4, 1);

@@ -273,6 +273,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // level l: CAT_l is used as TWO DENSE tensors (up = first half of the buffer, skip = second) and expand_l_1 runs as two
   // launches of the 16-channel z-column kernel over them (vx_conv3d_args.acc_in) -- level 1 of the F = 8 networks
   bool halves[4] = {false, false, false, false};
+  bool fuse_up1 = false, usplit1_ = false;   // upscale3 inside expand_2_1's up-half launch; B_2 handed over as fp16 pairs
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
   const int ICH = w->in_channels > 1 ? w->in_channels : 1;
@@ -445,7 +446,11 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       a2.in_pitch = C; a2.out_pitch = C; a2.N = N; a2.D = L.D; a2.H = L.H; a2.W = L.W; a2.Cin = C; a2.Cout = C;
       a2.act = VX_ACT_LRELU; a2.drop_mode = dm; a2.drop_seed = r->seed; a2.drop_layer = (uint32_t)dl; a2.w_family = w->split_family;
       a2.acc_in = p.A[l]; a2.acc_pitch = C; a2.seed_dev = r->seed_dev; a2.range_flag = r->range_flag; a2.out_half = 1;
-      VX_STEP("expand_2_1(up half)", vx_conv3d_k3(&a2, stream));
+      if (fuse_up1) {   // upscale3 evaluated by this launch's staging waves from B_2 (the up tensor never exists)
+        a2.in = p.B[l + 1]; a2.up_in = p.B[l + 1]; a2.up_pitch = 2 * C; a2.up_w = w->up3_zc16; a2.up_b = w->up_b[2];
+        a2.up_split = usplit1_ ? 1 : 0;
+      }
+      VX_STEP(fuse_up1 ? "upscale3+expand_2_1(up half)" : "expand_2_1(up half)", vx_conv3d_k3(&a2, stream));
     }
     else if (skip_raw[l])   // the skip half of CAT_l is contr_l_2's raw output: InstanceNorm + LeakyReLU + dropout layer 2 l + 1 on load
       VX_STEP(kConv[wi], conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 2 * l + 1, 1,
@@ -456,10 +461,15 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     // expand_2_2's output has ONE reader when upscale2 is fused into expand_1_1: hand it over pre-split
     osplit_ = l == 1 && fuse_up && dm != VX_DROP_MASK && !vx_cfg().s16_no_upsplit;   // (level 1 runs on the tile kernel)
     if (osplit_) usplit_ = true;
+    // ... and expand_3_2's when upscale3 is evaluated inside expand_2_1's up-half launch (round 5)
+    if (l == 2 && halves[1] && w->up3_zc16 && dm != VX_DROP_MASK && vx_conv3d_k3_upfuse_ok(p.lv[1].D, p.lv[1].H, p.lv[1].W, 16, 16) == 2) {
+      fuse_up1 = true;
+      if (!vx_cfg().s16_no_upsplit) { osplit_ = true; usplit1_ = true; }
+    }
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     st16_ = 0;
     osplit_ = false;
-    if (l > 1 || (l == 1 && !fuse_up))
+    if ((l > 1 || (l == 1 && !fuse_up)) && !(l == 2 && fuse_up1))
       VX_STEP(kUp[1 + (3 - l)], convT(p.B[l], 1 + (3 - l), p.CAT[l - 1], halves[l - 1] ? C / 2 : C, L, C, C / 2, VX_ACT_NONE, -1, halves[l - 1]));
   }
   // ---------------- head ----------------

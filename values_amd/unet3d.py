@@ -160,6 +160,10 @@ class UNet3D(nn.Module):
                 keep += [part, pk]
                 w.split_w[hidx] = pk.data_ptr()
             w.split_family = lib.vx_conv3d_k3_family(16, 16)
+            u3 = torch.empty(lib.vx_convT_zc16_packed_floats(), dtype=torch.float32, device=device)
+            _lib.check(lib.vx_pack_convT_zc16(_lib.ptr(sd["upscale3.weight"]), _lib.ptr(u3), st), "vx_pack_convT_zc16")
+            keep.append(u3)
+            w.up3_zc16 = u3.data_ptr()
         fw, fb = self._head_params(sd)
         keep += [fw, fb]
         w.final_w = fw.data_ptr()

@@ -1403,8 +1403,13 @@ def test_conv3d_zc16_fused_upconvolution_matches_oracle(shape, split, vxcfg):
         assert lib.vx_last_kernel_name().decode() == "conv3d_zc16_kernel<16,1,0,%d,1>" % acc
         pre_act = conv + (part.double() if acc else b.double().view(1, 16, 1, 1, 1))
         ref = F.leaky_relu(pre_act, 0.01) * keep * 2.0
-        err = (ncdhw(out).cpu().double() - ref).abs().max().item()
-        assert err < 8e-5, (acc, err)
+        dlt = (ncdhw(out).cpu().double() - ref).abs()
+        err = dlt.max().item()
+        where = np.unravel_index(int(dlt.argmax()), dlt.shape)
+        bad_z = (dlt.amax((0, 1, 3, 4)) > 8e-5).nonzero().flatten().tolist()
+        bad_y = (dlt.amax((0, 1, 2, 4)) > 8e-5).nonzero().flatten().tolist()
+        bad_x = (dlt.amax((0, 1, 2, 3)) > 8e-5).nonzero().flatten().tolist()
+        assert err < 8e-5, (acc, err, where, "z", bad_z, "y", bad_y, "x", bad_x)
     vxcfg.set(s16_no_upfuse=1)
     assert lib.vx_conv3d_k3_upfuse_ok(d, h, w, 16, 16) == 0
     with pytest.raises(_lib.VxError):

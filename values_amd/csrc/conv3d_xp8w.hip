@@ -926,6 +926,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     int e_ci = -1, e_n = 0, e_ty = 0, e_tx = 0, e_hflip = 0;
     uint32_t e_key = 0;
     float* e_ho = nullptr;     // head: this lane's output pointer for z0 = 0, r = 0 (un-flipped position)
+#ifdef VX_HEAD_PAIRS
+    float* e_hs = nullptr;     // (timing experiment) the slot's base
+#endif
     ptrdiff_t e_hz = 0, e_hy = 0;
 
     auto epilogue = [&](int ci, int k) {
@@ -941,6 +944,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           if (e_hflip & 2) gy = a.H - 1 - gy;
           if (e_hflip & 4) gx = a.W - 1 - gx;
           e_ho = a.head_out + (size_t)slot * a.head_C * hnvox + ((size_t)gz * a.H + gy) * a.W + gx;
+#ifdef VX_HEAD_PAIRS
+          e_hs = a.head_out + (size_t)slot * a.head_C * hnvox;
+#endif
           e_hz = (ptrdiff_t)((e_hflip & 1) ? -1 : 1) * TZ * a.H * a.W;
           e_hy = (e_hflip & 2) ? -a.W : a.W;
         }
@@ -952,6 +958,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       const uint32_t hw_item = (EPI == 1 || EPI == 2 || EPI == 4) ? vx_mix32(((vox0 >> 2) + hword_l) ^ e_key) : 0u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
+      // (measured and not kept, round 5: the R keep-words requested up front instead of one ds_bpermute + s_waitcnt lgkmcnt(0) per
+      // row: +-0.5 % on all four layers that draw them, same-process A/B -- the exposed LDS round trips are not what the epilogue costs)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling: the bits of multiply-then-add)
@@ -983,6 +991,21 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         }
         if (HEAD) {
           float* o = e_ho + (ptrdiff_t)k * e_hz + (ptrdiff_t)r * e_hy;
+#ifdef VX_HEAD_PAIRS
+          // TIMING EXPERIMENT ONLY (tools/build_variant.sh pairs -DVX_HEAD_PAIRS; round-4 verdict item 2a): the two class logits of
+          // a voxel as ONE interleaved 8-byte store [voxel][2] instead of two planar 4-byte stores.  The addresses are those of
+          // an interleaved tensor laid over the planar buffer (same bytes written in total), so the RESULTS ARE NOT the planar
+          // logits: never built into the product library.
+          {
+            float p0 = hb[0], p1 = hb[1];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { p0 = fmaf(hw4[0][kk], v[kk], p0); p1 = fmaf(hw4[1][kk], v[kk], p1); }
+            p0 = vx_add_xor16(p0);
+            p1 = vx_add_xor16(p1);
+            if (!(g & 1)) *reinterpret_cast<f32x2*>(o + (o - e_hs)) = (f32x2){p0, p1};
+          }
+          continue;
+#endif
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
             if (c < a.head_C) {

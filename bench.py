@@ -83,6 +83,10 @@ def layer_table(F=8, S=64):
     for lvl in (4, 3, 2, 1):
         c = F << (lvl - 1)
         t[f"expand_{lvl}_1"] = ("conv", 2 * c, c, S >> (lvl - 1))
+        # (round 5) the same layer as two launches over the halves of its input: conv_skip(skip) + bias -> partial sums, then
+        # conv_up(up) + partial sums -> activation (the second launch also reads the 4 c bytes per voxel of partial sums)
+        t[f"expand_{lvl}_1(skip half)"] = ("conv", c, c, S >> (lvl - 1))
+        t[f"expand_{lvl}_1(up half)"] = ("conv_acc", c, c, S >> (lvl - 1))
         t[f"expand_{lvl}_2"] = ("conv", c, c, S >> (lvl - 1))
         if lvl > 1:
             t[f"upscale{lvl}"] = ("convT", c, c // 2, S >> (lvl - 1))
@@ -99,6 +103,8 @@ def launch_cost(kind, ci, co, edge, N, N_in=None):
         N_in = N
     if kind == "conv":
         return 2.0 * 27 * ci * co * vox * N, 4.0 * ci * vox * N_in, 4.0 * co * vox * N, 4.0 * 27 * ci * co
+    if kind == "conv_acc":     # + the partial sums it adds (vx_conv3d_args.acc_in), counted with the weights: read whatever is fused in front
+        return 2.0 * 27 * ci * co * vox * N, 4.0 * ci * vox * N_in, 4.0 * co * vox * N, 4.0 * 27 * ci * co + 4.0 * co * vox * N
     if kind == "convT":
         return 2.0 * ci * co * 8 * vox * N, 4.0 * ci * vox * N, 4.0 * 8 * co * vox * N, 4.0 * 8 * ci * co
     if kind == "conv1x1":
@@ -191,7 +197,7 @@ def roofline_leg(model, x, T, reps=3, chunks=None):
     sec = a["ms"] * 1e-3
     tflops = a["flops"] / sec / 1e12
     gbs = a["bytes"] / sec / 1e9
-    split = "s16" in name or "xp8" in name
+    split = "s16" in name or "xp8" in name or "zc16" in name
     mpeak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     t_mfma = a["flops"] / (mpeak * 1e12)
     t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)

@@ -11,16 +11,17 @@
 //   prologue instruction sits on the critical path (contr_2_2: +0.136 ms for the pass it replaces); here the prologue, the
 //   pooled epilogue's partner pass and the loads ride in waves of their own.
 //
-// K schedule with input-row reuse (Cin = 16; 15 steps of K = 32 for 27 taps x 16 channels = 13.5):
+// K schedule with input-row reuse (Cin = 16; 14 steps of K = 32 for 27 taps x 16 channels = 13.5):
 //   steps (kz, ky), 9 of them: k-groups g = (kx = g >> 1 in {0, 1}, channel octet g & 1).  The B fragment of input row
 //     (plane z + kz, row y) does not depend on ky: a wave reads the 4 + 2 row fragments of a plane ONCE and uses them for
 //     ky = 0, 1, 2 of its four output rows (the tile kernel reads a fragment per (step, column tile): 0.83 ds_read_b128
 //     per matrix instruction, at the LDS array's limit; here 0.5);
 //   steps 9..11 (ky): the kx = 2 taps of kz = 0 and kz = 1 as the two k-group pairs (g >> 1 = kz);
-//   steps 12..14 (ky): the kx = 2 tap of kz = 2 (k-groups 2, 3: zero weights).
+//   step 12: the kx = 2 taps of (kz = 2, ky = 0) and (kz = 2, ky = 1) as the two pairs (a fragment per output row: rows r, r + 1);
+//   step 13: the kx = 2 tap of (kz = 2, ky = 2) (k-groups 2, 3: zero weights).
 // Cin = 8: 9 steps (kz, ky), k-groups = kx 0..2 + a zero group -- the same row reuse, 75 % dense (the layer is HBM-bound).
 //
-// LDS: image [octet][hi | lo][6 plane slots x 10 x 34 positions][8 halves] = 128 KB (Cin = 16) + weights 30 KB + 1 KB of
+// LDS: image [octet][hi | lo][6 plane slots x 10 x 34 positions][8 halves] = 128 KB (Cin = 16) + weights 28 KB + 1 KB of
 // statistics slots.  TZ = 2 output planes per item; three groups of 2 plane slots (a step writes one group while the item
 // in flight reads the other two -- conv3d_xp8w.hip's scheme).
 #include "s16_common.h"
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
   constexpr int OCT_B = 2 * PREC_B;
   constexpr int OCT = CIN / 8;
   constexpr int IMG_B = OCT * OCT_B;
-  constexpr int NSTEP = CIN == 16 ? 15 : 9;
+  constexpr int NSTEP = CIN == 16 ? 14 : 9;
   constexpr int W_B = NSTEP * 2 * 1024;            // [step][hi | lo][lane 64][8 halves]
   constexpr int GRP_B = TZ * ZP * 16;              // bytes between two slot groups
   constexpr int PLN_B = ZP * 16;                   // bytes between two plane slots
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     for (int i = tid; i < W_B / 16; i += NTH) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
     if (tid < 16) s_bias[tid] = a.bias[tid];
   }
-  // the image starts as zeros: a zero-weight k-group (Cin = 16: steps 12..14; Cin = 8: the fourth group) multiplies whatever
+  // the image starts as zeros: a zero-weight k-group (Cin = 16: step 13; Cin = 8: the fourth group) multiplies whatever
   // sits at the position it reads, which must be finite from the first item on
   {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -619,26 +620,34 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         if (s_ >= NZ) s_ -= NZ;
         sl[kz] = s_ * PLN_B;
       }
-      constexpr int NPH = CIN == 16 ? 5 : 3;
+      // phases = groups of steps that share their row fragments.  Cin = 16: phases 0..2 (type 1, kz = phase) and 3 (the kx = 2 taps
+      // of kz = 0 / 1) have three steps (ky) over 6 rows -- tile r of step ky reads row r + ky; phase 4 is the ONE step that holds
+      // the kx = 2 taps of (kz = 2, ky = 0 / 1) as its two k-group pairs: its fragment of tile r mixes rows r and r + 1 by lane
+      // (4 fragments, no reuse); phase 5 the half-empty step of (kz = 2, ky = 2): rows 2..5.  14 steps for 13.5 (round 5, second
+      // version: the first ran the kz = 2 taps as three half-empty steps, 15).  Cin = 8: three phases of three steps.
+      constexpr int NPH = CIN == 16 ? 6 : 3;
+      auto ph_of = [](int t) { return t < 12 ? t / 3 : t - 8; };           // step -> phase
+      auto ky_of = [](int t) { return t < 12 ? t % 3 : 0; };               // step -> row offset of tile r within the phase's rows
+      auto nrows = [](int ph) { return ph < 4 ? R + 2 : R; };
+      const unsigned char* rowp[NPH];
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        if (ph < 3) rowp[ph] = s_img + bP + sl[ph];
+        else if (ph == 3) rowp[ph] = s_img + bQ + ((g >> 1) ? sl[1] : sl[0]);
+        else if (ph == 4) rowp[ph] = s_img + bQ + sl[2] + (g >> 1) * ROW_B;
+        else rowp[ph] = s_img + bQ + sl[2] + 2 * ROW_B;
+      }
 #ifndef ZC_NO_PIPE
       if constexpr (!POOL)      // (the pooling instance holds 8 statistics registers + its window state across the loop: 168 + scratch)
       // ONE software pipeline over the NSTEP K-steps, 12 matrix instructions each.  Left alone hipcc sinks every ds_read_b128 to
-      // just before its consumer (ds_read; s_waitcnt lgkmcnt(0..1); v_mfma: an exposed LDS latency per weight pair and per row
-      // group -- ~1 500 of ~4 400 cycles per item in the ISA of the first version).  Here every step requests, behind its own matrix
-      // instructions and pinned there (sched_group_barrier), exactly six fragments of LATER steps:
+      // just before its consumer (ds_read; s_waitcnt lgkmcnt(0..1); v_mfma).  Here every step requests, behind its own matrix
+      // instructions and pinned there (sched_group_barrier), fragments of LATER steps:
       //   step (phase p, ky = 0): the weights of (p, 1) + rows 4, 5 of phase p          (needed at ky = 1 / ky = 2)
       //   step (p, 1):            the weights of (p, 2) + rows 0, 1 of phase p + 1
       //   step (p, 2):            the weights of (p + 1, 0) + rows 2, 3 of phase p + 1
-      // -- 0.5 reads per matrix instruction, uniformly; at most 8 row fragments + 2 weight pairs live (112 VGPRs with the
-      // accumulators).
+      //   step 12 (phase 4):      the weights of step 13 + the four rows of phase 5
+      // -- 0.5 reads per matrix instruction over the item.  Measured -2 .. -3.5 % (same-process A/B against the plain loop).
       {
-        const unsigned char* rowp[NPH];
-#pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-          if (ph < 3) rowp[ph] = s_img + bP + sl[ph];
-          else if (ph == 3) rowp[ph] = s_img + bQ + ((g >> 1) ? sl[1] : sl[0]);
-          else rowp[ph] = s_img + bQ + sl[2];
-        }
         f16x8 rh[NPH][R + 2], rl[NPH][R + 2], wh[NSTEP], wl[NSTEP];
         auto ld_row = [&](int ph, int jr) {
           rh[ph][jr] = *reinterpret_cast<const f16x8*>(rowp[ph] + jr * ROW_B);
@@ -654,11 +663,17 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         __builtin_amdgcn_sched_group_barrier(0x100, 3 + 2 * R, 0);      // (+ the bias vector)
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
-          const int ph = t / 3, ky = t % 3;
+          const int ph = ph_of(t), ky = ky_of(t);
           int nrd = 0;
           if (t + 1 < NSTEP) { ld_w(t + 1); nrd += 2; }
-          if (ky == 0) { ld_row(ph, R); ld_row(ph, R + 1); nrd += 4; }
-          else if (ph + 1 < NPH) { ld_row(ph + 1, 2 * (ky - 1)); ld_row(ph + 1, 2 * (ky - 1) + 1); nrd += 4; }
+          if (t < 12) {
+            if (ky == 0) { ld_row(ph, R); ld_row(ph, R + 1); nrd += 4; }
+            else if (ph + 1 < NPH) { ld_row(ph + 1, 2 * (ky - 1)); ld_row(ph + 1, 2 * (ky - 1) + 1); nrd += 4; }
+          } else if (t == 12) {
+#pragma unroll
+            for (int jr = 0; jr < R; ++jr) ld_row(5, jr);
+            nrd += 2 * R;
+          }
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const bool fresh = t == 0;      // the bias is the first product's C operand
@@ -678,19 +693,17 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
 #endif
 #pragma unroll
       for (int ph = 0; ph < NPH; ++ph) {
-        const unsigned char* row0;
-        if (ph < 3) row0 = s_img + bP + sl[ph];
-        else if (ph == 3) row0 = s_img + bQ + ((g >> 1) ? sl[1] : sl[0]);
-        else row0 = s_img + bQ + sl[2];
         f16x8 bh[R + 2], bl[R + 2];
 #pragma unroll
         for (int jr = 0; jr < R + 2; ++jr) {
-          bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * ROW_B);
-          bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * ROW_B + PREC_B);
+          if (jr < nrows(ph)) {
+            bh[jr] = *reinterpret_cast<const f16x8*>(rowp[ph] + jr * ROW_B);
+            bl[jr] = *reinterpret_cast<const f16x8*>(rowp[ph] + jr * ROW_B + PREC_B);
+          }
         }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int step = ph * 3 + ky;
+        for (int ky = 0; ky < (ph < 4 ? 3 : 1); ++ky) {
+          const int step = ph < 4 ? ph * 3 + ky : 8 + ph;
           const f16x8 ah = *reinterpret_cast<const f16x8*>(wlane + step * 2048);
           const f16x8 al = *reinterpret_cast<const f16x8*>(wlane + step * 2048 + 1024);
 #pragma unroll
@@ -912,7 +925,7 @@ bool vx_conv3d_zc16_applies(int D, int H, int W, int Cin, int Cout) {
 
 int64_t vx_conv3d_zc16_packed_floats(int Cin, int Cout) {
   if (!vx_conv3d_zc16_packs(Cin, Cout)) return 0;
-  return (int64_t)(Cin == 16 ? 15 : 9) * 2 * 64 * 8 / 2;
+  return (int64_t)(Cin == 16 ? 14 : 9) * 2 * 64 * 8 / 2;
 }
 
 // torch (16, Cin, 3,3,3) fp32 -> [step][hi | lo][lane 64][8 halves] in the K schedule of the kernel's header
@@ -926,7 +939,8 @@ __global__ void pack_conv3d_zc16_kernel(const float* __restrict__ w, _Float16* _
       ci = 8 * (g & 1) + j;
       if (step < 9) { kz = step / 3; ky = step % 3; kx = g >> 1; }
       else if (step < 12) { ky = step - 9; kz = g >> 1; kx = 2; }
-      else { ky = step - 12; kz = 2; kx = 2; zero = (g >> 1) != 0; }
+      else if (step == 12) { ky = g >> 1; kz = 2; kx = 2; }
+      else { ky = 2; kz = 2; kx = 2; zero = (g >> 1) != 0; }
     } else {
       ci = j; kz = step / 3; ky = step % 3; kx = g; zero = g == 3;
     }
@@ -970,7 +984,7 @@ extern "C" int vx_pack_convT_zc16(const float* w_torch, float* packed, vx_stream
 template <int CIN, int EPI, int PRE, int ACC = 0, int UP = 0>
 static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
   constexpr int PP = ((6 * 340 + 15) / 16) * 16;
-  constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 15 : 9) * 2048 + 8 * 16 * 2 * 4 + 64;
+  constexpr size_t lds = (size_t)(CIN / 8) * 2 * PP * 16 + (size_t)(CIN == 16 ? 14 : 9) * 2048 + 8 * 16 * 2 * 4 + 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv3d_zc16_kernel<CIN, EPI, PRE, ACC, UP>;
   static bool attr = false;

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     // so the global row offset is a running scalar add and the LDS row offset an immediate; the 2 halo voxels per row (x = -1,
     // x = 32) are gathered into HIT extra iterations of the per-lane form (one each for waves 3, 2, 1).
     const int pw = wave - NW;
+#ifdef ZC_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(ZC_PRODUCER_PRIO);
+#endif
     if constexpr (UP != 0) {
       // ---- fused up-convolution.  A wave owns a plane of the step (u_pz; fine plane 2 s - 1 + u_pz: odd -> dz = 1 of coarse
       // plane s - 1, even -> dz = 0 of coarse plane s) and HALF of that plane's coarse window (6 rows x 18 columns = 108 coarse
@@ -478,8 +481,12 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       return v;
     };
     auto split4 = [&](const f32x4 v, f16x4& hi, f16x4& lo) {
+#ifdef ZC_SPLIT_PACKED
       if constexpr (PRE != 0) vx_split4_s(v, hi, lo);
       else vx_split4(v, hi, lo);
+#else
+      vx_split4_s(v, hi, lo);      // plain instructions: the staging waves are this kernel's critical path (stamps: 96 % busy)
+#endif
     };
 
     auto commit = [&](int grp) {

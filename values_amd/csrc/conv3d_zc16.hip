@@ -162,9 +162,11 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     // so the global row offset is a running scalar add and the LDS row offset an immediate; the 2 halo voxels per row (x = -1,
     // x = 32) are gathered into HIT extra iterations of the per-lane form (one each for waves 3, 2, 1).
     const int pw = wave - NW;
-#ifdef ZC_PRODUCER_PRIO
-    __builtin_amdgcn_s_setprio(ZC_PRODUCER_PRIO);
-#endif
+    // staging waves with a prologue (or the fused up-convolution) run at raised priority: they are the critical path (stamps: 93 %
+    // busy, 70 % of it in the conversion; the multiplying waves park 33-53 % at the barrier).  Per layer in the forward, same box:
+    // pool-finish prologue -8 %, normalise-on-load -6.6 %, fused up-convolution -1.3 %; +2.4 % WITHOUT a prologue and +2.8 % on the
+    // pooling instance (whose multiplying waves carry the long epilogue) -- not raised there.
+    if constexpr ((PRE != 0 && !POOL) || UP != 0) __builtin_amdgcn_s_setprio(2);
     if constexpr (UP != 0) {
       // ---- fused up-convolution.  A wave owns a plane of the step (u_pz; fine plane 2 s - 1 + u_pz: odd -> dz = 1 of coarse
       // plane s - 1, even -> dz = 0 of coarse plane s) and HALF of that plane's coarse window (6 rows x 18 columns = 108 coarse

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
           if (a.out_split) {   // the consumer is the fused up-convolution: hand the piece over as the fp16 pairs it multiplies
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             f16x4 hi, lo;
-            vx_split4(v, hi, lo);
+            vx_split4_s(v, hi, lo);      // (plain instructions: packed fp32 beside the partner wave's matrix stream costs three)
             const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
             sv = (u32x4){h2[0], h2[1], l2[0], l2[1]};
           }

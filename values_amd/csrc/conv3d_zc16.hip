@@ -34,7 +34,7 @@ struct Zc16Args {
   unsigned mcps, mtx;         // multiply-high magics: / (tiles_x * tiles_y), / tiles_x
   int stat_epc;               // statistics entries per column in stats_partial (entry 0 real, the rest zero)
   unsigned long long* stamps;
-  int abl;                    // diagnostic build only: phase ablation bits (1 no multiply, 2 no epilogue, 4 no commit, 8 no loads)
+  int abl;                    // diagnostic build only: phase ablation bits (1 no multiply, 2 no epilogue, 4 no commit, 8 no loads, 16 no LDS writes, 32 no split)
 };
 
 #ifdef VX_CONV_STAMPS
@@ -520,7 +520,8 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         }
         if constexpr (PRE == 3) v = poolfin_piece(v, p_mean, p_rstd, fbuf[i], (p_rowbad >> i) & 1u, two);
         f16x4 hi, lo;
-        split4(v, hi, lo);
+        if (ZC_ABL & 32) { hi = __builtin_bit_cast(f16x4, (f32x2){v[0], v[1]}); lo = __builtin_bit_cast(f16x4, (f32x2){v[2], v[3]}); }   // (diagnostic build: no split arithmetic)
+        else split4(v, hi, lo);
         if (!(ZC_ABL & 16)) {
           *reinterpret_cast<f16x4*>(dst) = hi;
           *reinterpret_cast<f16x4*>(dst + PREC_B) = lo;

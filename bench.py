@@ -827,7 +827,9 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
     if args.roofline_only:
         roof = model.profile_forward(views.t.view(-1, H, W, 4), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=8,
                                      nhwc=True, reps=8)
-        roof["traffic"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
+        # the PMC record is a mean over ALL launches of the instance (several layer shapes): it cannot be the traffic of the one
+        # shape the object names -- quoted beside it, `traffic` stays null
+        roof["instance_traffic_mean"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
         return {"config": "C4 roofline leg only", "hrnet_width": args.hrnet_width, "images": B, "roofline": roof}
 
     def step_eager(i):
@@ -859,7 +861,9 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
         roof = model.profile_forward(views.t.view(-1, H, W, 4), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=8,
                                      nhwc=True)
         # HBM-side bytes per launch (PMC passes around `--config C4 --roofline-only`: the same single-stream launches)
-        roof["traffic"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
+        # the PMC record is a mean over ALL launches of the instance (several layer shapes): it cannot be the traffic of the one
+        # shape the object names -- quoted beside it, `traffic` stays null
+        roof["instance_traffic_mean"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg_2d(extra, model.state_dict(), H, W)

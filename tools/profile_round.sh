@@ -5,9 +5,9 @@ tag=${1:-rXX}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency > gpurun_out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency --no-batch64 > gpurun_out/${tag}_prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_${tag}_$c --output-format csv -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-latency > gpurun_out/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_${tag}_$c --output-format csv -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-latency --no-batch64 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1; mean per launch"

@@ -163,6 +163,33 @@ def test_non_cubic_volume_vs_oracle():
         model(torch.zeros(1, 1, 40, 16, 16).cuda())
 
 
+def test_non_cubic_volume_on_the_level1_z_column_kernel_vs_oracle():
+    """(32, 48, 128): level 1 is 16 x 24 x 64 -- two column tiles in x, three in y, eight items in z on conv3d_zc16.hip (round 5),
+    the two-launch expand_2_1 with upscale3 inside; MC-dropout with the exported hash masks and dropout off, against the float64
+    oracle.  Two volumes: several samples per workgroup."""
+    from values_amd import predict_uncertainty
+    import bench
+    S, T, seed = (32, 48, 128), 2, 99
+    model = make_model(seed_tag=3, do_dropout=True)
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1) + S, tag=91), formula_volume((1, 1) + S, tag=92)], 0))
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names) and any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names), names
+    sd = formula_sd_torch(seed_tag=3)
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, 2 * T, *S)]           # sample n = volume * T + pass
+    for v in range(2):
+        logits, ref = _oracle_maps(sd, x[v:v + 1], [[m[v * T + t:v * T + t + 1] for m in masks] for t in range(T)])
+        assert np.abs(out["logits"][v].cpu().numpy() - logits).max() < LOGIT_TOL
+        for k in KEYS:
+            assert np.abs(out[k][v].cpu().numpy() - ref[k]).max() < MAP_TOL, k
+    det = make_model(seed_tag=3, do_dropout=False)
+    from oracle.unet3d_oracle import unet3d_forward
+    with torch.no_grad():
+        y = det(x.float().cuda())
+        ref0 = unet3d_forward(sd, x, masks=None).numpy()
+    assert np.abs(y.cpu().numpy() - ref0).max() < LOGIT_TOL
+
+
 @pytest.mark.parametrize("f,size,ncls", [(16, 32, 2), (32, 16, 3)])
 def test_wider_networks_vs_oracle(f, size, ncls):
     """initial_filter_size 16 / 32 (ctor kwarg of unet3D_module.py:8-35): every layer on the 16x16x4 kernels, separate

@@ -1050,9 +1050,10 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
   else epi = 3;
   if (a.out_split && a.stats_partial) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): out_split goes with the activation epilogues");
   if (a.acc_in) {
-    if (a.Cin != 16 || pre != 0 || a.stats_partial || a.acc_pitch < 16 || a.acc_pitch % 4 || !vx_aligned16(a.acc_in))
+    if (a.Cin != 16 || pre != 0 || a.stats_partial || a.acc_pitch < 16 || a.acc_pitch % 4 || !vx_aligned16(a.acc_in) ||
+        (int64_t)a.D * a.H * a.W * a.acc_pitch * 4 >= (1ll << 31))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): partial sums (acc_in) go with 16 -> 16, no prologue, an activation epilogue, a "
-              "16-byte aligned tensor of pitch >= 16 (pitch %d)", a.acc_pitch);
+              "16-byte aligned tensor of pitch >= 16 (pitch %d), one sample below 2 GiB", a.acc_pitch);
     if (a.up_in) {
       if (epi == 1) return launch_zc16<16, 1, 0, 1, 1>(ka, s);
       return launch_zc16<16, 3, 0, 1, 1>(ka, s);

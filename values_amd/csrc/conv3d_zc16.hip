@@ -1019,7 +1019,7 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): the fused up-convolution (32 coarse channels -> the conv's 16 input channels) goes with an "
             "activation epilogue, no prologue, up_pitch >= 32 (got %d), up_w packed by vx_pack_convT_zc16", a.up_pitch);
   if (a.drop_mode == VX_DROP_MASK || a.in_drop_mode == VX_DROP_MASK) return 1;
-  if (!a.out || (!a.out_xblk && a.in_pitch != a.Cin)) return 1;
+  if (!a.out) return 1;
   Zc16Args ka;
   ka.a = a;
   ka.w = w_block;

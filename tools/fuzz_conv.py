@@ -12,12 +12,16 @@ dev = torch.device("cuda", 0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+nzc = 0
 for case in range(cases):
     cin, cout = rng.choice([(8, 8), (16, 8), (8, 8), (16, 8), (16, 16), (8, 16), (32, 16), (32, 32), (24, 8)])
     big = rng.random() < 0.6
     d = rng.randint(1, 9)
     h = rng.randint(32, 70) if big else rng.randint(1, 31)
     w = rng.randint(1, 70)
+    if cout == 16 and cin in (8, 16) and rng.random() < 0.6:
+        # shapes the role-split z-column kernel of round 5 takes (conv3d_zc16.hip): W % 32 == 0, H % 8 == 0, D even >= 4
+        d, h, w = 2 * rng.randint(2, 6), 8 * rng.randint(1, 5), 32 * rng.randint(1, 2)
     n = rng.randint(1, 40 if rng.random() < 0.2 else 4)
     mode = rng.choice(["plain_stats", "lrelu_hash", "head", "relu"])
     if mode == "head" and (cout != 8 or cin not in (8, 16)):
@@ -53,18 +57,25 @@ for case in range(cases):
                 a.head_out, a.head_w, a.head_b, a.head_C = head.data_ptr(), hw.data_ptr(), hb.data_ptr(), 2
             _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
             torch.cuda.synchronize()
+            run.kernel = lib.vx_last_kernel_name().decode()
             return out, st, head
 
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}", flush=True)
     got = run({})
+    zc16 = run.kernel.startswith("conv3d_zc16")
+    nzc = nzc + 1 if zc16 else nzc
     if os.environ.get("FUZZ_VERBOSE"):
-        print("  default ok", flush=True)
+        print("  default ok", run.kernel, flush=True)
     gen = run({"s16_no_xp8": 1, "s16_generic": 1})     # the tile kernel's generic instance (round 4: s16_no_db / s16_no_epi became ONE field)
     if os.environ.get("FUZZ_VERBOSE"):
         print("  generic ok", flush=True)
     f32 = run({"conv_fp32": 1})
-    ok = all(torch.equal(p, q) for p, q in zip(got, gen))
+    if zc16:    # another K schedule and another statistics tiling than the tile kernel: the same function to float32 rounding
+        ok = (got[0] - gen[0]).abs().max().item() < 2e-5 and \
+            (got[1].double().sum(1) - gen[1].double().sum(1)).abs().max().item() < 1e-4 * max(1.0, d * h * w) ** 0.5
+    else:
+        ok = all(torch.equal(p, q) for p, q in zip(got, gen))
     tile_counts_differ = False
     err = max((got[0] - f32[0]).abs().max().item(), (got[2] - f32[2]).abs().max().item())
     serr = 0.0
@@ -73,5 +84,5 @@ for case in range(cases):
     if not ok or err > 2e-5 or serr > 1e-4 or torch.isnan(got[0]).any():
         bad += 1
         print(f"FAIL case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}: bit-equal={ok} err_vs_fp32={err:.2e} stats={serr:.2e}")
-print(f"{cases} cases, {bad} failures")
+print(f"{cases} cases ({nzc} on the 16-channel z-column kernel), {bad} failures")
 sys.exit(1 if bad else 0)

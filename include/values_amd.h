@@ -366,7 +366,11 @@ int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
 int vx_norm_act_drop_pool_bcast(const vx_norm_args* a, int x_repeat, vx_stream_t stream);
 
 /* K6: ConvTranspose3d(k=2, s=2) (+ReLU+Dropout for center.4), unet3D_module.py:113-120, 157-190;
- * writes channels [out_coff, out_coff+Cout) of the concat buffer (K7: torch.cat disappears). */
+ * writes channels [out_coff, out_coff+Cout) of the concat buffer (K7: torch.cat disappears).
+ * Cin in {64, 128} with Cout % 8 == 0 (% 4 for 128) under vx_config.conv_fp32 == 0 (round 5): the products run on the fp16 matrix
+ * cores by operand splitting, like the 3x3x3 convolutions -- same accuracy, and the same contract on the INPUT: |x| < 65504
+ * (the producers inside vx_unet3d_forward record it in their range_flag).  A WEIGHT past 65504 is reported through this launch's
+ * range_flag (infinity).  conv_fp32 != 0 keeps the native-fp32 instruction. */
 typedef struct vx_convT_args {
   const float* in; int32_t in_pitch;
   const float* w_packed; const float* bias;

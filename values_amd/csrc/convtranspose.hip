@@ -278,6 +278,173 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
   }
 }
 
+// Split-fp16 variant for the DEEP up-convolutions (Cin = 64 / 128: center.4, upscale4; round 5).  On the native-fp32 matrix
+// instruction those two launches were bound by the instruction itself (8 * Cout rows x Cin / 4 instructions of 32 cycles per 16
+// voxels: 42-46 TF, 0.12 + 0.06 ms for 0.21 + 0.03 GB) and had no registers left for a prefetch.  Here the same GEMM runs as three
+// v_mfma_f32_16x16x32_f16 per 32 channels (operand splitting as conv3d_s16.hip: products exact, fp32 accumulation; the weights are
+// gathered from the fp32 packing and split once per workgroup), 5 x fewer matrix cycles, and the next column tile's input is in
+// flight while this one is multiplied and stored.  k index of a lane: channels 32 q + 8 g .. + 7 (two 16-byte loads per K step).
+#include "s16_common.h"
+template <int CIN, int RT, bool MASK = false>
+__global__ __launch_bounds__(256) void convT_k2s2_s16_kernel(vx_convT_args a, int ncoltiles, int nvox_in, ConvTDecode dc) {
+  constexpr int Q = CIN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int OW = a.W * 2, OH = a.H * 2, OD = a.D * 2;
+  const int rt0 = blockIdx.y * RT;
+  f16x8 wh[RT][Q], wl[RT][Q];
+  float rmax = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = 16 * (rt0 + rt) + m;
+    const int pos = row / a.Cout, co = row % a.Cout;
+    const float* wp = a.w_packed + (size_t)(pos >> 1) * CIN * 2 * a.Cout + (pos & 1) * a.Cout + co;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float w = wp[(size_t)(32 * q + 8 * g + j) * 2 * a.Cout];
+        // a weight past the fp16 range is clamped (finite arithmetic below) and reported through the range word like an
+        // activation past it: the caller re-runs on the native-fp32 kernels (vx_config.conv_fp32 = 1)
+        const float c = fminf(fmaxf(w, -65504.f), 65504.f);
+        if (!(fabsf(w) <= 65504.f)) rmax = __builtin_inff();
+        const _Float16 h = (_Float16)c;
+        wh[rt][q][j] = h;
+        wl[rt][q][j] = (_Float16)((c - (float)h) * 2048.f);
+      }
+  }
+  int opos[RT], oco[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = 16 * (rt0 + rt) + 4 * g;
+    opos[rt] = row / a.Cout;
+    oco[rt] = row % a.Cout;
+  }
+  const int xs = a.out_xblk ? __builtin_ctz((unsigned)a.out_xblk) : 0;
+  const int wstride = (int)gridDim.x * 4;
+  auto load_x = [&](int ct, f32x4* dst) {
+    int v = ct * 16 + m;
+    if (v >= nvox_in) v = nvox_in - 1;
+    const float* __restrict__ xin = a.in + (size_t)v * a.in_pitch + 8 * g;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      dst[2 * q] = *reinterpret_cast<const f32x4*>(xin + 32 * q);
+      dst[2 * q + 1] = *reinterpret_cast<const f32x4*>(xin + 32 * q + 4);
+    }
+  };
+  f32x4 xnext[2 * Q];
+  {
+    const int ct0 = blockIdx.x * 4 + wave;
+    load_x(ct0 < ncoltiles ? ct0 : ncoltiles - 1, xnext);
+  }
+  const uint32_t seed0 = vx_seed_of(a, a.drop_seed);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int ct = blockIdx.x * 4 + wave; ct < ncoltiles; ct += wstride) {
+    const int v = ct * 16 + m;
+    const int vc = v < nvox_in ? v : nvox_in - 1;
+    f16x8 bh[Q], bl[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      f16x4 h0, l0, h1, l1;
+      vx_split4(xnext[2 * q], h0, l0);
+      vx_split4(xnext[2 * q + 1], h1, l1);
+      const u32x2 a0 = __builtin_bit_cast(u32x2, h0), a1 = __builtin_bit_cast(u32x2, h1);
+      const u32x2 c0 = __builtin_bit_cast(u32x2, l0), c1 = __builtin_bit_cast(u32x2, l1);
+      bh[q] = __builtin_bit_cast(f16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+      bl[q] = __builtin_bit_cast(f16x8, (u32x4){c0[0], c0[1], c1[0], c1[1]});
+    }
+    {
+      const int ctn = ct + wstride;
+      load_x(ctn < ncoltiles ? ctn : ncoltiles - 1, xnext);
+    }
+    // vx_split4 writes the lo halves from inline assembly: no wait states before a matrix instruction that reads them
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned r = (unsigned)vc, qq;
+    qq = ct_div(r, dc.mW); const int x = (int)(r - qq * (unsigned)a.W); r = qq;
+    qq = ct_div(r, dc.mH); const int y = (int)(r - qq * (unsigned)a.H); r = qq;
+    qq = ct_div(r, dc.mD); const int z = (int)(r - qq * (unsigned)a.D);
+    const int n = (int)qq;
+    const uint32_t dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);
+      f32x4 accx = zero;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[rt][q], bh[q], acc, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[rt][q], bl[q], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[rt][q], bh[q], accx, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(accx[j], 1.0f / 2048.f, acc[j]);
+      const int pos = opos[rt];
+      const int oz = 2 * z + (pos >> 2), oy = 2 * y + ((pos >> 1) & 1), ox = 2 * x + (pos & 1);
+      const size_t orow = ((size_t)n * OD + oz) * OH + oy;
+      if (a.act == VX_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      } else if (a.act == VX_ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.01f * acc[j]);
+      }
+      if (a.drop_mode == VX_DROP_HASH) {
+        const uint32_t bits = vx_drop_bits4(dkey, (uint32_t)(((oz * OH + oy) * OW + ox) * a.Cout + oco[rt]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
+      }
+      if constexpr (MASK) {
+        const uint32_t mk = *reinterpret_cast<const uint32_t*>(a.drop_mask + (orow * OW + ox) * a.Cout + oco[rt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = ((mk >> (8 * j)) & 0xFFu) ? 2.f * acc[j] : 0.f;
+      }
+      float* op;
+      if (a.out_xblk)
+        op = a.out + orow * (2 * (size_t)OW * a.Cout) +
+             ((((ox >> xs) * 2 + a.out_half) << xs) + (ox & (a.out_xblk - 1))) * a.Cout + oco[rt];
+      else
+        op = a.out + (orow * OW + ox) * a.out_pitch + a.out_coff + oco[rt];
+      *reinterpret_cast<f32x4*>(op) = acc;      // (lanes beyond the last voxel store its values a second time: no branch around the store)
+      rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+    }
+  }
+  if (a.range_flag) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+    if (lane == 0 && !(rmax < 32768.f)) atomicMax(a.range_flag, __float_as_uint(rmax));
+  }
+}
+
+template <int CIN, int RT>
+static int launch_convT_s16(const vx_convT_args& a, hipStream_t s) {
+  const int64_t nvox = (int64_t)a.N * a.D * a.H * a.W;
+  const int ncoltiles = (int)((nvox + 15) / 16);
+  const int groups = (a.Cout / 2) / RT;
+  int bx = (ncoltiles + 3) / 4;
+  // 512 workgroups (two per CU at these instances' registers), each wave walking its share of the column tiles: the weight gather
+  // of the prologue is paid once per wave.  Measured at 320 samples (tools/ab_convT.py): upscale4 0.108 -> 0.056 ms, center.4
+  // 0.052 -> 0.033; with one column tile per wave (the fp32 kernel's grid) the same kernel is 20-30 % SLOWER than the fp32 one,
+  // and <64,8> / <128,4> (256 registers, one workgroup per CU) reach 0.076 / 0.034.
+  const int cap = (512 + groups - 1) / groups;
+  if (bx > cap) bx = cap;
+  auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
+  ConvTDecode dc;
+  dc.mW = magic(a.W); dc.mH = magic(a.H); dc.mD = magic(a.D);
+  static const char* kname = vx_kname("convT_k2s2_s16_kernel<%d,%d,false>", CIN, RT);
+  static const char* kname_m = vx_kname("convT_k2s2_s16_kernel<%d,%d,true>", CIN, RT);
+  vx_note_kernel(a.drop_mode == VX_DROP_MASK ? kname_m : kname);
+  if (a.drop_mode == VX_DROP_MASK)
+    hipLaunchKernelGGL((convT_k2s2_s16_kernel<CIN, RT, true>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a, ncoltiles,
+                       (int)nvox, dc);
+  else
+    hipLaunchKernelGGL((convT_k2s2_s16_kernel<CIN, RT, false>), dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, s, a, ncoltiles,
+                       (int)nvox, dc);
+  VX_CHECK_LAUNCH("vx_convT_k2s2(s16)");
+  return VX_OK;
+}
+
 template <int CIN, int RT>
 static int launch_convT_mfma(const vx_convT_args& a, hipStream_t s) {
   const int64_t nvox = (int64_t)a.N * a.D * a.H * a.W;
@@ -357,6 +524,11 @@ extern "C" int vx_convT_k2s2(const vx_convT_args* ap, vx_stream_t stream) {
     const int tiles = a.Cout / 2;
     if (a.Cin == 16 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<16, 4>(a, s) : launch_convT_mfma<16, 8>(a, s);
     if (a.Cin == 32 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<32, 4>(a, s) : launch_convT_mfma<32, 8>(a, s);
+    // the deep up-convolutions on the split-fp16 products (vx_config.conv_fp32 == 0: the family the convolutions run in)
+    if (vx_cfg().conv_fp32 == 0) {
+      if (a.Cin == 64 && tiles % 4 == 0) return launch_convT_s16<64, 4>(a, s);
+      if (a.Cin == 128 && tiles % 2 == 0) return launch_convT_s16<128, 2>(a, s);
+    }
     if (a.Cin == 64 && tiles % 4 == 0) return tiles % 8 ? launch_convT_mfma<64, 4>(a, s) : launch_convT_mfma<64, 8>(a, s);
     if (a.Cin == 128 && tiles % 4 == 0) return launch_convT_mfma<128, 4>(a, s);
   }

@@ -97,6 +97,8 @@ typedef struct vx_config {
                               normalise + pool pass of the second contract block */
   int32_t s16_no_halves;   /* expand_2_1 as ONE launch of the tile kernel over the x-blocked concat buffer instead of two launches of the
                               16-channel z-column kernel over its halves (round 5, vx_conv3d_args.acc_in, vx_unet3d_weights.split_w) */
+  int32_t s16_no_deep;     /* the general tile kernels instead of the role-split kernel of the deep layers (round 5, conv3d_deep.hip:
+                              Cout % 32 == 0, Cin >= 16, volumes of 32^3 voxels and below) */
   int32_t c2s_no_wide;     /* 2D 3x3 layers of <= 48 input channels: one work item per 16-channel sub-block (round 2) instead of
                               one per tile with all sub-blocks staged together; same bits */
   int32_t c2s_no_oct;      /* 2D 3x3 layers of <= 8 or 17..24 input channels: the sub-block K schedule (5 / 10 steps) instead of

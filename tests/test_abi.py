@@ -115,13 +115,17 @@ def test_host_only_queries(lib, vxcfg):
         rows = -(-cout // (16 * nt)) * 16 * nt
         pieces = 32 if xp else 64           # x-pair blocks are [co >> 2][kx 4][co & 3] pieces, not one per lane
         return (rows // 16) * (cin // cb) * steps * 2 * pieces * 8 // 2
-    for cin, cout in ((16, 8), (24, 8), (32, 16), (32, 32), (128, 64)):
-        assert lib.vx_conv3d_k3_packed_floats(cin, cout) == s16(cin, cout)
+    # round 5, family 7 (Cout % 32 == 0, Cin >= 16): the tile kernel's fragments followed by the deep-layer kernel's
+    # [Cout / 32][Cin / 8][7 K steps][2 row tiles][hi | lo][64 lanes][8 halves] (conv3d_deep.hip)
+    def deep(cin, cout):
+        return (cout // 32) * (cin // 8) * 7 * 2 * 2 * 64 * 8 // 2 if cout % 32 == 0 and cin >= 16 else 0
+    for cin, cout in ((16, 8), (24, 8), (32, 16), (32, 32), (128, 64), (8, 32)):
+        assert lib.vx_conv3d_k3_packed_floats(cin, cout) == s16(cin, cout) + deep(cin, cout)
     # round 5, family 6 (Cout = 16, Cin in {8, 16}): the tile kernel's fragments followed by the z-column kernel's
     # [14 or 9 K steps][hi | lo][64 lanes][8 halves] (conv3d_zc16.hip; which kernel runs depends on the volume's shape)
     assert lib.vx_conv3d_k3_packed_floats(16, 16) == s16(16, 16) + 14 * 2 * 64 * 8 // 2
     assert lib.vx_conv3d_k3_packed_floats(8, 16) == s16(8, 16) + 9 * 2 * 64 * 8 // 2
-    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (8, 16), (32, 16), (16, 32), (3, 8))] == [2, 6, 6, 1, 1, 0]
+    assert [lib.vx_conv3d_k3_family(ci, co) for ci, co in ((16, 8), (16, 16), (8, 16), (32, 16), (16, 32), (8, 32), (128, 128), (3, 8))] == [2, 6, 6, 1, 7, 1, 7, 0]
     assert lib.vx_conv3d_k3_pool_layout(64, 64, 64, 8, 8) == 1 and lib.vx_conv3d_k3_pool_layout(32, 32, 32, 16, 16) == 2
     assert lib.vx_conv3d_k3_pool_layout(16, 16, 16, 16, 16) == 0 and lib.vx_conv3d_k3_pool_layout(32, 32, 32, 32, 32) == 0
     vxcfg.set(s16_no_zc16=1)

@@ -1414,3 +1414,144 @@ def test_conv3d_zc16_fused_upconvolution_matches_oracle(shape, split, vxcfg):
     assert lib.vx_conv3d_k3_upfuse_ok(d, h, w, 16, 16) == 0
     with pytest.raises(_lib.VxError):
         _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the role-split kernel of the deep layers (conv3d_deep.hip: Cout % 32 == 0, volumes of 32^3 and below)
+def _deep_launch(x_dev, cin, cout, wp, bd, n, d, h, w, *, act=0, drop=0, seed=0, layer=0, stats=False, pre=None, in_xblk=0,
+                 out_split=False, out_pitch=None, out_coff=0):
+    """one vx_conv3d_k3 launch on a dense channels-last (or x-blocked concat) device input.
+    Returns (out device tensor, stats or None, kernel name)"""
+    lib = _lib.load()
+    a = _lib.ConvArgs()
+    a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+    op = out_pitch or cout
+    out = torch.full((n, d, h, w, op), -77.0, dtype=torch.float32, device=dev())
+    a.in_ = x_dev.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = bd.data_ptr(); a.out = out.data_ptr()
+    a.in_pitch, a.out_pitch, a.out_coff = cin, op, out_coff
+    a.in_xblk = in_xblk
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+    a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, seed, layer
+    a.out_half, a.out_split = 1, 1 if out_split else 0
+    st = None
+    if stats:
+        nt = lib.vx_conv3d_k3_tiles_for(d, h, w, cout)
+        st = torch.full((n, nt, cout, 2), 5.0, dtype=torch.float32, device=dev())
+        a.stats_partial = st.data_ptr()
+    if pre is not None:
+        a.in_mean, a.in_rstd, a.in_repeat = pre[0].data_ptr(), pre[1].data_ptr(), 1
+        a.in_drop_mode, a.in_drop_seed, a.in_drop_layer = pre[2], pre[3], pre[4]
+    _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "vx_conv3d_k3")
+    torch.cuda.synchronize()
+    return out, st, lib.vx_last_kernel_name().decode()
+
+
+def _pack_deep(cin, cout, seed):
+    lib = _lib.load()
+    wt = torch.from_numpy(formula_tensor((cout, cin, 3, 3, 3), seed, scale=(1.0 / (27 * cin)) ** 0.5)).float().contiguous()
+    b = torch.from_numpy(formula_tensor((cout,), seed + 1, scale=0.2)).float().contiguous()
+    wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+    _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt.to(dev())), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+    return wt, b, wp, b.to(dev())
+
+
+# (Cin, Cout, (N, D, H, W)): the 64^3 network's deep layers (16^3 / 8^3 / 4^3), several tiles per sample in every direction,
+# four 4^3 samples per tile, non-cubic volumes, more tiles than workgroups' first round
+DEEP_CASES = [(16, 32, (2, 16, 16, 16)), (32, 32, (1, 8, 16, 32)), (32, 64, (3, 8, 8, 8)), (64, 64, (2, 8, 8, 8)),
+              (64, 128, (8, 4, 4, 4)), (128, 128, (4, 4, 4, 4)), (24, 32, (1, 4, 8, 16)), (32, 32, (2, 12, 8, 8)),
+              (16, 64, (2, 8, 16, 16))]
+
+
+@pytest.mark.parametrize("cin,cout,shape", DEEP_CASES)
+def test_conv3d_deep_plain_and_activation_epilogues_match_oracle(cin, cout, shape, vxcfg):
+    """conv3d_deep.hip (round 5; unet3D_module.py:81-120, 231-243, 263-267 at the 16^3 / 8^3 / 4^3 levels): bias + statistics,
+    LeakyReLU / ReLU, LeakyReLU + hash dropout (+ the pre-split hand-over, + an output pitch wider than Cout) against the
+    float64 oracle; the knob that switches the kernel off gives the tile kernel's numbers."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_family(cin, cout) == 7
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 801, scale=1.5)).float()
+    wt, b, wp, bd = _pack_deep(cin, cout, 802)
+    xd = cl(x).to(dev())
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    tol = 4e-5
+    # --- bias + statistics (EPI 0)
+    out, st, kn = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, stats=True)
+    multi = d * h * w < 256                  # several samples per tile: per-sample statistics stay with the tile kernel
+    assert (kn.startswith("conv3d_k3_s16_kernel") if multi else kn.startswith("conv3d_deep_kernel<") and kn.endswith(",0,0>")), kn
+    got = ncdhw(out).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < tol, err
+    ssum = st.double().sum(1).cpu()
+    np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ssum[..., 1].numpy(), (got.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    # --- run-time activation (EPI 3), into a wider output at a channel offset
+    for act, fn in ((_lib.VX_ACT_LRELU, lambda t: F.leaky_relu(t, 0.01)), (_lib.VX_ACT_RELU, F.relu), (0, lambda t: t)):
+        o2, _, kn = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, act=act, out_pitch=cout + 8, out_coff=4)
+        assert kn.startswith("conv3d_deep_kernel<") and kn.endswith(",3,0>"), kn
+        assert (ncdhw(o2[..., 4:4 + cout]).cpu().double() - fn(ref)).abs().max().item() < tol
+        assert (o2[..., :4] == -77.0).all() and (o2[..., 4 + cout:] == -77.0).all()
+    # --- LeakyReLU + hash dropout (EPI 1), plain / pre-split
+    keep = _hash_mask(77, 13, n, cout, d, h, w)
+    want = F.leaky_relu(ref, 0.01) * keep * 2.0
+    o3, _, kn = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13)
+    assert kn.startswith("conv3d_deep_kernel<") and kn.endswith(",1,0>"), kn
+    assert (ncdhw(o3).cpu().double() - want).abs().max().item() < tol
+    o4, _, _ = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=77, layer=13, out_split=True)
+    hl = o4.cpu().contiguous().view(torch.float16).view(n, d, h, w, cout // 4, 2, 4).float()      # [quad][hi | lo][4]
+    back = (hl[..., 0, :] + hl[..., 1, :] / 2048.0).reshape(n, d, h, w, cout)
+    assert (back - o3.cpu()).abs().max().item() <= 1e-6 * max(1.0, o3.abs().max().item())
+    # --- the knob: the tile kernel on the same launch
+    vxcfg.set(s16_no_deep=1)
+    o6, st6, kn = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, stats=True)
+    assert kn.startswith("conv3d_k3_s16_kernel"), kn
+    assert (ncdhw(o6).cpu().double() - ref).abs().max().item() < tol
+    assert (o6 - out).abs().max().item() < 2e-5
+    np.testing.assert_allclose(st6.double().sum(1).cpu().numpy(), ssum.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 16, 16, 16)), (64, 64, (3, 8, 8, 8)), (16, 32, (1, 8, 8, 16))])
+@pytest.mark.parametrize("pmode", [1, 0])
+def test_conv3d_deep_prologue_matches_oracle(cin, cout, shape, pmode, vxcfg):
+    """The second conv of a contract block at the deep levels (contr_3_2 / contr_4_2): normalise-on-load of the raw first conv
+    (InstanceNorm + LeakyReLU + hash dropout in the staging waves) + its own statistics (unet3D_module.py:231-237)."""
+    n, d, h, w = shape
+    raw = (torch.from_numpy(formula_tensor((n, cin, d, h, w), 811, scale=2.0)) + 0.3).float()
+    wt, b, wp, bd = _pack_deep(cin, cout, 812)
+    mean = raw.double().mean((2, 3, 4)).float().contiguous().to(dev())
+    rstd = (1.0 / torch.sqrt(raw.double().var((2, 3, 4), unbiased=False) + 1e-5)).float().contiguous().to(dev())
+    keep_in = _hash_mask(61, 4, n, cin, d, h, w) if pmode else torch.ones((n, cin, d, h, w), dtype=torch.float64)
+    xin = F.leaky_relu((raw.double() - mean.cpu().double().view(n, cin, 1, 1, 1)) * rstd.cpu().double().view(n, cin, 1, 1, 1), 0.01)
+    xin = xin * keep_in * (2.0 if pmode else 1.0)
+    ref = F.conv3d(xin, wt.double(), b.double(), padding=1)
+    pre = (mean, rstd, _lib.VX_DROP_HASH if pmode else _lib.VX_DROP_NONE, 61, 4)
+    out, st, kn = _deep_launch(cl(raw).to(dev()), cin, cout, wp, bd, n, d, h, w, stats=True, pre=pre)
+    assert kn.startswith("conv3d_deep_kernel<") and kn.endswith(",0,1>"), kn
+    got = ncdhw(out).cpu()
+    err = (got.double() - ref).abs().max().item()
+    assert err < 6e-5, err
+    ssum = st.double().sum(1).cpu()
+    np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    vxcfg.set(s16_no_deep=1)
+    o2, _, kn = _deep_launch(cl(raw).to(dev()), cin, cout, wp, bd, n, d, h, w, stats=True, pre=pre)
+    assert kn.startswith("conv3d_k3_s16_kernel"), kn
+    assert (o2 - out).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("csrc,cout,shape,xb", [(32, 32, (2, 16, 16, 16), 4), (64, 64, (2, 8, 8, 8), 4), (16, 32, (1, 8, 8, 16), 2),
+                                                 (128, 128, (4, 4, 4, 4), 2)])
+def test_conv3d_deep_reads_the_x_blocked_concat_buffer(csrc, cout, shape, xb, vxcfg):
+    """The first conv of an expand block (expand_4_1 / expand_3_1) reads cat([up, skip], 1) from the x-blocked buffer
+    [N][D][H][W/xb][2][xb][C] (unet3D_module.py:263-267, 332-356): chunks of the up half, then of the skip half."""
+    n, d, h, w = shape
+    cin = 2 * csrc
+    up = torch.from_numpy(formula_tensor((n, csrc, d, h, w), 821, scale=1.2)).float()
+    skip = torch.from_numpy(formula_tensor((n, csrc, d, h, w), 822, scale=0.9)).float()
+    wt, b, wp, bd = _pack_deep(cin, cout, 823)
+    ref = F.leaky_relu(F.conv3d(torch.cat([up, skip], 1).double(), wt.double(), b.double(), padding=1), 0.01)
+    keep = _hash_mask(5, 9, n, cout, d, h, w)
+    buf = to_xblk(up, skip, xb).to(dev())
+    out, _, kn = _deep_launch(buf, cin, cout, wp, bd, n, d, h, w, act=_lib.VX_ACT_LRELU, drop=_lib.VX_DROP_HASH, seed=5, layer=9, in_xblk=xb)
+    assert kn.startswith("conv3d_deep_kernel<") and kn.endswith(",1,0>"), kn
+    err = (ncdhw(out).cpu().double() - ref * keep * 2.0).abs().max().item()
+    assert err < 6e-5, err

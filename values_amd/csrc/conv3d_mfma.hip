@@ -54,6 +54,12 @@ bool vx_conv3d_zc16_applies(int D, int H, int W, int Cin, int Cout);
 int64_t vx_conv3d_zc16_packed_floats(int Cin, int Cout);
 int vx_pack_conv3d_zc16(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
 int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_tiles, hipStream_t s);   // 1 = not taken
+// conv3d_deep.hip: the role-split tile kernel of the deep layers (Cout % 32 == 0, volumes of 32^3 and below)
+bool vx_conv3d_deep_packs(int Cin, int Cout);
+bool vx_conv3d_deep_applies(int N, int D, int H, int W, int Cin, int Cout);
+int64_t vx_conv3d_deep_packed_floats(int Cin, int Cout);
+int vx_pack_conv3d_deep(const float* w_torch, float* w_packed, int Cin, int Cout, hipStream_t s);
+int vx_conv3d_k3_deep(const vx_conv3d_args& a, const float* w_block, int stat_tiles, hipStream_t s);   // 1 = not taken
 void vx_conv3d_s16_tile(int H, int W, int Cout, int* txv, int* ty, int* tz);
 
 struct ConvKArgs {
@@ -516,6 +522,8 @@ extern "C" int vx_conv3d_k3_family(int Cin, int Cout) {
   const ConvCfg c = conv_config(Cin, Cout);
   // 6: the tile kernel's fragments FOLLOWED BY the z-column kernel's (conv3d_zc16.hip: which of the two runs depends on the
   // volume's shape, known only at launch)
+  // 7: the tile kernel's fragments FOLLOWED BY the deep-layer kernel's (conv3d_deep.hip; Cout % 32 == 0, Cin >= 16)
+  if (c.S16 && !vx_conv3d_s16_head_fusable(Cin, Cout) && vx_conv3d_deep_packs(Cin, Cout)) return 7;
   if (c.S16) return vx_conv3d_s16_head_fusable(Cin, Cout) ? 2 : (vx_conv3d_zc16_packs(Cin, Cout) ? 6 : 1);   // head-fusable == x-pair packing
   if (c.C8) return 5;
   return c.XP ? 4 : 3;
@@ -525,7 +533,7 @@ extern "C" int64_t vx_conv3d_k3_packed_floats(int Cin, int Cout) {
   if (Cin % 8 != 0 || Cout % 8 != 0 || Cin <= 0 || Cout <= 0) return -1;
   ConvCfg c = conv_config(Cin, Cout);
   if (c.C8) return (int64_t)27 * Cin * 8;
-  if (c.S16) return vx_conv3d_s16_packed_floats(Cin, Cout) + vx_conv3d_zc16_packed_floats(Cin, Cout);
+  if (c.S16) return vx_conv3d_s16_packed_floats(Cin, Cout) + vx_conv3d_zc16_packed_floats(Cin, Cout) + vx_conv3d_deep_packed_floats(Cin, Cout);
   if (c.XP) return (int64_t)16 * Cin * 36;
   return (int64_t)conv_rows_padded(Cout, c.NT) * Cin * 27;
 }
@@ -538,7 +546,10 @@ extern "C" int vx_pack_conv3d_k3(const float* w_torch, float* w_packed, int Cin,
   if (c.C8) return vx_pack_conv3d_k3_c8(w_torch, w_packed, Cin, (hipStream_t)stream);
   if (c.S16) {
     const int rc = vx_pack_conv3d_k3_s16(w_torch, w_packed, Cin, Cout, (hipStream_t)stream);
-    if (rc != VX_OK || !vx_conv3d_zc16_packs(Cin, Cout)) return rc;
+    if (rc != VX_OK) return rc;
+    if (vx_conv3d_deep_packs(Cin, Cout))      // (never both: the z-column kernel packs Cout = 16)
+      return vx_pack_conv3d_deep(w_torch, w_packed + vx_conv3d_s16_packed_floats(Cin, Cout), Cin, Cout, (hipStream_t)stream);
+    if (!vx_conv3d_zc16_packs(Cin, Cout)) return rc;
     return vx_pack_conv3d_zc16(w_torch, w_packed + vx_conv3d_s16_packed_floats(Cin, Cout), Cin, Cout, (hipStream_t)stream);
   }
   int blocks = (int)((total + 255) / 256);
@@ -799,6 +810,12 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     // the Cout = 16 layers below full resolution: role-split z-column kernel (conv3d_zc16.hip); its weights follow the tile
     // kernel's in the packed block (family 6)
     const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
+    if (rc != 1) return rc;
+  }
+  if (c.S16 && vx_conv3d_deep_applies(a.N, a.D, a.H, a.W, a.Cin, a.Cout)) {
+    // the deep layers (Cout % 32 == 0 on small volumes): role-split tile kernel (conv3d_deep.hip); its weights follow the tile
+    // kernel's in the packed block (family 7)
+    const int rc = vx_conv3d_k3_deep(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
   // the tile kernel's prologue: a dense input, or (round 5) the skip half of an x-blocked concat input whose halves are whole

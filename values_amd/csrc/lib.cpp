@@ -63,6 +63,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_poolfin = env_int("VX_S16_NO_POOLFIN", 0);
   g_cfg.s16_no_zc16 = env_int("VX_S16_NO_ZC16", 0);
   g_cfg.s16_no_halves = env_int("VX_S16_NO_HALVES", 0);
+  g_cfg.s16_no_deep = env_int("VX_S16_NO_DEEP", 0);
   g_cfg.c2s_no_wide = env_int("VX_C2S_NO_WIDE", 0);
   g_cfg.c2s_no_oct = env_int("VX_C2S_NO_OCT", 0);
 }

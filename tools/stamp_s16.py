@@ -85,10 +85,10 @@ for spec in sys.argv[1:] or ["8:8:64:0:0:0", "8:8:64:1:1:1", "16:8:64:1:1:0"]:
         continue
     kname = lib.vx_last_kernel_name().decode()
     print("  kernel", kname)
-    if "xp8w" not in kname and "zc16" not in kname:
+    if "xp8w" not in kname and "zc16" not in kname and "deep" not in kname:
         d = d.reshape(-1, 8, 8)[: 4096]      # 8-wave kernels index [workgroup][8 waves]
     groups = [("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))]
-    if "xp8w" in kname or "zc16" in kname:
+    if "xp8w" in kname or "zc16" in kname or "deep" in kname:
         groups.append(("producers", slice(8, 16)))
     for half, sl in groups:
         dd = d[:, sl]

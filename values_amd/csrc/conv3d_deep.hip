@@ -23,7 +23,8 @@
 struct DeepArgs {
   vx_conv3d_args a;
   const float* w;                 // this kernel's block of the packed weights (vx_conv3d_deep_packed_floats)
-  int tx, ty, tz, ts;             // tile: voxels along x, y, z; samples (> 1 only when a tile is whole samples)
+  int tx, ty, tz, ts;             // tile: voxels along x, y, z (powers of two); samples (> 1 only when a tile is whole samples)
+  int ltx, lty, ltz;              // their base-2 logarithms
   int tiles_x, tiles_y, tiles_z;
   int npos;                       // halo positions of a tile: ts (tx + 2)(ty + 2)(tz + 2)
   int nchunks, ncg;               // 8-channel input chunks; 32-row output groups
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* s_img = smem_raw;
   unsigned char* s_w = smem_raw + 2 * DEEP_IMG_B;
-  float* s_red = reinterpret_cast<float*>(s_w + 2 * DEEP_W_B);        // [NW][32][2]
-  float* s_bias = s_red + NW * 32 * 2;                                // [Cout]
+  float* s_red = reinterpret_cast<float*>(s_w + 2 * DEEP_W_B);        // [tile parity 2][NW][32][2]
+  float* s_bias = s_red + 2 * NW * 32 * 2;                            // [Cout]
 
   const vx_conv3d_args& a = ka.a;
   auto kernarg = [&]() {      // fields used once per tile are re-read where they are used (conv3d_xp8w.hip)
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
   // into the other buffer and load S_{j+2}, the multiplying waves compute S_j.
   if (wave >= NW) {
     // =============================================== STAGING ===============================================
+    // raised priority where the staging waves are the critical path -- with the prologue, and on the small tile (half the matrix
+    // work per item for the same weight chunk): same-process A/B at 320 samples -3 % / -1.5 .. -3 %; +4 % on the large plain tile
+    if constexpr (PRE != 0 || R == 2) __builtin_amdgcn_s_setprio(2);
     const int t = tid - NW * 64;
     const int q = t & 1;                           // the thread's 4-channel quad of the chunk (256 threads: constant over its pieces)
     const int xb = a.in_xblk;
@@ -277,26 +281,26 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
     // =============================================== MULTIPLYING ===============================================
     // column tile r of this wave: voxels (wave R + r) 16 + m of the tile, ordered (sample, z, y, x)
     int vbase[R];                  // byte offset of the voxel's halo position at tap (0, 0, 0)
-    unsigned ovoff[R], eoff[R];
-    int smp_r[R];
     const int out_voxf = a.out_pitch;
     const size_t out_sample = (size_t)a.D * a.H * a.W * out_voxf;
+    // (tile extents are powers of two: a voxel's coordinates are shifts and masks -- the epilogue recomputes them per tile
+    // instead of holding three more registers per column tile across the matrix loop)
+    auto vox_of = [&](int v, int& cx_, int& ly, int& lz, int& smp) {
+      cx_ = v & (TX - 1); v >>= ka.ltx;
+      ly = v & (TY - 1); v >>= ka.lty;
+      lz = v & (TZ - 1); smp = v >> ka.ltz;
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int v = (wave * R + r) * 16 + m;
-      const int cx_ = v % TX, r1 = v / TX;
-      const int ly = r1 % TY, r2 = r1 / TY;
-      const int lz = r2 % TZ, smp = r2 / TZ;
+      int cx_, ly, lz, smp;
+      vox_of((wave * R + r) * 16 + m, cx_, ly, lz, smp);
       vbase[r] = (((smp * HZ + lz) * HY + ly) * HX + cx_) * 16;
-      const int ovox = (lz * a.H + ly) * a.W + cx_;
-      ovoff[r] = (unsigned)(((size_t)smp * out_sample + (size_t)ovox * out_voxf + a.out_coff + 4 * g) * 4);
-      eoff[r] = (unsigned)(ovox * a.Cout + 4 * g);
-      smp_r[r] = smp;
     }
     int toff[NSTEP];               // this lane's tap of every step, as a byte offset (the 28th tap re-reads the 27th: zero weights, finite data)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       int tap = 4 * s + g;
+      if (DP_ABL & 64) tap = 4 * s;              // (diagnostic build: every k-group reads the same positions -- no bank conflicts)
       if (tap > 26) tap = 26;
       toff[s] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
     }
@@ -307,32 +311,67 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
 
     f32x4 acc[R][NT], accx[R][NT];
 
+    // ONE software pipeline over the 7 K-steps of an item, 6 R matrix instructions each, row tile by row tile.  Every fragment of
+    // step s + 1 is requested at least 11 matrix instructions before its first use, into registers that are free by then, and
+    // pinned there (sched_group_barrier) -- left alone hipcc sinks every ds_read_b128 to just before its consumer and the wave
+    // waits out an LDS latency per tile:
+    //   hi halves of the B fragments (used by both products of a row tile): a second register set, requested behind the first
+    //     row tile's matrix instructions;
+    //   lo halves (one product per row tile): the same registers, each behind its last use in the second row tile;
+    //   A fragments of a row tile: behind that row tile's last matrix instruction.
+    // Within a row tile the two products into the cross accumulator sit R matrix instructions apart (no dependent pair).
     auto multiply = [&](int buf) {
       const unsigned char* img = s_img + buf * DEEP_IMG_B;
       const unsigned char* wb = wlane + buf * DEEP_W_B;
+      f16x8 wh[NT], wl[NT], bh[2][R], bl[R];
+      int vb_[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { vb_[r] = vbase[r]; asm volatile("" : "+v"(vb_[r])); }   // (the 7 R address sums stay inside the item: not 28 registers across the loop)
+      auto ldA = [&](int s, int nt) {
+        wh[nt] = *reinterpret_cast<const f16x8*>(wb + ((s * NT + nt) * 2) * 1024);
+        wl[nt] = *reinterpret_cast<const f16x8*>(wb + ((s * NT + nt) * 2 + 1) * 1024);
+      };
+      auto ldBh = [&](int s, int r) { bh[s & 1][r] = *reinterpret_cast<const f16x8*>(img + vb_[r] + toff[s]); };
+      auto ldBl = [&](int s, int r) { bl[r] = *reinterpret_cast<const f16x8*>(img + vb_[r] + toff[s] + DEEP_PREC_B); };
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) ldA(0, nt);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { ldBh(0, r); ldBl(0, r); }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2 * R, 0);
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
-        f16x8 wh[NT], wl[NT];
+        const bool more = s + 1 < NSTEP;
+        const int set = s & 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          wh[nt] = *reinterpret_cast<const f16x8*>(wb + ((s * NT + nt) * 2) * 1024);
-          wl[nt] = *reinterpret_cast<const f16x8*>(wb + ((s * NT + nt) * 2 + 1) * 1024);
-        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const f16x8 bh = *reinterpret_cast<const f16x8*>(img + vbase[r] + toff[s]);
-          const f16x8 bl = *reinterpret_cast<const f16x8*>(img + vbase[r] + toff[s] + DEEP_PREC_B);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh, acc[r][nt], 0, 0, 0);
-            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl, accx[r][nt], 0, 0, 0);
-            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh, accx[r][nt], 0, 0, 0);
+          for (int r = 0; r < R; ++r) {
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bh[set][r], acc[r][nt], 0, 0, 0);
+            accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], bl[r], accx[r][nt], 0, 0, 0);
+            if (more && nt == 0) ldBh(s + 1, r);
+            if (more && nt == NT - 1) ldBl(s + 1, r);
           }
+#pragma unroll
+          for (int r = 0; r < R; ++r) accx[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], bh[set][r], accx[r][nt], 0, 0, 0);
+          if (more) ldA(s + 1, nt);
         }
+#ifndef DEEP_NO_PIPE
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, R, 0);
+          if (more) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#endif
       }
     };
 
     auto epilogue = [&](int ci) {
+      float* red = s_red + (ci & 1) * (NW * 32 * 2);
       int n0, tzi, tyi, txi, cg;
       pair_of(ci, n0, tzi, tyi, txi, cg);
       const auto kp = kernarg();
@@ -347,10 +386,21 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ssum[nt][j] = 0.f; ssq[nt][j] = 0.f; }
       }
+      int m_ = m;
+      asm volatile("" : "+v"(m_));      // (keeps the per-tile address arithmetic below inside the epilogue)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        uint32_t key = 0;
-        if (EPI == 1) key = vx_drop_key(seed_out, kp->a.drop_layer, (uint32_t)(n0 + smp_r[r]));
+        int cx_, ly, lz, smp;
+        vox_of((wave * R + r) * 16 + m_, cx_, ly, lz, smp);
+        const int ovox = (lz * a.H + ly) * a.W + cx_;
+        // (32-bit offsets: the host checked that a tile's samples stay below 2 GiB)
+        const unsigned ovoff_r = ((unsigned)smp * (unsigned)out_sample + (unsigned)ovox * (unsigned)out_voxf + (unsigned)kp->a.out_coff + 4u * g) * 4u;
+        // ONE keep-word per voxel: the workgroup's 32 output channels are bits 0..31 of word voxel * (Cout / 32) + cg
+        uint32_t hword = 0;
+        if (EPI == 1) {
+          const uint32_t key = vx_drop_key(seed_out, kp->a.drop_layer, (uint32_t)(n0 + smp));
+          hword = vx_mix32(((vox0 + (unsigned)ovox) * (unsigned)ka.ncg + (unsigned)cg) ^ key) >> (4 * g);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling)
@@ -368,11 +418,11 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
           }
           if (EPI == 1) {
-            const uint32_t bits = vx_drop_bits4(key, vox0 * (unsigned)a.Cout + eoff[r] + (unsigned)(cg * 32 + nt * 16));
+            const uint32_t bits = hword >> (16 * nt);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= __uint_as_float((bits << (30 - j)) & 0x40000000u);
           }
-          if (!STATS) rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          if (!STATS) rmax = vx_max3abs(vx_max3abs(rmax, v[0], v[1]), v[2], v[3]);
           u32x4 sv = __builtin_bit_cast(u32x4, v);
           if (EPI == 1 || EPI == 3) {
             if (a.out_split) {   // the consumer is a fused up-convolution: hand the piece over as the fp16 pairs it multiplies
@@ -383,7 +433,7 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
               sv = (u32x4){h2[0], h2[1], l2[0], l2[1]};
             }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(sv, osrd, (int)ovoff[r], (int)(osoff + (unsigned)(nt * 64)), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(sv, osrd, (int)ovoff_r, (int)(osoff + (unsigned)(nt * 64)), 0);
           // gfx950 store-data hazard with an SGPR soffset (conv3d_mfma.hip)
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_nop 3" ::: "memory");
@@ -400,8 +450,8 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
 #pragma unroll
             for (int rot = 8; rot >= 1; rot >>= 1) { s += vx_row_ror(s, rot); qq += vx_row_ror(qq, rot); }
             if (m == 0) {
-              s_red[(wave * 32 + nt * 16 + g * 4 + j) * 2 + 0] = s;
-              s_red[(wave * 32 + nt * 16 + g * 4 + j) * 2 + 1] = qq;
+              red[(wave * 32 + nt * 16 + g * 4 + j) * 2 + 0] = s;
+              red[(wave * 32 + nt * 16 + g * 4 + j) * 2 + 1] = qq;
             }
           }
       }
@@ -410,6 +460,7 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
     // statistics of a complete tile: entry 0 of the tile's block is real, the other stat_epc - 1 are zero
     // (vx_instnorm_finalize sums vx_conv3d_k3_tiles_for entries per sample)
     auto flush_tile = [&](int ci) {
+      const float* red = s_red + (ci & 1) * (NW * 32 * 2);
       int n0, tzi, tyi, txi, cg;
       pair_of(ci, n0, tzi, tyi, txi, cg);
       const auto kp = kernarg();
@@ -421,8 +472,8 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
         float s = 0.f, qq = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-          s += s_red[(w * 32 + tid) * 2 + 0];
-          qq += s_red[(w * 32 + tid) * 2 + 1];
+          s += red[(w * 32 + tid) * 2 + 0];
+          qq += red[(w * 32 + tid) * 2 + 1];
         }
         dst[tid * 2 + 0] = s;
         dst[tid * 2 + 1] = qq;
@@ -431,13 +482,22 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
         if (tid < 64) dst[(size_t)e * a.Cout * 2 + tid] = 0.f;
     };
 
+    // waves 0..3 multiply(j) then store a finished tile; waves 4..7 store the tile they finished in the previous iteration FIRST,
+    // then multiply(j): the partner wave of a SIMD multiplies while the other runs the tile's epilogue
+    const bool late = wave >= NW / 2;
     Cur cx = {0, 0};
     int j = 0;
-    int fl_ci = -1;                               // tile whose statistics sit in s_red, complete after the next barrier
+    int prev_ci = -1;                             // waves 4..7: the tile still to store
+    int fl_ci = -1, fl_at = 0;                    // tile whose statistics are complete in s_red after barrier fl_at
     while (cx.ci < npair_wg) {
       __syncthreads();
       DP_STAMP(0);
-      if (STATS && fl_ci >= 0) { flush_tile(fl_ci); fl_ci = -1; }
+      if (STATS && fl_ci >= 0 && j >= fl_at && !late) { flush_tile(fl_ci); fl_ci = -1; }
+      if (late && prev_ci >= 0) {
+        if (!(DP_ABL & 2)) epilogue(prev_ci);      // (raised priority for it: measured nothing)
+        prev_ci = -1;
+      }
+      DP_STAMP(2);
       if (cx.c == 0) {
         int n0, tzi, tyi, txi, cg;
         pair_of(cx.ci, n0, tzi, tyi, txi, cg);
@@ -452,8 +512,9 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       if (!(DP_ABL & 1)) multiply(j & 1);
       DP_STAMP(1);
       if (cx.c == NCH - 1) {
-        if (!(DP_ABL & 2)) epilogue(cx.ci);
-        if (STATS) fl_ci = cx.ci;
+        if (late) prev_ci = cx.ci;
+        else if (!(DP_ABL & 2)) epilogue(cx.ci);
+        if (STATS) { fl_ci = cx.ci; fl_at = j + 2; }
       }
       DP_STAMP(2);
 #ifdef VX_CONV_STAMPS
@@ -462,9 +523,10 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       advance(cx);
       ++j;
     }
+    if (late && prev_ci >= 0) epilogue(prev_ci);
     if (STATS) {
       __syncthreads();
-      if (fl_ci >= 0) flush_tile(fl_ci);
+      if (fl_ci >= 0 && !late) flush_tile(fl_ci);
     }
   }
   if (!STATS && a.range_flag) {
@@ -533,6 +595,7 @@ static bool deep_geo(int N, int D, int H, int W, int R, DeepGeo* o) {
   if (tz < 1 || D % tz) return false;
   int ts = vox / (tx * ty * tz);
   if (ts * tx * ty * tz != vox) return false;
+  if ((ty & (ty - 1)) || (tz & (tz - 1))) return false;      // (the kernel decodes a tile's voxels with shifts)
   if (ts > 1 && (tx != W || ty != H || tz != D || N % ts)) return false;
   const int npos = ts * (tx + 2) * (ty + 2) * (tz + 2);
   if (npos > (R == 4 ? DEEP_NPOS : 896)) return false;      // the image's positions; 2 npos pieces in IN_IT x 256
@@ -552,7 +615,9 @@ static int deep_pick(int N, int D, int H, int W, int Cout, DeepGeo* o) {
     return (double)pairs / (double)(rounds * 256);
   };
   int r = ok4 ? 4 : 2;
-  if (ok4 && ok2 && eff(g2) > 1.15 * eff(g4)) r = 2;
+  // (8^3 x 64 channels at 320 samples: 640 large tiles fill 2.5 rounds of workgroups, 1 280 small ones 5 -- and the large tile is
+  // still 2 % faster; at 16^3 the small tile costs 20 %)
+  if (ok4 && ok2 && eff(g2) > 1.3 * eff(g4)) r = 2;
   static const int force = getenv("VX_DEEP_R") ? atoi(getenv("VX_DEEP_R")) : 0;      // (tuning)
   if (force == 4 && ok4) r = 4;
   if (force == 2 && ok2) r = 2;
@@ -570,7 +635,7 @@ bool vx_conv3d_deep_applies(int N, int D, int H, int W, int Cin, int Cout) {
 
 template <int R, int EPI, int PRE>
 static int launch_deep(const DeepArgs& ka, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)DEEP_IMG_B + 2 * (size_t)DEEP_W_B + 8 * 32 * 2 * 4 + DEEP_MAXC * 4;
+  constexpr size_t lds = 2 * (size_t)DEEP_IMG_B + 2 * (size_t)DEEP_W_B + 2 * 8 * 32 * 2 * 4 + DEEP_MAXC * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv3d_deep_kernel<R, EPI, PRE>;
   static bool attr = false;
@@ -610,6 +675,7 @@ int vx_conv3d_k3_deep(const vx_conv3d_args& a, const float* w_block, int stat_ti
   ka.a = a;
   ka.w = w_block;
   ka.tx = g.tx; ka.ty = g.ty; ka.tz = g.tz; ka.ts = g.ts;
+  ka.ltx = __builtin_ctz((unsigned)g.tx); ka.lty = __builtin_ctz((unsigned)g.ty); ka.ltz = __builtin_ctz((unsigned)g.tz);
   ka.tiles_x = g.tiles_x; ka.tiles_y = g.tiles_y; ka.tiles_z = g.tiles_z;
   ka.npos = g.npos;
   ka.nchunks = a.Cin / 8;

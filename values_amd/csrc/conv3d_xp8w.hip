@@ -20,6 +20,8 @@ struct Xp8wArgs {
   int tiles_x, tiles_y, kz;   // columns per sample = tiles_x * tiles_y; kz = items per column
   int ncols;                  // columns in the launch (N * tiles_y * tiles_x)
   unsigned mcps, mtx;         // multiply-high magics: / (tiles_x * tiles_y), / tiles_x
+  int rep;                    // > 1: column order (source volume, column, sample of the volume) -- see col_of
+  unsigned mrep;              // multiply-high magic: / rep
   int stat_epc;               // statistics entries per column in stats_partial (entry 0 real, the rest zero)
   unsigned long long* stamps;
   int abl;                    // diagnostic build only: phase ablation bits (1 no multiply, 2 no epilogue, 4 no commit, 8 no loads)
@@ -136,10 +138,20 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
   struct Cur { int ci, s; };      // column number of this workgroup, step within the column (0 .. KZ)
   auto advance = [&](Cur& c) { if (++c.s > KZ) { c.s = 0; ++c.ci; } };
+  // Column order.  Plain: (sample, column).  With in_repeat = T samples reading ONE raw tensor (MC-dropout: contr_1_2 over the
+  // once-per-volume first-layer tensor) the T samples of a source volume's column are NEIGHBOURS in the order -- (volume, column,
+  // sample) -- so that they run at the same time on workgroups of one XCD and the column is fetched from HBM once: in the plain
+  // order the ten samples of a volume sat on five XCDs and the shared 0.27 GB tensor was fetched 1.31 GB worth (PMC, rounds 3-5).
   auto col_of = [&](int ci, int& n, int& ty, int& tx) {
-    const unsigned col = (unsigned)(vb + ci * G);
+    unsigned col = (unsigned)(vb + ci * G);
+    unsigned t_rep = 0;
+    if (ka.rep > 1) {
+      const unsigned qr = __umulhi(col, ka.mrep);
+      t_rep = col - qr * (unsigned)ka.rep;
+      col = qr;
+    }
     const unsigned q = cps == 1 ? col : __umulhi(col, ka.mcps);
-    n = (int)q;
+    n = ka.rep > 1 ? (int)(q * (unsigned)ka.rep + t_rep) : (int)q;
     const unsigned rem = col - q * (unsigned)cps;
     const unsigned q2 = ka.tiles_x == 1 ? rem : __umulhi(rem, ka.mtx);
     ty = (int)q2;
@@ -1200,6 +1212,11 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   const int cps = ka.tiles_x * ka.tiles_y;
   ka.ncols = a.N * cps;
   ka.mcps = (unsigned)((1ull << 32) / (unsigned)cps) + 1u;
+  ka.rep = (a.in_mean && a.in_repeat > 1 && a.N % a.in_repeat == 0) ? a.in_repeat : 1;
+#ifdef XP_NO_REPORDER
+  ka.rep = 1;
+#endif
+  ka.mrep = (unsigned)((1ull << 32) / (unsigned)ka.rep) + 1u;
   ka.mtx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.stat_epc = stat_tiles / cps;
   ka.stamps = nullptr;

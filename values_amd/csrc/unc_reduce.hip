@@ -19,6 +19,21 @@ template <> __device__ __forceinline__ double vx_log<double>(double v) { return 
 template <typename TIn> __device__ __forceinline__ TIn vx_exp(TIn v);
 template <> __device__ __forceinline__ float vx_exp<float>(float v) { return expf(v); }
 template <> __device__ __forceinline__ double vx_exp<double>(double v) { return exp(v); }
+// The softmax of the per-sample loop (round 5): the pass over the logits was bound by its ARITHMETIC, not by memory -- libm's
+// expf / logf / IEEE division are ~15 / ~20 / ~10 vector instructions each, ~85 per (voxel, sample) with two classes, 0.24 ms per
+// 32 x 10 x 2 x 64^3 logits where the bytes need 0.15.  The arguments are confined: z - max <= 0, 1 <= den <= C.  There the
+// hardware forms are accurate in ABSOLUTE terms -- exp2(d log2 e) is off by <= |d| 2^-23 relative, and |d| e^d <= 1 / e: < 5e-8
+// absolute on a probability; v_log_f32 on [1, C] and v_rcp_f32 are good to 1 ulp -- three orders below the 1e-4 the maps are held to
+// (and below the 2e-6 of the fixture tests).  The class of the maximum contributes exp(0) = 1 exactly and is not evaluated.
+template <typename TIn> __device__ __forceinline__ TIn vx_exp_np(TIn v);      // v <= 0
+template <> __device__ __forceinline__ float vx_exp_np<float>(float v) { return __expf(v); }
+template <> __device__ __forceinline__ double vx_exp_np<double>(double v) { return exp(v); }
+template <typename TIn> __device__ __forceinline__ TIn vx_log_den(TIn v);     // 1 <= v <= C
+template <> __device__ __forceinline__ float vx_log_den<float>(float v) { return __logf(v); }
+template <> __device__ __forceinline__ double vx_log_den<double>(double v) { return log(v); }
+template <typename TIn> __device__ __forceinline__ TIn vx_inv(TIn v);
+template <> __device__ __forceinline__ float vx_inv<float>(float v) { return __builtin_amdgcn_rcpf(v); }
+template <> __device__ __forceinline__ double vx_inv<double>(double v) { return 1.0 / v; }
 
 template <typename TIn, int VEC>
 __device__ __forceinline__ void load_vec(const TIn* p, TIn (&v)[VEC]) {
@@ -198,9 +213,9 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
         TIn e[C];
         TIn den = 0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { e[c] = vx_exp<TIn>(z[c][k] - m); den += e[c]; }
-        const TIn inv = (TIn)1 / den;
-        const TIn lden = vx_log<TIn>(den);
+        for (int c = 0; c < C; ++c) { e[c] = c == mi ? (TIn)1 : vx_exp_np<TIn>(z[c][k] - m); den += e[c]; }
+        const TIn inv = vx_inv<TIn>(den);
+        const TIn lden = vx_log_den<TIn>(den);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const TIn p = e[c] * inv;
@@ -221,7 +236,11 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
     float iout[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) iout[k] = 1.f;
-    if (EX && ex.out_count) load_inv_count<VEC>(ex.out_count, (int64_t)b * nvox + v0, iout);
+    const bool counted = EX && ex.out_count;      // (uniform: without counts nothing is divided by 1.f -- an IEEE division is ~11 instructions)
+    if (counted) load_inv_count<VEC>(ex.out_count, (int64_t)b * nvox + v0, iout);
+    // 1 / T once: the expected entropy and the variance moments are scaled by it (1 ulp from the division; the class means, which
+    // decide the arg-max, keep the division)
+    const TIn invT = (TIn)1 / (TIn)T;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       pe[k] = 0.f;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
       for (int c = 0; c < C; ++c) {
         float mo[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) mo[k] = (float)(sum[c][k] / (TIn)T) / iout[k];
+        for (int k = 0; k < VEC; ++k) { mo[k] = (float)(sum[c][k] / (TIn)T); if (counted) mo[k] /= iout[k]; }
         store_f32<VEC>(mean_prob + ((size_t)b * C + c) * nvox + v0, mo);
       }
     }
@@ -248,9 +267,9 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       o_pe[k] = -pe[k];
-      o_ee[k] = (float)(-ee[k] / (TIn)T);
+      o_ee[k] = (float)(-ee[k] * invT);
       o_mi[k] = o_pe[k] - o_ee[k];
-      if (EX && ex.out_count) { o_pe[k] /= iout[k]; o_ee[k] /= iout[k]; o_mi[k] /= iout[k]; }
+      if (counted) { o_pe[k] /= iout[k]; o_ee[k] /= iout[k]; o_mi[k] /= iout[k]; }
     }
     store_f32<VEC>(pred_entropy + (size_t)b * nvox + v0, o_pe);
     store_f32<VEC>(exp_entropy + (size_t)b * nvox + v0, o_ee);
@@ -263,11 +282,12 @@ __global__ __launch_bounds__(256) void unc_reduce_logit_kernel(const TIn* __rest
         TIn var = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const TIn md = d1[c][k] / (TIn)T;
-          const TIn vv = d2[c][k] / (TIn)T - md * md;
+          const TIn md = d1[c][k] * invT;
+          const TIn vv = d2[c][k] * invT - md * md;
           var += vv > (TIn)0 ? vv : (TIn)0;
         }
-        o_v[k] = (float)(var / (TIn)C) / (iout[k] * iout[k]);
+        o_v[k] = (float)(var * ((TIn)1 / (TIn)C));
+        if (counted) o_v[k] /= iout[k] * iout[k];
       }
       store_f32<VEC>(ex.variance + (size_t)b * nvox + v0, o_v);
     }

@@ -79,16 +79,21 @@ __device__ __forceinline__ void bil_coord(int d, int in, float ratio, int& i0, i
   l1 = s - (float)i0;
 }
 
+// Index scheme of the two streaming kernels below (round 5): grid = (pieces of an output row / 256, OH, N) -- image and row are
+// block indices, the piece within the row splits into (pixel, channel quad) with ONE 32-bit multiply-high.  The first form
+// decoded a flat 64-bit piece index with three 64-bit divisions per thread (~600 vector instructions around 3 loads and a
+// store): the passes ran at 0.15-0.2 of the HBM rate and were the top line of the C4 profile (18 % of the step).
 template <bool RESIZE>
-__global__ __launch_bounds__(256) void affine_gather_kernel(vx_affine_args a, int64_t total) {
+__global__ __launch_bounds__(256) void affine_gather_kernel(vx_affine_args a, unsigned mC4, int rowp) {
   const int C4 = a.C / 4;
   const float ry = (float)a.H / (float)a.OH, rx = (float)a.W / (float)a.OW;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i;
-    const int c = (int)(r % C4) * 4; r /= C4;
-    const int ox = (int)(r % a.OW); r /= a.OW;
-    const int oy = (int)(r % a.OH); r /= a.OH;
-    const int n = (int)r;
+  {
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p >= rowp) return;
+    const int ox = C4 == 1 ? (int)p : (int)__umulhi(p, mC4);
+    const int c = ((int)p - ox * C4) * 4;
+    const int oy = (int)blockIdx.y;
+    const int n = (int)blockIdx.z;
     const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
     auto fetch = [&](int y, int x) {
       const size_t pix = ((size_t)n * a.H + y) * a.W + x;
@@ -145,17 +150,18 @@ extern "C" int vx_affine_gather(const vx_affine_args* ap, vx_stream_t stream) {
     VX_FAIL(VX_E_ALIGN, "vx_affine_gather: pitches/offsets must be multiples of 4 floats");
   if (a.drop_mode == VX_DROP_MASK && !a.drop_mask) VX_FAIL(VX_E_NULL, "vx_affine_gather: mask mode without mask");
   if (a.act != VX_ACT_NONE && a.act != VX_ACT_RELU) VX_FAIL(VX_E_DTYPE, "vx_affine_gather: act must be none or relu");
-  const int64_t total = (int64_t)a.N * a.OH * a.OW * (a.C / 4);
-  // one piece per thread up to 2^20 blocks: with the grid capped at 16384 blocks a 1024 x 512 x 32-view tensor of 20 channels
-  // (5.2 M pieces) left a quarter of the threads a second trip -- and everybody waiting for it
-  int64_t nb = (total + 255) / 256;
-  if (nb > (1 << 20)) nb = 1 << 20;
-  const int blocks = (int)nb;
+  const int C4 = a.C / 4;
+  const int64_t rowp64 = (int64_t)a.OW * C4;
+  if (a.OH > 65535 || a.N > 65535 || rowp64 * C4 >= (1ll << 31))
+    VX_FAIL(VX_E_SHAPE, "vx_affine_gather: at most 65535 rows / images and 2^31 / (C / 4) pieces per row (got %d x %d x %d x %d)", a.N, a.OH, a.OW, a.C);
+  const int rowp = (int)rowp64;
+  const unsigned mC4 = (unsigned)((1ull << 32) / (unsigned)C4) + 1u;      // exact for p < 2^32 / C4
+  const dim3 grid((unsigned)((rowp + 255) / 256), (unsigned)a.OH, (unsigned)a.N);
   hipStream_t s = (hipStream_t)stream;
   if (a.OH != a.H || a.OW != a.W)
-    hipLaunchKernelGGL(affine_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, a, total);
+    hipLaunchKernelGGL(affine_gather_kernel<true>, grid, dim3(256), 0, s, a, mC4, rowp);
   else
-    hipLaunchKernelGGL(affine_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, a, total);
+    hipLaunchKernelGGL(affine_gather_kernel<false>, grid, dim3(256), 0, s, a, mC4, rowp);
   VX_CHECK_LAUNCH("vx_affine_gather");
   return VX_OK;
 }
@@ -163,14 +169,15 @@ extern "C" int vx_affine_gather(const vx_affine_args* ap, vx_stream_t stream) {
 // vx_fuse_sum: the terms of a SUM fusion in one pass (see the header); every term is evaluated with affine_gather_kernel's
 // expressions, the sum runs in term order -- the bits of the chained passes
 template <int NT>
-__global__ __launch_bounds__(256) void fuse_sum_kernel(vx_fuse_args a, int64_t total) {
+__global__ __launch_bounds__(256) void fuse_sum_kernel(vx_fuse_args a, unsigned mC4, int rowp) {
   const int C4 = a.C / 4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i;
-    const int c = (int)(r % C4) * 4; r /= C4;
-    const int ox = (int)(r % a.OW); r /= a.OW;
-    const int oy = (int)(r % a.OH); r /= a.OH;
-    const int n = (int)r;
+  {
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p >= rowp) return;
+    const int ox = C4 == 1 ? (int)p : (int)__umulhi(p, mC4);
+    const int c = ((int)p - ox * C4) * 4;
+    const int oy = (int)blockIdx.y;
+    const int n = (int)blockIdx.z;
     const size_t row = a.group_images > 0 ? (size_t)(n / a.group_images) * a.C : 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -219,15 +226,19 @@ extern "C" int vx_fuse_sum(const vx_fuse_args* ap, vx_stream_t stream) {
     if (!tm.x || tm.H <= 0 || tm.W <= 0 || tm.x_pitch % 4 || tm.x_pitch < a.C) VX_FAIL(VX_E_SHAPE, "vx_fuse_sum: term %d", t);
     if ((tm.scale == nullptr) != (tm.shift == nullptr)) VX_FAIL(VX_E_NULL, "vx_fuse_sum: scale / shift of term %d must come together", t);
   }
-  const int64_t total = (int64_t)a.N * a.OH * a.OW * (a.C / 4);
-  int64_t nb = (total + 255) / 256;
-  if (nb > (1 << 20)) nb = 1 << 20;
+  const int C4 = a.C / 4;
+  const int64_t rowp64 = (int64_t)a.OW * C4;
+  if (a.OH > 65535 || a.N > 65535 || rowp64 * C4 >= (1ll << 31))
+    VX_FAIL(VX_E_SHAPE, "vx_fuse_sum: at most 65535 rows / images and 2^31 / (C / 4) pieces per row (got %d x %d x %d x %d)", a.N, a.OH, a.OW, a.C);
+  const int rowp = (int)rowp64;
+  const unsigned mC4 = (unsigned)((1ull << 32) / (unsigned)C4) + 1u;
+  const dim3 grid((unsigned)((rowp + 255) / 256), (unsigned)a.OH, (unsigned)a.N);
   hipStream_t s = (hipStream_t)stream;
   switch (a.nterms) {
-    case 1: hipLaunchKernelGGL(fuse_sum_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
-    case 2: hipLaunchKernelGGL(fuse_sum_kernel<2>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
-    case 3: hipLaunchKernelGGL(fuse_sum_kernel<3>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
-    default: hipLaunchKernelGGL(fuse_sum_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, a, total); break;
+    case 1: hipLaunchKernelGGL(fuse_sum_kernel<1>, grid, dim3(256), 0, s, a, mC4, rowp); break;
+    case 2: hipLaunchKernelGGL(fuse_sum_kernel<2>, grid, dim3(256), 0, s, a, mC4, rowp); break;
+    case 3: hipLaunchKernelGGL(fuse_sum_kernel<3>, grid, dim3(256), 0, s, a, mC4, rowp); break;
+    default: hipLaunchKernelGGL(fuse_sum_kernel<4>, grid, dim3(256), 0, s, a, mC4, rowp); break;
   }
   VX_CHECK_LAUNCH("vx_fuse_sum");
   return VX_OK;

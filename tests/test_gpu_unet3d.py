@@ -556,6 +556,22 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     assert (alt["logits"] - out["logits"]).abs().max().item() < 2e-5
     for k in KEYS:
         assert np.abs(alt[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
+    # Round 5: the 16^3 / 8^3 layers (Cout = 32 / 64) ran on the role-split kernel of the deep layers (conv3d_deep.hip: statistics,
+    # normalise-on-load, the x-blocked concat input, LeakyReLU + dropout (+ the pre-split hand-over to the fused upscale3)); the knob
+    # runs the tile kernel on them
+    import re
+    count = lambda pat: sum(re.match(pat, n) is not None for n in names)      # (tile size 4 / 2: picked by the number of workgroups it fills)
+    assert count(r"conv3d_deep_kernel<[24],0,0>") == 2 and count(r"conv3d_deep_kernel<[24],0,1>") == 2, names
+    assert count(r"conv3d_deep_kernel<[24],1,0>") == 4, names
+    assert any(n.startswith("convT_k2s2_s16_kernel<64,4,false>") for n in names) and any(n.startswith("convT_k2s2_s16_kernel<128,2,false>") for n in names), names
+    with _lib.config(s16_no_deep=1):
+        alt = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+        names5 = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert not any("deep" in n for n in names5) and len(names5) == len(names)
+    assert np.abs(alt["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
+    assert (alt["logits"] - out["logits"]).abs().max().item() < 2e-5
+    for k in KEYS:
+        assert np.abs(alt[k][0].cpu().numpy() - ref[k]).max() < MAP_TOL, k
     # dropout off: the plain-epilogue instances, EPI = 0 / run-time activation
     det = make_model(do_dropout=False)
     with torch.no_grad():
@@ -768,7 +784,7 @@ def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():
     assert torch.equal(gd(x2)["logits"], predict_uncertainty([det], x2, n_pred=1)["logits"])
 
 
-@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfin=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1)])
+@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfin=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1), dict(s16_no_deep=1)])
 def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     """The level-0 data-flow variants behind vx_config: a separate normalise pass for the skip half instead of expand_1_1
     normalising the raw tensor on load (s16_skip_raw=0), no normalise-on-load at all (s16_no_prenorm), the general tile
@@ -792,7 +808,7 @@ def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     # the un-shared first layer (per-sample src / flip: the TTA path) with dropout off
     det = make_model(do_dropout=False)
     a = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
-    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfin=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0)     # the defaults
+    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfin=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0, s16_no_deep=0)     # the defaults
     b = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
     assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5
 

@@ -167,7 +167,6 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
     unsigned p_bad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;
     // per-PAIR state (recomputed at chunk 0)
-    bool cs_have = false;
     unsigned cs_bad = 0xFFFFFFFFu, cs_soff = 0;
     int cs_n = 0, cs_cg = 0;
     __amdgpu_buffer_rsrc_t cs_srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
@@ -175,7 +174,6 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       const bool have = ci < npair_wg;
       int n0 = 0, tzi = 0, tyi = 0, txi = 0, cg = 0;
       if (have) pair_of(ci, n0, tzi, tyi, txi, cg);
-      cs_have = have;
       unsigned bad = ibad_always;
       if (txi == 0) bad |= ibad_xlo;
       if (txi == ka.tiles_x - 1) bad |= ibad_xhi;
@@ -618,9 +616,6 @@ static int deep_pick(int N, int D, int H, int W, int Cout, DeepGeo* o) {
   // (8^3 x 64 channels at 320 samples: 640 large tiles fill 2.5 rounds of workgroups, 1 280 small ones 5 -- and the large tile is
   // still 2 % faster; at 16^3 the small tile costs 20 %)
   if (ok4 && ok2 && eff(g2) > 1.3 * eff(g4)) r = 2;
-  static const int force = getenv("VX_DEEP_R") ? atoi(getenv("VX_DEEP_R")) : 0;      // (tuning)
-  if (force == 4 && ok4) r = 4;
-  if (force == 2 && ok2) r = 2;
   *o = r == 4 ? g4 : g2;
   return r;
 }

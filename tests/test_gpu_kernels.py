@@ -1459,7 +1459,7 @@ def _pack_deep(cin, cout, seed):
 # four 4^3 samples per tile, non-cubic volumes, more tiles than workgroups' first round
 DEEP_CASES = [(16, 32, (2, 16, 16, 16)), (32, 32, (1, 8, 16, 32)), (32, 64, (3, 8, 8, 8)), (64, 64, (2, 8, 8, 8)),
               (64, 128, (8, 4, 4, 4)), (128, 128, (4, 4, 4, 4)), (24, 32, (1, 4, 8, 16)), (32, 32, (2, 12, 8, 8)),
-              (16, 64, (2, 8, 16, 16))]
+              (16, 64, (2, 8, 16, 16)), (32, 32, (36, 16, 16, 16)), (64, 128, (84, 4, 4, 4))]      # (the last two: 288 / 336 tiles on 256 workgroups)
 
 
 @pytest.mark.parametrize("cin,cout,shape", DEEP_CASES)
@@ -1510,7 +1510,7 @@ def test_conv3d_deep_plain_and_activation_epilogues_match_oracle(cin, cout, shap
     np.testing.assert_allclose(st6.double().sum(1).cpu().numpy(), ssum.numpy(), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 16, 16, 16)), (64, 64, (3, 8, 8, 8)), (16, 32, (1, 8, 8, 16))])
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 16, 16, 16)), (64, 64, (3, 8, 8, 8)), (16, 32, (1, 8, 8, 16)), (16, 32, (33, 16, 16, 16))])
 @pytest.mark.parametrize("pmode", [1, 0])
 def test_conv3d_deep_prologue_matches_oracle(cin, cout, shape, pmode, vxcfg):
     """The second conv of a contract block at the deep levels (contr_3_2 / contr_4_2): normalise-on-load of the raw first conv

@@ -377,6 +377,49 @@ def test_convT_matches_oracle(cin, cout, shape):
         a.out = out.data_ptr(); a.out_xblk = 0
 
 
+def test_convT_split_fp16_reports_weights_and_outputs_past_the_fp16_range(vxcfg):
+    """vx_convT_k2s2 on split-fp16 products (Cin in {64, 128}, round 5): a weight past 65504 is clamped (finite arithmetic) and
+    reported through the launch's range word as infinity; an output past 32768 reports its magnitude; in-range launches leave the
+    word alone; conv_fp32 = 1 runs the native-fp32 kernel on the same packed weights (include/values_amd.h, vx_convT_args)."""
+    lib = _lib.load()
+    n, d, h, w, cin, cout = 2, 4, 4, 4, 64, 32
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 151)).float()
+    wt = torch.from_numpy(formula_tensor((cin, cout, 2, 2, 2), 152, scale=(1.0 / cin) ** 0.5)).float().contiguous()
+    b = torch.zeros((cout,), dtype=torch.float32)
+
+    def run(wts, xin):
+        wd = wts.contiguous().to(dev())
+        wp = torch.empty(lib.vx_convT_k2s2_packed_floats(cin, cout), dtype=torch.float32, device=dev())
+        _lib.check(lib.vx_pack_convT_k2s2(_lib.ptr(wd), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "packT")
+        out = torch.empty((n, 2 * d, 2 * h, 2 * w, cout), dtype=torch.float32, device=dev())
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev())
+        xd = cl(xin).to(dev())
+        a = _lib.ConvTArgs()
+        a.in_ = xd.data_ptr(); a.in_pitch = cin; a.w_packed = wp.data_ptr(); a.bias = b.to(dev()).data_ptr()
+        bias_keep = b.to(dev()); a.bias = bias_keep.data_ptr()
+        a.out = out.data_ptr(); a.out_pitch = cout; a.out_coff = 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+        a.range_flag = flag.data_ptr()
+        _lib.check(lib.vx_convT_k2s2(C.byref(a), _lib.stream_ptr()), "convT")
+        torch.cuda.synchronize()
+        return out, flag.view(torch.float32).item(), lib.vx_last_kernel_name().decode()
+
+    out, fl, kn = run(wt, x)
+    assert kn.startswith("convT_k2s2_s16_kernel<64,") and fl == 0.0, (kn, fl)
+    ref = F.conv_transpose3d(x.double(), wt.double(), None, stride=2)
+    assert (ncdhw(out).cpu().double() - ref).abs().max().item() < 1e-5
+    big = wt.clone(); big[3, 5, 0, 1, 1] = 1.0e5                   # one weight past the fp16 range
+    _, fl, _ = run(big, x)
+    assert fl == float("inf"), fl
+    _, fl, _ = run(wt, x * 3.0e4)                                   # outputs past 32768, weights and inputs in range
+    assert 32768.0 <= fl < float("inf"), fl
+    vxcfg.set(conv_fp32=1)
+    out32, fl, kn = run(big, x)
+    assert kn.startswith("convT_k2s2_mfma_kernel<64,"), kn
+    ref = F.conv_transpose3d(x.double(), big.double(), None, stride=2)
+    assert ((ncdhw(out32).cpu().double() - ref).abs() / (1.0 + ref.abs())).max().item() < 1e-5
+
+
 @pytest.mark.parametrize("c,shape,pool", [(8, (2, 8, 8, 16), True), (16, (1, 4, 6, 10), True), (8, (1, 3, 5, 7), False),
                                           (64, (2, 2, 2, 2), True), (256, (1, 2, 4, 6), True), (4, (1, 2, 2, 2), False)])
 def test_instnorm_lrelu_drop_pool_matches_oracle(c, shape, pool):

@@ -362,6 +362,21 @@ typedef struct vx_norm_args {
                                  the first layer's activation / dropout pass feeds a split-fp16 conv un-normalised) */
 } vx_norm_args;
 int vx_norm_act_drop_pool(const vx_norm_args* a, vx_stream_t stream);
+/* Round 5: a streaming pass that takes its InstanceNorm statistics from the producing conv's PARTIALS instead of from a
+ * vx_instnorm_finalize launch in front of it: every workgroup reduces the partials of its sample itself (float64, the formula of
+ * vx_instnorm_finalize; the summation order differs, so mean / rstd agree with it to the last bit except on a rounding
+ * boundary) and mean_out / rstd_out [N][C] (nullable) receive them for later readers.  stats_partial [N][tiles][C][2] as
+ * vx_conv3d_args.stats_partial, count = voxels per sample the sums run over, C <= 512. */
+typedef struct vx_stat_src {
+  const float* stats_partial; int32_t tiles; float eps; int64_t count;
+  float* mean_out; float* rstd_out;
+} vx_stat_src;
+/* vx_norm_act_drop_pool with a->mean == a->rstd == NULL and the statistics from `st` (x_repeat 1) */
+int vx_norm_act_drop_pool_stats(const vx_norm_args* a, const vx_stat_src* st, vx_stream_t stream);
+/* vx_prenorm_split / vx_pool_finish_z (above) with the statistics from `st` (C = 8 / 16) */
+int vx_prenorm_split_stats(float* x, const vx_stat_src* st, int N, int64_t nvox, float scale, vx_stream_t stream);
+int vx_pool_finish_z_stats(const float* pool_raw, const uint32_t* pool_flags, const vx_stat_src* st, float* out, int out_pitch,
+                           int N, int Dp, int64_t plane_voxels, int drop_scale2, vx_stream_t stream);
 /* Same, but sample n of the OUTPUT reads sample n / x_repeat of x / mean / rstd: the T MC-dropout samples of a
  * volume share contr_1_1's conv output and statistics (test_3D.py:462-472 feeds the same input T times; dropout
  * is the first thing that differs), so that conv runs once per volume and this kernel fans it out. */

@@ -44,9 +44,9 @@ def test_struct_sizes_match_c(lib):
     code = r'''
 #include <stdio.h>
 #include "values_amd.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx_norm_args), sizeof(vx_convT_args),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_conv3d_args), sizeof(vx_norm_args), sizeof(vx_convT_args),
  sizeof(vx_unet3d_weights), sizeof(vx_unet3d_run), sizeof(vx_conv2d_args), sizeof(vx_affine_args), sizeof(vx_config),
- sizeof(vx_unc_outputs), sizeof(vx_fuse_args)); return 0;}
+ sizeof(vx_unc_outputs), sizeof(vx_fuse_args), sizeof(vx_stat_src)); return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "s.c")
@@ -55,7 +55,7 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_con
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])  # header is plain C
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(c) for c in (_lib.ConvArgs, _lib.NormArgs, _lib.ConvTArgs, _lib.UNet3DWeights, _lib.UNet3DRun,
-                                        _lib.Conv2dArgs, _lib.AffineArgs, _lib.Config, _lib.UncOutputs, _lib.FuseArgs)]
+                                        _lib.Conv2dArgs, _lib.AffineArgs, _lib.Config, _lib.UncOutputs, _lib.FuseArgs, _lib.StatSrc)]
     assert mine == sizes
 
 

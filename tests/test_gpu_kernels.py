@@ -1598,3 +1598,108 @@ def test_conv3d_deep_reads_the_x_blocked_concat_buffer(csrc, cout, shape, xb, vx
     assert kn.startswith("conv3d_deep_kernel<") and kn.endswith(",1,0>"), kn
     err = (ncdhw(out).cpu().double() - ref * keep * 2.0).abs().max().item()
     assert err < 6e-5, err
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: streaming passes that reduce the producing conv's statistics partials themselves (vx_stat_src)
+def _stat_src(partials, tiles, count, mean_out, rstd_out):
+    st = _lib.StatSrc()
+    st.stats_partial = partials.data_ptr(); st.tiles = tiles; st.eps = 1e-5; st.count = count
+    st.mean_out = mean_out.data_ptr(); st.rstd_out = rstd_out.data_ptr()
+    return st
+
+
+def _finalize(partials, n, tiles, c, count):
+    lib = _lib.load()
+    mean = torch.empty((n, c), dtype=torch.float32, device=dev()); rstd = torch.empty_like(mean)
+    _lib.check(lib.vx_instnorm_finalize(_lib.ptr(partials), n, tiles, c, count, 1e-5, _lib.ptr(mean), _lib.ptr(rstd), _lib.stream_ptr()), "finalize")
+    return mean, rstd
+
+
+@pytest.mark.parametrize("c,shape,tiles,pool", [(32, (3, 8, 8, 16), 16, True), (64, (2, 4, 8, 8), 2, True), (16, (2, 4, 4, 8), 5, False),
+                                                 (256, (1, 2, 4, 4), 3, True), (8, (2, 4, 8, 32), 300, True)])
+def test_norm_pass_with_its_own_statistics_equals_finalize_then_pass(c, shape, tiles, pool):
+    """vx_norm_act_drop_pool_stats (the normalise + pool passes of the deep levels, unet3D_module.py:231-237, 314-323) against
+    vx_instnorm_finalize + vx_norm_act_drop_pool on the same partials: mean / rstd to one ulp, outputs to float32 rounding."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    x = cl(torch.from_numpy(formula_tensor((n, c, d, h, w), 901, scale=2.0)).float()).to(dev())
+    count = d * h * w
+    # partials of a made-up tiling whose sums are the tensor's
+    part = torch.from_numpy(formula_tensor((n, tiles, c, 2), 902, scale=3.0)).float()
+    tot = torch.stack([x.cpu().double().sum((1, 2, 3)), (x.cpu().double() ** 2).sum((1, 2, 3))], -1)
+    part[:, 0] += (tot - part.double().sum(1)).float()
+    part = part.contiguous().to(dev())
+    mean, rstd = _finalize(part, n, tiles, c, count)
+
+    def run(stats):
+        a = _lib.NormArgs()
+        out = torch.full((n, d, h, w, c), -7.0, dtype=torch.float32, device=dev())
+        pl = torch.full((n, d // 2, h // 2, w // 2, c), -7.0, dtype=torch.float32, device=dev())
+        a.x = x.data_ptr(); a.x_pitch = c; a.out = out.data_ptr(); a.out_pitch = c
+        a.N, a.D, a.H, a.W, a.C = n, d, h, w, c
+        a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 5, 3
+        if pool:
+            a.pool_out = pl.data_ptr(); a.pool_pitch = c
+        if stats:
+            mo = torch.zeros((n, c), dtype=torch.float32, device=dev()); ro = torch.zeros_like(mo)
+            st = _stat_src(part, tiles, count, mo, ro)
+            _lib.check(lib.vx_norm_act_drop_pool_stats(C.byref(a), C.byref(st), _lib.stream_ptr()), "norm_stats")
+            torch.cuda.synchronize()
+            return out, pl, mo, ro, lib.vx_last_kernel_name().decode()
+        a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+        _lib.check(lib.vx_norm_act_drop_pool(C.byref(a), _lib.stream_ptr()), "norm")
+        torch.cuda.synchronize()
+        return out, pl, mean, rstd, lib.vx_last_kernel_name().decode()
+
+    o1, p1, m1, r1, k1 = run(True)
+    o0, p0, m0, r0, k0 = run(False)
+    assert k1.count(",") == 2 and k1.endswith(",true>") and k0.count(",") == 1, (k1, k0)      # <POOL, WIDE, FOLD> / <POOL, WIDE>
+    assert ((m1 - m0).abs() <= 1.2e-7 * (1.0 + m0.abs())).all() and ((r1 - r0).abs() <= 1.2e-7 * r0.abs()).all()
+    assert (o1 - o0).abs().max().item() <= 2e-6 * max(1.0, o0.abs().max().item())
+    if pool:
+        assert (p1 - p0).abs().max().item() <= 2e-6 * max(1.0, p0.abs().max().item())
+
+
+def test_prenorm_split_and_pool_finish_z_with_their_own_statistics():
+    """vx_prenorm_split_stats / vx_pool_finish_z_stats against vx_instnorm_finalize followed by the plain entry points."""
+    lib = _lib.load()
+    # --- the once-per-volume pre-split of the first block
+    n, nvox, tiles = 3, 4096, 37
+    x = torch.from_numpy(formula_tensor((n, nvox, 8), 911, scale=2.0)).float().contiguous()
+    part = torch.from_numpy(formula_tensor((n, tiles, 8, 2), 912, scale=3.0)).float()
+    tot = torch.stack([x.double().sum(1), (x.double() ** 2).sum(1)], -1)
+    part[:, 0] += (tot - part.double().sum(1)).float()
+    part = part.contiguous().to(dev())
+    mean, rstd = _finalize(part, n, tiles, 8, nvox)
+    a0 = x.clone().to(dev()); a1 = x.clone().to(dev())
+    _lib.check(lib.vx_prenorm_split(_lib.ptr(a0), _lib.ptr(mean), _lib.ptr(rstd), n, nvox, 2.0, _lib.stream_ptr()), "presplit")
+    mo = torch.zeros((n, 8), dtype=torch.float32, device=dev()); ro = torch.zeros_like(mo)
+    st = _stat_src(part, tiles, nvox, mo, ro)
+    _lib.check(lib.vx_prenorm_split_stats(_lib.ptr(a1), C.byref(st), n, nvox, 2.0, _lib.stream_ptr()), "presplit_stats")
+    torch.cuda.synchronize()
+    assert lib.vx_last_kernel_name().decode() == "prenorm_split_kernel<true>"
+    assert ((mo - mean).abs() <= 1.2e-7 * (1.0 + mean.abs())).all() and ((ro - rstd).abs() <= 1.2e-7 * rstd.abs()).all()
+    def unsplit(t):
+        hl = t.cpu().contiguous().view(torch.float16).view(n, nvox, 2, 2, 4).float()      # [quad][hi | lo][4]
+        return hl[..., 0, :] + hl[..., 1, :] / 2048.0
+    assert (unsplit(a1) - unsplit(a0)).abs().max().item() <= 2e-6 * max(1.0, unsplit(a0).abs().max().item())
+    # --- the z pair + statistics of the 16-channel level's pooled tensor
+    n, dp, pv, tiles = 2, 3, 20, 9
+    raw = torch.from_numpy(formula_tensor((n, 2 * dp, pv, 16), 921, scale=2.0)).float().contiguous().to(dev())
+    flags = (torch.from_numpy(formula_tensor((n, 2 * dp, pv, 4), 922)) > 0.5).to(torch.int32) * 5
+    flags = flags.contiguous().to(dev())
+    part = torch.from_numpy(formula_tensor((n, tiles, 16, 2), 923, scale=3.0)).float()
+    part[..., 1] = part[..., 1].abs() * 40 + 50.0        # (a positive variance)
+    part = part.contiguous().to(dev())
+    count = 8 * 2 * dp * pv
+    mean, rstd = _finalize(part, n, tiles, 16, count)
+    o0 = torch.empty((n, dp, pv, 16), dtype=torch.float32, device=dev()); o1 = torch.empty_like(o0)
+    _lib.check(lib.vx_pool_finish_z(_lib.ptr(raw), _lib.ptr(flags), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(o0), 16, n, dp, pv, 1, _lib.stream_ptr()), "pfz")
+    mo = torch.zeros((n, 16), dtype=torch.float32, device=dev()); ro = torch.zeros_like(mo)
+    st = _stat_src(part, tiles, count, mo, ro)
+    _lib.check(lib.vx_pool_finish_z_stats(_lib.ptr(raw), _lib.ptr(flags), C.byref(st), _lib.ptr(o1), 16, n, dp, pv, 1, _lib.stream_ptr()), "pfz_stats")
+    torch.cuda.synchronize()
+    assert lib.vx_last_kernel_name().decode() == "pool_finish_z_kernel<true>"
+    assert ((mo - mean).abs() <= 1.2e-7 * (1.0 + mean.abs())).all() and ((ro - rstd).abs() <= 1.2e-7 * rstd.abs()).all()
+    assert (o1 - o0).abs().max().item() <= 2e-6 * max(1.0, o0.abs().max().item())

@@ -535,7 +535,8 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     import bench
     names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
     assert any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names) and any(n.startswith("conv3d_zc16_kernel<8,0,3,0,0>") for n in names), names
-    assert any(n.startswith("pool_finish_z_kernel") for n in names) and len(names) <= 33
+    assert any(n.startswith("pool_finish_z_kernel<true>") for n in names) and len(names) <= 30      # (three of the eight finalize launches ride in their consumers)
+    assert sum(n.startswith("instnorm_finalize_kernel") for n in names) == 5 and sum(n.startswith("norm_act_drop_pool_kernel<true,false,true>") for n in names) == 2
     assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names), names       # expand_2_1 as two launches over its halves, upscale3 inside
     assert not any(n.startswith("convT_k2s2_mfma_kernel<32,") for n in names), names           # (no upscale3 launch)
     with _lib.config(s16_no_upfuse=1):       # ... separate upscale launches (upscale2 and upscale3)

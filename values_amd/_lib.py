@@ -48,6 +48,11 @@ class NormArgs(C.Structure):
                 ("range_flag", _p)]
 
 
+class StatSrc(C.Structure):
+    """vx_stat_src: a streaming pass reduces the producing conv's statistics partials itself (round 5)."""
+    _fields_ = [("stats_partial", _p), ("tiles", _i32), ("eps", C.c_float), ("count", _i64), ("mean_out", _p), ("rstd_out", _p)]
+
+
 class ConvTArgs(C.Structure):
     _fields_ = [("in_", _p), ("in_pitch", _i32), ("w_packed", _p), ("bias", _p),
                 ("out", _p), ("out_pitch", _i32), ("out_coff", _i32),
@@ -151,6 +156,9 @@ SIGNATURES = {
     "vx_instnorm_finalize": (_i, [_p, _i, _i, _i, _i64, C.c_float, _p, _p, _p]),
     "vx_norm_act_drop_pool": (_i, [C.POINTER(NormArgs), _p]),
     "vx_norm_act_drop_pool_bcast": (_i, [C.POINTER(NormArgs), _i, _p]),
+    "vx_norm_act_drop_pool_stats": (_i, [C.POINTER(NormArgs), C.POINTER(StatSrc), _p]),
+    "vx_prenorm_split_stats": (_i, [_p, C.POINTER(StatSrc), _i, _i64, C.c_float, _p]),
+    "vx_pool_finish_z_stats": (_i, [_p, _p, C.POINTER(StatSrc), _p, _i, _i, _i, _i64, _i, _p]),
     "vx_convT_k2s2": (_i, [C.POINTER(ConvTArgs), _p]),
     "vx_conv1x1_ncdhw": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vx_unet3d_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),

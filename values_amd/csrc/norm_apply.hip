@@ -41,6 +41,69 @@ extern "C" int vx_instnorm_finalize(const float* stats_partial, int N, int ntile
   return VX_OK;
 }
 
+// Round 5: the statistics of ONE sample reduced by the consuming streaming pass itself (vx_stat_src): every workgroup of
+// sample n sums the sample's partials (tiles x C x 2 floats, L2-resident) in float64 -- L = 256 / C threads per channel over
+// strided tiles, then one thread per channel over the L partial sums -- and keeps mean / rstd in LDS; the workgroups with
+// blockIdx.x == 0 also write them out for later readers.  Same formula as instnorm_finalize_kernel (biased variance, eps inside
+// the root); the float64 summation ORDER differs, i.e. the float results agree to the last bit except on a rounding boundary.
+// The four instnorm_finalize launches in front of these passes (first block's pre-split, vx_pool_finish_z, the two normalise +
+// pool passes of the deep levels) are gone: 33 -> 29 launches per forward.
+struct StatSrc { const float* partial; int tiles; double inv_count; float eps; float* mean_out; float* rstd_out; };
+constexpr int VX_STAT_MAXC = 512;
+__device__ __forceinline__ void vx_block_instnorm(const StatSrc& st, int n, int C, bool write, float* s_mu, float* s_rs, double* s_part) {
+  const float* p = st.partial + (size_t)n * st.tiles * C * 2;
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int cw = C - c0 < 256 ? C - c0 : 256;
+    int L = 1;
+    while (2 * L * cw <= 256) L *= 2;
+    const int c = tid % cw, sub = tid / cw;
+    double s = 0.0, q = 0.0;
+    if (sub < L) {
+      // (four tiles' loads in flight per trip: the trips are dependent L2 round trips)
+      const size_t tstride = (size_t)L * C * 2;
+      const float* e = p + ((size_t)sub * C + c0 + c) * 2;
+      int t = sub;
+      for (; t + 3 * L < st.tiles; t += 4 * L, e += 4 * tstride) {
+        const f32x2 v0 = *reinterpret_cast<const f32x2*>(e), v1 = *reinterpret_cast<const f32x2*>(e + tstride);
+        const f32x2 v2 = *reinterpret_cast<const f32x2*>(e + 2 * tstride), v3 = *reinterpret_cast<const f32x2*>(e + 3 * tstride);
+        s += (double)v0[0]; q += (double)v0[1];
+        s += (double)v1[0]; q += (double)v1[1];
+        s += (double)v2[0]; q += (double)v2[1];
+        s += (double)v3[0]; q += (double)v3[1];
+      }
+      for (; t < st.tiles; t += L, e += tstride) {
+        const f32x2 v0 = *reinterpret_cast<const f32x2*>(e);
+        s += (double)v0[0];
+        q += (double)v0[1];
+      }
+    }
+    s_part[tid] = s;
+    s_part[256 + tid] = q;
+    __syncthreads();
+    if (tid < cw) {
+      double S = 0.0, Q = 0.0;
+      for (int k = 0; k < L; ++k) { S += s_part[k * cw + tid]; Q += s_part[256 + k * cw + tid]; }
+      const double mu = S * st.inv_count;
+      double var = Q * st.inv_count - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)st.eps));
+      s_mu[c0 + tid] = m;
+      s_rs[c0 + tid] = r;
+      if (write && st.mean_out) st.mean_out[(size_t)n * C + c0 + tid] = m;
+      if (write && st.rstd_out) st.rstd_out[(size_t)n * C + c0 + tid] = r;
+    }
+    __syncthreads();
+  }
+}
+static int vx_stat_src_check(const vx_stat_src* st, int C, const char* who, StatSrc* o) {
+  if (!st || !st->stats_partial) VX_FAIL(VX_E_NULL, "%s: null statistics source", who);
+  if (st->tiles <= 0 || st->count <= 0 || C > VX_STAT_MAXC) VX_FAIL(VX_E_SHAPE, "%s: %d tiles, %lld values per channel, C = %d (<= %d)", who, st->tiles, (long long)st->count, C, VX_STAT_MAXC);
+  o->partial = st->stats_partial; o->tiles = st->tiles; o->inv_count = 1.0 / (double)st->count; o->eps = st->eps;
+  o->mean_out = st->mean_out; o->rstd_out = st->rstd_out;
+  return VX_OK;
+}
+
 // One thread = one 16-byte piece (4 channels of one voxel) of a full-resolution ROW; consecutive lanes hold
 // consecutive pieces, so every load/store instruction of a wave is one contiguous 1 KiB segment of the row.
 // POOL: the thread handles the same piece of the 4 rows (2z+dz, 2y+dy) of a 2x2 row bundle, takes their max,
@@ -63,12 +126,15 @@ __device__ __forceinline__ void vx_range_report(uint32_t* flag, float rmax) {
 __device__ __forceinline__ unsigned vx_magic_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
 // WIDE (pooling with more than 128 channels): the x-neighbour's piece would sit in another wave, so a thread takes
 // BOTH voxels of an x-pair (a row then has W/2 * C/4 work items) and no shuffle is needed.
-template <bool POOL, bool WIDE = false>
-__global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a, int x_repeat, NormDecode dc) {
+template <bool POOL, bool WIDE = false, bool FOLD = false>
+__global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a, int x_repeat, NormDecode dc, StatSrc st) {
   const int C4 = a.C / 4;
   const int PW = (WIDE ? a.W / 2 : a.W) * C4;  // work items per row
   const int n = blockIdx.y;
   const int RH = POOL ? a.H / 2 : a.H;   // rows (row bundles) per z
+  __shared__ float s_mu[FOLD ? VX_STAT_MAXC : 4], s_rs[FOLD ? VX_STAT_MAXC : 4];
+  __shared__ double s_part[FOLD ? 512 : 1];
+  if constexpr (FOLD) vx_block_instnorm(st, n / x_repeat, a.C, blockIdx.x == 0, s_mu, s_rs, s_part);
   float rmax = 0.f;   // largest |value| stored: range guard of the split-fp16 consumers when nothing normalises (a.range_flag)
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < dc.per_sample; i += gridDim.x * 256u) {
     const unsigned row = vx_magic_div(i, dc.mPW);       // i / PW
@@ -78,7 +144,10 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
     const int by = (int)(row - (unsigned)bz * (unsigned)RH);
     const int ns = n / x_repeat;
     f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = (f32x4){1.f, 1.f, 1.f, 1.f};
-    if (a.mean) {
+    if constexpr (FOLD) {
+      mu = *reinterpret_cast<const f32x4*>(s_mu + c);
+      rs = *reinterpret_cast<const f32x4*>(s_rs + c);
+    } else if (a.mean) {
       mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)ns * a.C + c);
       rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)ns * a.C + c);
     }
@@ -219,12 +288,26 @@ __global__ __launch_bounds__(256) void norm_act_drop_fanout_kernel(vx_norm_args 
   vx_range_report(a.range_flag, rmax);
 }
 
+static int norm_act_drop_pool_impl(const vx_norm_args* ap, int x_repeat, const vx_stat_src* stsrc, vx_stream_t stream);
 extern "C" int vx_norm_act_drop_pool(const vx_norm_args* ap, vx_stream_t stream) {
-  return vx_norm_act_drop_pool_bcast(ap, 1, stream);
+  return norm_act_drop_pool_impl(ap, 1, nullptr, stream);
+}
+extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat, vx_stream_t stream) {
+  return norm_act_drop_pool_impl(ap, x_repeat, nullptr, stream);
+}
+extern "C" int vx_norm_act_drop_pool_stats(const vx_norm_args* ap, const vx_stat_src* st, vx_stream_t stream) {
+  if (!st) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool_stats: null statistics source");
+  return norm_act_drop_pool_impl(ap, 1, st, stream);
 }
 
-extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat, vx_stream_t stream) {
+static int norm_act_drop_pool_impl(const vx_norm_args* ap, int x_repeat, const vx_stat_src* stsrc, vx_stream_t stream) {
   if (!ap) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null args");
+  StatSrc st = {};
+  if (stsrc) {
+    const int rc = vx_stat_src_check(stsrc, ap->C, "vx_norm_act_drop_pool_stats", &st);
+    if (rc != VX_OK) return rc;
+    if (ap->mean || ap->rstd) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool_stats: the statistics come from the source, mean / rstd must be NULL");
+  }
   if (x_repeat < 1) VX_FAIL(VX_E_SHAPE, "vx_norm_act_drop_pool: x_repeat must be >= 1");
   const vx_norm_args& a = *ap;
   if (!a.x || (!a.out && !a.pool_out)) VX_FAIL(VX_E_NULL, "vx_norm_act_drop_pool: null tensor");
@@ -278,15 +361,28 @@ extern "C" int vx_norm_act_drop_pool_bcast(const vx_norm_args* ap, int x_repeat,
       if (fx > fcap) fx = fcap;
       vx_note_kernel("norm_act_drop_fanout_kernel");
       hipLaunchKernelGGL(norm_act_drop_fanout_kernel, dim3(fx, ns), dim3(256), 0, s, a, x_repeat, dc);
+    } else if (stsrc) {
+      // (four pieces per thread: the workgroup's reduction of the partials is paid once per 1 024 pieces instead of 256)
+      bx = (bx + 3) / 4;
+      if (wide) {
+        vx_note_kernel("norm_act_drop_pool_kernel<true,true,true>");
+        hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
+      } else if (pool) {
+        vx_note_kernel("norm_act_drop_pool_kernel<true,false,true>");
+        hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, false, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
+      } else {
+        vx_note_kernel("norm_act_drop_pool_kernel<false,false,true>");
+        hipLaunchKernelGGL((norm_act_drop_pool_kernel<false, false, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
+      }
     } else if (wide) {
       vx_note_kernel("norm_act_drop_pool_kernel<true,true>");
-      hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
+      hipLaunchKernelGGL((norm_act_drop_pool_kernel<true, true>), dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
     } else if (pool) {
       vx_note_kernel("norm_act_drop_pool_kernel<true,false>");
-      hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
+      hipLaunchKernelGGL(norm_act_drop_pool_kernel<true>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
     } else {
       vx_note_kernel("norm_act_drop_pool_kernel<false,false>");
-      hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc);
+      hipLaunchKernelGGL(norm_act_drop_pool_kernel<false>, dim3(bx, a.N), dim3(256), 0, s, a, x_repeat, dc, st);
     }
   }
   VX_CHECK_LAUNCH("vx_norm_act_drop_pool");
@@ -349,10 +445,19 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
 
 // vx_pool_finish_z: the 16-channel z-column kernel leaves the (y, x) half of every window per z-plane (values_amd.h); one
 // thread = one 16-byte piece of a pooled voxel: maximum / OR over the z pair, then pool_finish_kernel's arithmetic
+template <bool FOLD>
 __global__ __launch_bounds__(256) void pool_finish_z_kernel(const float* __restrict__ raw, const uint32_t* __restrict__ flags,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ out, int out_pitch, unsigned Dp, unsigned pv_plane, float s) {
+                                                            float* __restrict__ out, int out_pitch, unsigned Dp, unsigned pv_plane, float s,
+                                                            StatSrc st) {
   const int n = blockIdx.y;
+  __shared__ float s_mu[FOLD ? 16 : 4], s_rs[FOLD ? 16 : 4];
+  __shared__ double s_part[FOLD ? 512 : 1];
+  if constexpr (FOLD) {
+    vx_block_instnorm(st, n, 16, blockIdx.x == 0, s_mu, s_rs, s_part);
+    mean = s_mu - (size_t)n * 16;       // (the loads below index [n][16])
+    rstd = s_rs - (size_t)n * 16;
+  }
   const unsigned pieces = Dp * pv_plane * 4u;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
     const unsigned vox = i >> 2, q = i & 3u;
@@ -376,9 +481,17 @@ __global__ __launch_bounds__(256) void pool_finish_z_kernel(const float* __restr
 }
 
 // vx_prenorm_split: one thread = one 16-byte piece, in place (values_amd.h)
+template <bool FOLD>
 __global__ __launch_bounds__(256) void prenorm_split_kernel(float* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, unsigned pieces, float scale) {
+                                                            const float* __restrict__ rstd, unsigned pieces, float scale, StatSrc st) {
   const int n = blockIdx.y;
+  __shared__ float s_mu[FOLD ? 8 : 4], s_rs[FOLD ? 8 : 4];
+  __shared__ double s_part[FOLD ? 512 : 1];
+  if constexpr (FOLD) {
+    vx_block_instnorm(st, n, 8, blockIdx.x == 0, s_mu, s_rs, s_part);
+    mean = s_mu - (size_t)n * 8;
+    rstd = s_rs - (size_t)n * 8;
+  }
   f32x4* xs = reinterpret_cast<f32x4*>(x) + (size_t)n * pieces;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
     const int c = (i & 1u) * 4;
@@ -409,9 +522,25 @@ extern "C" int vx_prenorm_split(float* x, const float* mean, const float* rstd, 
   const unsigned pieces = (unsigned)(nvox * 2);
   unsigned bx = (pieces + 255u) / 256u;
   if (bx > 512u) bx = 512u;
-  vx_note_kernel("prenorm_split_kernel");
-  hipLaunchKernelGGL(prenorm_split_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, pieces, scale);
+  vx_note_kernel("prenorm_split_kernel<false>");
+  hipLaunchKernelGGL(prenorm_split_kernel<false>, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, pieces, scale, StatSrc{});
   VX_CHECK_LAUNCH("vx_prenorm_split");
+  return VX_OK;
+}
+
+extern "C" int vx_prenorm_split_stats(float* x, const vx_stat_src* stsrc, int N, int64_t nvox, float scale, vx_stream_t stream) {
+  if (!x) VX_FAIL(VX_E_NULL, "vx_prenorm_split_stats: null pointer");
+  if (N <= 0 || N >= 65536 || nvox <= 0 || nvox >= (1ll << 30)) VX_FAIL(VX_E_SHAPE, "vx_prenorm_split_stats: empty / too large");
+  if (!vx_aligned16(x)) VX_FAIL(VX_E_ALIGN, "vx_prenorm_split_stats: alignment");
+  StatSrc st;
+  const int rc = vx_stat_src_check(stsrc, 8, "vx_prenorm_split_stats", &st);
+  if (rc != VX_OK) return rc;
+  const unsigned pieces = (unsigned)(nvox * 2);
+  unsigned bx = (pieces + 255u) / 256u;
+  if (bx > 128u) bx = 128u;       // (longer-lived workgroups than the plain pass: each reduces the partials once)
+  vx_note_kernel("prenorm_split_kernel<true>");
+  hipLaunchKernelGGL(prenorm_split_kernel<true>, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, pieces, scale, st);
+  VX_CHECK_LAUNCH("vx_prenorm_split_stats");
   return VX_OK;
 }
 
@@ -444,9 +573,29 @@ extern "C" int vx_pool_finish_z(const float* pool_raw, const uint32_t* pool_flag
   const unsigned pieces = (unsigned)(Dp * plane_voxels * 4);
   unsigned bx = (pieces + 255u) / 256u;
   if (bx > 64u) bx = 64u;
-  vx_note_kernel("pool_finish_z_kernel");
-  hipLaunchKernelGGL(pool_finish_z_kernel, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags, mean,
-                     rstd, out, out_pitch, (unsigned)Dp, (unsigned)plane_voxels, drop_scale2 ? 2.f : 1.f);
+  vx_note_kernel("pool_finish_z_kernel<false>");
+  hipLaunchKernelGGL(pool_finish_z_kernel<false>, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags, mean,
+                     rstd, out, out_pitch, (unsigned)Dp, (unsigned)plane_voxels, drop_scale2 ? 2.f : 1.f, StatSrc{});
   VX_CHECK_LAUNCH("vx_pool_finish_z");
+  return VX_OK;
+}
+
+extern "C" int vx_pool_finish_z_stats(const float* pool_raw, const uint32_t* pool_flags, const vx_stat_src* stsrc, float* out,
+                                      int out_pitch, int N, int Dp, int64_t plane_voxels, int drop_scale2, vx_stream_t stream) {
+  if (!pool_raw || !pool_flags || !out) VX_FAIL(VX_E_NULL, "vx_pool_finish_z_stats: null pointer");
+  if (N <= 0 || Dp <= 0 || plane_voxels <= 0 || (int64_t)Dp * plane_voxels >= (1ll << 28)) VX_FAIL(VX_E_SHAPE, "vx_pool_finish_z_stats: empty / too large");
+  if (out_pitch < 16 || out_pitch % 4 || !vx_aligned16(pool_raw) || !vx_aligned16(out))
+    VX_FAIL(VX_E_ALIGN, "vx_pool_finish_z_stats: pitch %d / alignment", out_pitch);
+  if (N >= 65536) VX_FAIL(VX_E_SHAPE, "vx_pool_finish_z_stats: N");
+  StatSrc st;
+  const int rc = vx_stat_src_check(stsrc, 16, "vx_pool_finish_z_stats", &st);
+  if (rc != VX_OK) return rc;
+  const unsigned pieces = (unsigned)(Dp * plane_voxels * 4);
+  unsigned bx = (pieces + 255u) / 256u;
+  if (bx > 16u) bx = 16u;
+  vx_note_kernel("pool_finish_z_kernel<true>");
+  hipLaunchKernelGGL(pool_finish_z_kernel<true>, dim3(bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_raw, pool_flags,
+                     (const float*)nullptr, (const float*)nullptr, out, out_pitch, (unsigned)Dp, (unsigned)plane_voxels, drop_scale2 ? 2.f : 1.f, st);
+  VX_CHECK_LAUNCH("vx_pool_finish_z_stats");
   return VX_OK;
 }

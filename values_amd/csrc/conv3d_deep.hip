@@ -9,8 +9,8 @@
 //     128 R voxels (R = 4: 512 -- 16 x 8 x 4 of a 16^3 volume, a whole 8^3 sample; R = 2: 256 -- half an 8^3 sample, FOUR 4^3
 //     samples) x 32 output channels; accumulators live across the Cin / 8 items of a tile;
 //   * waves 8..11 (STAGING) commit item j + 1 -- the 8-channel chunk of the tile's halo window, split into fp16 hi / lo, with
-//     the optional normalise-on-load prologue, AND that chunk's 28 KB of weights -- into the other LDS buffer while item j is
-//     multiplied, then issue the loads of item j + 2.  One barrier per item.
+//     the optional normalise-on-load prologue -- into the other LDS buffer while item j is multiplied, move that item's 28 KB
+//     of weights there by LDS-DMA, then issue the loads of item j + 2.  One barrier per item.
 //
 // K = 32 step: four taps x 8 channels (k-group g = tap & 3; 27 taps in 7 steps, the 28th has zero weights), B fragment = one
 // ds_read_b128 per precision at (the column's halo position + the tap's offset), A fragment = one per (row tile, precision):
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
     }
     const uint32_t seed_in = PRE == 1 ? vx_seed_of(a, a.in_drop_seed) : 0u;
 
-    f32x4 ibuf[IN_IT], wbuf[W_IT];
+    f32x4 ibuf[IN_IT];
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
     unsigned p_bad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;
     // per-PAIR state (recomputed at chunk 0)
     unsigned cs_bad = 0xFFFFFFFFu, cs_soff = 0;
-    int cs_n = 0, cs_cg = 0;
+    int cs_n = 0;
     __amdgpu_buffer_rsrc_t cs_srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0, 0x00020000);
     auto pair_state = [&](int ci) {
       const bool have = ci < npair_wg;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       if (!have) bad = 0xFFFFFFFFu;
       cs_bad = bad;
       cs_soff = (unsigned)((((tzi * TZ) * a.H + tyi * TY) * rowf + txi * TX * voxf) * 4);
-      cs_n = n0; cs_cg = cg;
+      cs_n = n0;
       cs_srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n0 * in_sample - biasf), 0, VX_NUMREC, 0x00020000);
       if constexpr (PRE == 1) p_key = vx_drop_key(seed_in, a.in_drop_layer, (uint32_t)n0);
     };
@@ -209,9 +209,31 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
         p_mean = *reinterpret_cast<const f32x4*>(a.in_mean + (size_t)cs_n * a.Cin + chunk * 8 + q * 4);
         p_rstd = *reinterpret_cast<const f32x4*>(a.in_rstd + (size_t)cs_n * a.Cin + chunk * 8 + q * 4);
       }
-      const f32x4* src = reinterpret_cast<const f32x4*>(ka.w) + (size_t)(cs_cg * NCH + chunk) * (DEEP_W_B / 16);
+    };
+    // The chunk's weights go to LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 28 consecutive KiB of global memory -> 28 consecutive KiB
+    // of LDS, no layout change, no registers, no ds_write): 7 instructions per staging wave, issued in the iteration that commits the
+    // item, landed before its closing barrier.  Against seven global loads + seven ds_write_b128 per thread (13 LDS-path cycles each):
+    // -2 .. -4 % on every instance (tools/ab_layers.py, same process).
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    const unsigned lds_w0 = (unsigned)(unsigned long long)s_w;
+    int wd_cg = 0;
+    auto dma_w = [&](const Cur& x, int buf) {
+      if (x.ci >= npair_wg) return;
+      if (x.c == 0) { int n0, tzi, tyi, txi; pair_of(x.ci, n0, tzi, tyi, txi, wd_cg); }
+      const unsigned long long base = (unsigned long long)(ka.w) + (unsigned long long)(wd_cg * NCH + x.c) * DEEP_W_B;
+      i32x4_ srd;
+      srd[0] = (int)(unsigned)(base & 0xFFFFFFFFull);
+      srd[1] = (int)(unsigned)((base >> 32) & 0xFFFFull);
+      srd[2] = DEEP_W_B;
+      srd[3] = 0x00020000;
+      const int pw_ = wave - NW;
 #pragma unroll
-      for (int it = 0; it < W_IT; ++it) wbuf[it] = src[t + it * NST];
+      for (int i = 0; i < W_IT; ++i) {
+        const unsigned kb = (unsigned)((pw_ * W_IT + i) * 1024);
+        const unsigned m0v = lds_w0 + (unsigned)(buf * DEEP_W_B) + kb;
+        const unsigned vo = kb + (unsigned)lane * 16u;
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(vo), "s"(srd) : "memory");
+      }
     };
     auto commit = [&](int buf) {
       unsigned char* img = s_img + buf * DEEP_IMG_B;
@@ -249,14 +271,13 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
           }
         }
       }
-      f32x4* wd = reinterpret_cast<f32x4*>(s_w + buf * DEEP_W_B);
-#pragma unroll
-      for (int it = 0; it < W_IT; ++it) wd[t + it * NST] = wbuf[it];
     };
 
     Cur cx = {0, 0}, cc = {0, 0}, cp = {0, 0};   // visible / to commit / to prefetch
     prefetch(cp); advance(cp);
+    dma_w(cc, 0);
     commit(0);    advance(cc);                   // S_0 -> buffer 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     prefetch(cp); advance(cp);
     int j = 0;
     while (cx.ci < npair_wg) {
@@ -264,9 +285,13 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       DP_STAMP(0);
       DP_WAIT_LOADS();
       DP_STAMP(3);
+      dma_w(cc, (j + 1) & 1);
       if (cc.ci < npair_wg && !(DP_ABL & 4)) commit((j + 1) & 1);
       DP_STAMP(4);
       if (!(DP_ABL & 8)) prefetch(cp);
+      // the DMA is older than the IN_IT image loads just issued: wait until only those are outstanding
+      if constexpr (IN_IT == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       DP_STAMP(5);
 #ifdef VX_CONV_STAMPS
       ++st_iters;

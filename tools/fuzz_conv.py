@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised shapes through vx_conv3d_k3: the default (specialised, double-buffered) instances must equal the generic
 split-fp16 kernel bit for bit (the role-split kernels of the 16-channel and the deep layers: within 2e-5 of it, another K
-schedule) and the native-fp32 kernels within 2e-5 (x sqrt(Cin / 32) beyond 32 input channels).    python tools/fuzz_conv.py [cases] [seed]"""
+schedule) and the native-fp32 kernels within 3e-5 (x sqrt(Cin / 32) beyond 32 input channels).    python tools/fuzz_conv.py [cases] [seed]"""
 import ctypes as C, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -90,7 +90,9 @@ for case in range(cases):
     serr = 0.0
     if mode == "plain_stats":   # tilings differ between the two modes: compare the totals
         serr = (got[1].double().sum((0, 1)) - f32[1].double().sum((0, 1))).abs().max().item() / max(1.0, n * d * h * w) ** 0.5
-    tol32 = 2e-5 * max(1.0, (cin / 32.0) ** 0.5)      # (the native-fp32 matrix instruction rounds after every K = 4: its error grows with K)
+    # (the native-fp32 matrix instruction rounds after every K = 4: its error grows with K -- at 32 -> 32 it is 1.0e-5 from float64
+    # where both split-fp16 kernels are 2.4e-6 (seed 42, case 378), times the dropout's 2)
+    tol32 = 3e-5 * max(1.0, (cin / 32.0) ** 0.5)
     if not ok or err > tol32 or serr > 1e-4 or torch.isnan(got[0]).any():
         bad += 1
         print(f"FAIL case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}: bit-equal={ok} err_vs_fp32={err:.2e} stats={serr:.2e}")

@@ -1502,7 +1502,8 @@ def _pack_deep(cin, cout, seed):
 # four 4^3 samples per tile, non-cubic volumes, more tiles than workgroups' first round
 DEEP_CASES = [(16, 32, (2, 16, 16, 16)), (32, 32, (1, 8, 16, 32)), (32, 64, (3, 8, 8, 8)), (64, 64, (2, 8, 8, 8)),
               (64, 128, (8, 4, 4, 4)), (128, 128, (4, 4, 4, 4)), (24, 32, (1, 4, 8, 16)), (32, 32, (2, 12, 8, 8)),
-              (16, 64, (2, 8, 16, 16)), (32, 32, (36, 16, 16, 16)), (64, 128, (84, 4, 4, 4))]      # (the last two: 288 / 336 tiles on 256 workgroups)
+              (16, 64, (2, 8, 16, 16)), (32, 32, (36, 16, 16, 16)), (64, 128, (84, 4, 4, 4)),      # (the last two: 288 / 336 tiles on 256 workgroups)
+              (64, 128, (5, 4, 4, 4)), (128, 128, (1, 4, 4, 4)), (64, 128, (7, 4, 4, 4))]          # round 6: batches that are no multiple of the four-sample tile
 
 
 @pytest.mark.parametrize("cin,cout,shape", DEEP_CASES)
@@ -1551,6 +1552,54 @@ def test_conv3d_deep_plain_and_activation_epilogues_match_oracle(cin, cout, shap
     assert (ncdhw(o6).cpu().double() - ref).abs().max().item() < tol
     assert (o6 - out).abs().max().item() < 2e-5
     np.testing.assert_allclose(st6.double().sum(1).cpu().numpy(), ssum.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,shape,n_big", [(64, 128, (4, 4, 4), 7), (128, 128, (4, 4, 4), 9), (32, 64, (8, 8, 8), 70), (32, 32, (16, 16, 16), 5)])
+def test_conv3d_deep_is_batch_independent(cin, cout, shape, n_big, vxcfg):
+    """Round-5 advice: the tile of conv3d_deep.hip is a function of the volume's shape and the channel count only -- never of the
+    batch size -- and the last four-sample tile of a 4^3 batch may hold fewer samples (masked loads and stores): a sample's output
+    and its statistics partials are the same BITS alone and among n_big - 1 batch mates (R = 2 at small batches gave other fp32 tile
+    sums, N % 4 != 0 sent the 4^3 layers to another kernel)."""
+    d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n_big, cin, d, h, w), 811, scale=1.5)).float()
+    wt, b, wp, bd = _pack_deep(cin, cout, 812)
+    xd = cl(x).to(dev())
+    stats = d * h * w >= 256
+    big, stb, knb = _deep_launch(xd, cin, cout, wp, bd, n_big, d, h, w, act=_lib.VX_ACT_LRELU)
+    assert knb.startswith("conv3d_deep_kernel<"), knb
+    for i in (0, n_big // 2, n_big - 1):
+        one, _, kn1 = _deep_launch(xd[i:i + 1].contiguous(), cin, cout, wp, bd, 1, d, h, w, act=_lib.VX_ACT_LRELU)
+        assert kn1 == knb, (kn1, knb)
+        assert torch.equal(one[0], big[i]), i
+    if stats:
+        bigs, stb, knb = _deep_launch(xd, cin, cout, wp, bd, n_big, d, h, w, stats=True)
+        one, st1, kn1 = _deep_launch(xd[n_big - 1:].contiguous(), cin, cout, wp, bd, 1, d, h, w, stats=True)
+        assert kn1 == knb and knb.startswith("conv3d_deep_kernel<"), (kn1, knb)
+        assert torch.equal(one[0], bigs[n_big - 1]) and torch.equal(st1[0], stb[n_big - 1])
+    ref = F.leaky_relu(F.conv3d(x.double(), wt.double(), b.double(), padding=1), 0.01)
+    assert (ncdhw(big).cpu().double() - ref).abs().max().item() < 4e-5
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 64, (1, 6, 8, 16)), (64, 64, (2, 6, 8, 32)), (32, 32, (1, 10, 16, 16))])
+def test_conv3d_deep_statistics_fall_back_where_its_tiles_do_not_divide_the_partials(cin, cout, shape, vxcfg):
+    """Round-5 advice: volumes with D % 4 == 2 at the deep levels (48 x 64 x 128 -> 6 x 8 x 16 at level 3): the deep kernel's small tile
+    gives 3 tiles per sample against a partials buffer of 4 entries -- the launch used to FAIL (VX_E_SHAPE); now the general tile
+    kernel takes it.  Statistics and output against the oracle either way."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    x = torch.from_numpy(formula_tensor((n, cin, d, h, w), 821, scale=1.5)).float()
+    wt, b, wp, bd = _pack_deep(cin, cout, 822)
+    xd = cl(x).to(dev())
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    out, st, kn = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, stats=True)
+    got = ncdhw(out).cpu()
+    assert (got.double() - ref).abs().max().item() < 4e-5, kn
+    ssum = st.double().sum(1).cpu()
+    np.testing.assert_allclose(ssum[..., 0].numpy(), got.double().sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ssum[..., 1].numpy(), (got.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
+    # without statistics the deep kernel still runs these shapes
+    o2, _, kn2 = _deep_launch(xd, cin, cout, wp, bd, n, d, h, w, act=_lib.VX_ACT_RELU)
+    assert (ncdhw(o2).cpu().double() - F.relu(ref)).abs().max().item() < 4e-5, kn2
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 16, 16, 16)), (64, 64, (3, 8, 8, 8)), (16, 32, (1, 8, 8, 16)), (16, 32, (33, 16, 16, 16))])
@@ -1703,3 +1752,142 @@ def test_prenorm_split_and_pool_finish_z_with_their_own_statistics():
     assert lib.vx_last_kernel_name().decode() == "pool_finish_z_kernel<true>"
     assert ((mo - mean).abs() <= 1.2e-7 * (1.0 + mean.abs())).all() and ((ro - rstd).abs() <= 1.2e-7 * rstd.abs()).all()
     assert (o1 - o0).abs().max().item() <= 2e-6 * max(1.0, o0.abs().max().item())
+
+
+def test_fuzz_conv_fixed_seed_slice():
+    """tools/fuzz_conv.py for a fixed seed, 60 cases (round-5 verdict: so that the driver's box, not only the builder's, runs it):
+    random (Cin, Cout, N, D, H, W, epilogue) through vx_conv3d_k3 -- the specialised instances against the generic split-fp16
+    kernel bit for bit, the role-split kernels of the 16-channel / deep layers against it to float32 rounding (2e-5), everything
+    against the native-fp32 kernels; batches that are no multiple of the deep kernel's four-sample tile included."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vx_fuzz_conv", os.path.join(root, "tools", "fuzz_conv.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    nzc, bad = mod.run_cases(60, 2026)
+    assert bad == 0, bad
+    assert nzc >= 8, nzc          # (the slice must reach conv3d_zc16.hip / conv3d_deep.hip)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the dropout bit generator (csrc/common.h: vx_drop_key / vx_drop_word) -- independence of the exported masks and the
+# key space (round-5 verdict, items "missing 7" / "next 3"; the reference draws torch's Bernoulli stream, unet3D_module.py:236, 242, 266)
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _np_mix32(h):
+    h = h.astype(np.uint64) & _M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7feb352d)) & _M32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846ca68b)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def _np_key(seed, layer, sample):
+    """host restatement of vx_drop_key: the two key words of a (seed, layer, sample) stream"""
+    s, l, n = (np.asarray(v, dtype=np.uint64) for v in (seed, layer, sample))
+    a = _np_mix32((s * np.uint64(0x9E3779B1) + l * np.uint64(0x85EBCA6B) + n * np.uint64(0xC2B2AE35) + np.uint64(0x27D4EB2F)) & _M32)
+    b = _np_mix32((s * np.uint64(0xC2B2AE3D) + l * np.uint64(0x27D4EB2F) + n * np.uint64(0x165667B1) + np.uint64(0x9E3779B9)) & _M32)
+    return a, b
+
+
+def _np_words(a, b, nwords, old=False):
+    """keep-words 0 .. nwords - 1 of the stream keyed (a, b); old = the one-word construction of rounds 1-5 (vx_mix32(index ^ a))"""
+    w = np.arange(nwords, dtype=np.uint64) ^ np.uint64(a)
+    if old:
+        return _np_mix32(w)
+    w ^= w >> np.uint64(16)
+    w = (w * np.uint64(0x7feb352d)) & _M32
+    w = (w + np.uint64(b)) & _M32
+    w ^= w >> np.uint64(15)
+    w = (w * np.uint64(0x846ca68b)) & _M32
+    w ^= w >> np.uint64(16)
+    return w
+
+
+def _device_words(seed, layer, n, elems):
+    """the keep-words vx_drop_hash_mask exports for samples 0 .. n - 1 of (seed, layer): (n, elems / 32) uint64"""
+    lib = _lib.load()
+    m = torch.empty((n, elems), dtype=torch.uint8, device=dev())
+    _lib.check(lib.vx_drop_hash_mask(int(seed) & 0xFFFFFFFF, layer, n, elems, _lib.ptr(m), _lib.stream_ptr()), "vx_drop_hash_mask")
+    bits = m.view(n, elems // 32, 32).to(torch.int64)
+    return (bits << torch.arange(32, device=dev())).sum(-1).cpu().numpy().astype(np.uint64)
+
+
+def test_hash_dropout_key_space_no_stream_is_a_permutation_of_another():
+    """Two streams whose first key words agree above the stream's word count were, until round 5, the SAME keep-words in XOR-permuted
+    order.  The colliding pair is constructed on the host (a second seed whose key agrees with seed 123's in the upper 16 bits, layer
+    1 = contr_1_2: 64^3 x 8 channels = 2^16 words), the old construction is shown to collide on it, and the device's streams for the
+    very same pair share (next to) no word; the host restatement of the generator is pinned to the device's words on the way."""
+    layer, elems = 1, 64 ** 3 * 8
+    nw = elems // 32
+    seeds = np.arange(1, 1 << 21, dtype=np.uint64)
+    a0, b0 = _np_key(123, layer, 0)
+    a, b = _np_key(seeds, layer, 0)
+    hit = np.nonzero(((a ^ a0) < np.uint64(nw)) & (seeds != np.uint64(123)))[0]
+    assert len(hit) >= 1
+    s1 = int(seeds[hit[0]])
+    a1, b1 = int(a[hit[0]]), int(b[hit[0]])
+    # the old one-word construction on this pair: a permuted copy
+    o0, o1 = _np_words(int(a0), 0, nw, old=True), _np_words(a1, 0, nw, old=True)
+    assert np.array_equal(np.sort(o0), np.sort(o1)) and not np.array_equal(o0, o1)
+    # the device's streams: the host restatement reproduces them, and they are unrelated
+    d0 = _device_words(123, layer, 1, elems)[0]
+    d1 = _device_words(s1, layer, 1, elems)[0]
+    assert np.array_equal(d0, _np_words(int(a0), int(b0), nw)) and np.array_equal(d1, _np_words(a1, b1, nw))
+    assert len(np.intersect1d(d0, d1)) <= 4          # 2^16 words out of 2^32: ~1 common value by chance
+    assert not np.array_equal(np.sort(d0), np.sort(d1))
+    # ... and no two of the 170 streams of one T = 10 volume (17 layers x 10 samples), nor those of the next seed, share their word sets
+    # at the full-resolution layers (layers 0, 1, 15, 16: 2^16 words each)
+    sets = {}
+    for seed in (123, 124):
+        for lay in (0, 1, 15, 16):
+            w = _device_words(seed, lay, 10, elems)
+            for t in range(10):
+                sets[(seed, lay, t)] = np.sort(w[t])
+    keys = list(sets)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            assert len(np.intersect1d(sets[keys[i]], sets[keys[j]], assume_unique=False)) <= 6, (keys[i], keys[j])
+
+
+def test_hash_dropout_masks_are_independent_across_samples_layers_seeds_channels_and_neighbours():
+    """The exported masks of a 64^3, T = 10 forward under seeds s and s + 1 (what bench.py feeds: consecutive seeds): keep rate per
+    (layer, channel) and the correlations between sample pairs, layer pairs of one shape, consecutive seeds, channel pairs of a voxel
+    and lag-1 neighbours along x / y / z, each within 4.5 sigma of a fair coin's (sigma = 1 / sqrt(N))."""
+    from tests.test_gpu_unet3d import make_model
+    model = make_model(do_dropout=True)
+    T, S, seed = 10, 64, 123
+    m0 = model.hash_dropout_masks(seed, T, S, S, S)
+    m1 = model.hash_dropout_masks(seed + 1, T, S, S, S)
+    sg = lambda m: m.float() * 2.0 - 1.0           # +-1
+    worst = 0.0
+
+    def chk(val, n, what):
+        nonlocal worst
+        z = abs(float(val)) * n ** 0.5
+        worst = max(worst, z)
+        assert z < 4.5, (what, float(val), n, z)
+
+    for li, m in enumerate(m0):
+        n_c = m.shape[0] * m.shape[2] * m.shape[3] * m.shape[4]
+        rate = sg(m).mean((0, 2, 3, 4))
+        assert (rate.abs() * n_c ** 0.5).max().item() < 4.5, (li, "keep rate per channel")
+        s = sg(m)
+        n_all = s[0].numel()
+        for t in range(T):          # sample pairs
+            for u in range(t + 1, T):
+                chk((s[t] * s[u]).mean(), n_all, (li, "samples", t, u))
+        chk((s * sg(m1[li])).mean(), s.numel(), (li, "consecutive seeds"))
+        chk((s[:, :-1] * s[:, 1:]).mean(), s[:, 1:].numel(), (li, "neighbouring channels"))
+        chk((s[:, 0] * s[:, s.shape[1] // 2]).mean(), s[:, 0].numel(), (li, "channels 0 / C/2"))
+        chk((s[..., :-1] * s[..., 1:]).mean(), s[..., 1:].numel(), (li, "lag 1 in x"))
+        chk((s[..., :-1, :] * s[..., 1:, :]).mean(), s[..., 1:, :].numel(), (li, "lag 1 in y"))
+        chk((s[:, :, :-1] * s[:, :, 1:]).mean(), s[:, :, 1:].numel(), (li, "lag 1 in z"))
+    for li in range(len(m0)):       # layer pairs of one shape
+        for lj in range(li + 1, len(m0)):
+            if m0[li].shape == m0[lj].shape:
+                chk((sg(m0[li]) * sg(m0[lj])).mean(), m0[li].numel(), ("layers", li, lj))
+    print(f"hash dropout: worst |z| over all checks = {worst:.2f}")

@@ -223,6 +223,6 @@ def test_config_C5_one_patch_of_128_vs_oracle_with_exported_masks():
     x = torch.from_numpy(imgn[c[0][0]:c[0][1], c[1][0]:c[1][1], c[2][0]:c[2][1]].copy())[None, None]
     _, ref = _oracle_maps(formula_sd_torch(), x, [[m[t:t + 1] for m in masks] for t in range(T)])
     sl = (slice(*c[0]), slice(*c[1]), slice(*c[2]))
+    from tests.test_gpu_unet3d import MAP_TOL, REG_MAP_TOL, assert_close
     for k in KEYS:
-        err = np.abs(out[k][sl].cpu().numpy() - ref[k]).max()
-        assert err < 1e-4, (k, err)
+        assert_close(np.abs(out[k][sl].cpu().numpy() - ref[k]).max(), MAP_TOL, REG_MAP_TOL, k)

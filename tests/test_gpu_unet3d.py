@@ -19,6 +19,18 @@ KEYS = ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty")
 MAP_TOL = 1e-4
 LOGIT_TOL = 1e-4
 TIE = 1e-5
+# Regression alarms beside the 1e-4 contract (round-5 verdict, "tighten the alarms"): the path measures 3e-6 on logits and 3e-7 on the
+# maps against the float64 oracle.  DESIGN section 4 records a gfx950 hazard (v_fma_mix* feeding a matrix instruction without wait
+# states) that produced 1e-4-sized, run-to-run different errors -- a contract-sized assert would have let it through.  These bounds sit
+# at ~5x the measured deviation of the split-fp16 path and are asserted wherever the network runs on its DEFAULT kernels.
+REG_LOGIT_TOL = 2e-5
+REG_MAP_TOL = 3e-6
+
+
+def assert_close(err, contract, regression, what):
+    """the north star's tolerance AND the regression bound (the message says which one broke)"""
+    assert err < contract, (what, "contract", err)
+    assert err < regression, (what, "regression bound: the path measured ~5x below this in round 5", err)
 
 
 def make_model(seed_tag=0, do_dropout=True, double=False, **kw):
@@ -58,11 +70,10 @@ def test_golden_mc_dropout_with_reference_masks(size):
     x = torch.from_numpy(g["input"]).double().cuda()
     out = predict_uncertainty([model], x, n_pred=T, dropout_masks=[stacked_masks(g, T)], want_sample_argmax=True)
     logits = out["logits"][0].cpu().numpy()
-    assert np.abs(logits - g["logits"]).max() < LOGIT_TOL
+    assert_close(np.abs(logits - g["logits"]).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits")
     for k in KEYS:
-        err = np.abs(out[k][0].cpu().numpy() - g[k]).max()
-        assert err < MAP_TOL, (k, err)
-    assert np.abs(out["mean_softmax"][0].cpu().numpy() - g["mean_softmax"]).max() < MAP_TOL
+        assert_close(np.abs(out[k][0].cpu().numpy() - g[k]).max(), MAP_TOL, REG_MAP_TOL, k)
+    assert_close(np.abs(out["mean_softmax"][0].cpu().numpy() - g["mean_softmax"]).max(), MAP_TOL, REG_MAP_TOL, "mean_softmax")
     clear = g["mean_margin"] > TIE
     assert (out["pred_seg_mean"][0].cpu().numpy() == g["mean_seg"])[clear].all()
     assert clear.mean() > 0.999
@@ -80,7 +91,7 @@ def test_golden_no_dropout_forward(size):
     with torch.no_grad():
         y = model(x)
     assert y.shape == (1, 2, size, size, size) and y.dtype == torch.float32
-    assert np.abs(y[0].cpu().numpy() - g["logits_nodrop"]).max() < LOGIT_TOL
+    assert_close(np.abs(y[0].cpu().numpy() - g["logits_nodrop"]).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits_nodrop")
     # eval() turns MC-dropout off like nn.Dropout does
     md = make_model(do_dropout=True).eval()
     with torch.no_grad():
@@ -188,6 +199,30 @@ def test_non_cubic_volume_on_the_level1_z_column_kernel_vs_oracle():
         y = det(x.float().cuda())
         ref0 = unet3d_forward(sd, x, masks=None).numpy()
     assert np.abs(y.cpu().numpy() - ref0).max() < LOGIT_TOL
+
+
+def test_non_cubic_volume_with_six_planes_at_level_3_vs_oracle():
+    """(48, 64, 128) -> 24 x 32 x 64 -> 12 x 16 x 32 -> 6 x 8 x 16 -> 3 x 4 x 8: D % 4 == 2 at the level of contr_4_1 / contr_4_2, where the
+    deep-layer kernel's tiles do not divide the statistics buffer (round-5 advice: the whole forward failed with VX_E_SHAPE); two
+    volumes, dropout off and MC-dropout through the exported hash masks."""
+    from oracle.unet3d_oracle import unet3d_forward
+    from values_amd import predict_uncertainty
+    S = (48, 64, 128)
+    sd = formula_sd_torch(seed_tag=6)
+    det = make_model(seed_tag=6, do_dropout=False)
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1) + S, tag=95), formula_volume((1, 1) + S, tag=96)], 0))
+    with torch.no_grad():
+        y = det(x.float().cuda())
+        ref0 = unet3d_forward(sd, x, masks=None).numpy()
+    assert_close(np.abs(y.cpu().numpy() - ref0).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits")
+    T, seed = 2, 31
+    model = make_model(seed_tag=6, do_dropout=True)
+    out = predict_uncertainty([model], x[:1].float().cuda(), n_pred=T, seeds=[seed])
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, T, *S)]
+    logits, ref = _oracle_maps(sd, x[:1], [[m[t:t + 1] for m in masks] for t in range(T)])
+    assert_close(np.abs(out["logits"][0].cpu().numpy() - logits).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits (MC)")
+    for k in KEYS:
+        assert_close(np.abs(out[k][0].cpu().numpy() - ref[k]).max(), MAP_TOL, REG_MAP_TOL, k)
 
 
 @pytest.mark.parametrize("f,size,ncls", [(16, 32, 2), (32, 16, 3)])
@@ -299,6 +334,13 @@ def test_volume_chunks_on_two_streams_equal_one_stream():
     s1 = predict_uncertainty([det], x[:3], n_pred=2, n_streams=2)
     s0 = predict_uncertainty([det], x[:3], n_pred=2, n_streams=1)
     assert torch.equal(s0["pred_entropy"], s1["pred_entropy"])
+    # the same at 64^3, where the role-split kernels of every level run (16^3 only reaches the general tile kernel): chunks of
+    # 2 volumes x 3 passes against 4 x 3 in one batch
+    x64 = torch.from_numpy(np.concatenate([formula_volume((1, 1, 64, 64, 64), tag=140 + i) for i in range(4)], 0)).float().cuda()
+    a = predict_uncertainty([det], x64, n_pred=3, n_streams=1)
+    b = predict_uncertainty([det], x64, n_pred=3, n_streams=2)
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_mode_switch_repacks_the_weights(vxcfg):
@@ -521,10 +563,9 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     sd = formula_sd_torch()
     logits, ref = _oracle_maps(sd, x, [[m[t:t + 1] for m in masks] for t in range(T)])
     got = out["logits"][0].cpu().numpy()
-    assert np.abs(got - logits).max() < LOGIT_TOL, np.abs(got - logits).max()
+    assert_close(np.abs(got - logits).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits")
     for k in KEYS:
-        err = np.abs(out[k][0].cpu().numpy() - ref[k]).max()
-        assert err < MAP_TOL, (k, err)
+        assert_close(np.abs(out[k][0].cpu().numpy() - ref[k]).max(), MAP_TOL, REG_MAP_TOL, k)
     # replaying the exported masks through VX_DROP_MASK (run-time epilogue instances) gives the same logits
     rep = predict_uncertainty([model], x.float().cuda(), n_pred=T, dropout_masks=[masks])
     assert (rep["logits"] - out["logits"]).abs().max().item() < 2e-5
@@ -578,7 +619,47 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     with torch.no_grad():
         y = det(x.float().cuda())
     l0, _ = _oracle_maps(sd, x, [None])
-    assert np.abs(y[0].cpu().numpy() - l0[0]).max() < LOGIT_TOL
+    assert_close(np.abs(y[0].cpu().numpy() - l0[0]).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits, dropout off")
+
+
+def test_bench_geometry_two_volumes_T10_at_64_vs_oracle():
+    """BASELINE config C2 at the BENCH's geometry against the oracle: V = 2 volumes x T = 10 MC-dropout samples at 64^3 on the default
+    (timed) kernels, the hash generator's masks exported and handed to the float64 oracle (20 CPU passes).  The only place where
+    contr_1_2's (volume, column, sample) column order (round 5: it differs from the plain order only for V > 1, T > 2) and
+    in_repeat = 10 meet the oracle; the 1-volume T = 2 test above cannot see either."""
+    from values_amd import predict_uncertainty
+    import bench
+    S, T, V, seed = 64, 10, 2, 777
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(np.concatenate([formula_volume((1, 1, S, S, S), tag=171 + v) for v in range(V)], 0))
+    out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert any(n.startswith("conv3d_xp8w_kernel<1,4,2,") for n in names), names          # contr_1_2 on the pre-split shared tensor
+    assert any(n.startswith("conv3d_xp8w_kernel<2,1,1,2,8") for n in names), names        # upscale2 composed into expand_1_1
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, V * T, S, S, S)]             # sample n = volume * T + pass
+    sd = formula_sd_torch()
+    for v in range(V):
+        logits, ref = _oracle_maps(sd, x[v:v + 1], [[m[v * T + t:v * T + t + 1] for m in masks] for t in range(T)])
+        assert_close(np.abs(out["logits"][v].cpu().numpy() - logits).max(), LOGIT_TOL, REG_LOGIT_TOL, ("logits", v))
+        for k in KEYS:
+            assert_close(np.abs(out[k][v].cpu().numpy() - ref[k]).max(), MAP_TOL, REG_MAP_TOL, (k, v))
+
+
+def test_a_samples_bits_do_not_depend_on_the_batch_size_at_64():
+    """InstanceNorm is per sample and every kernel's tile geometry is a function of the volume's shape only: a 64^3 sample computes
+    the same BITS alone, among 4 and among 65 (round-5 advice: conv3d_deep.hip picked its tile from how the batch filled the
+    workgroups and ran the 4^3 layers on another kernel when N % 4 != 0 -- 65 leaves one sample in the last four-sample tile)."""
+    model = make_model(do_dropout=False)
+    g = torch.Generator(device="cpu").manual_seed(65)
+    x = torch.randn((65, 1, 64, 64, 64), generator=g).cuda()
+    with torch.no_grad():
+        y65 = model(x)
+        y4 = model(x[:4])
+        y1 = model(x[:1])
+        ylast = model(x[64:65])
+        y3 = model(x[61:64])
+    assert torch.equal(y65[:4], y4) and torch.equal(y4[:1], y1)
+    assert torch.equal(y65[64:65], ylast) and torch.equal(y65[61:64], y3)
 
 
 def test_config_C3_full_size_five_members_64_vs_oracle():
@@ -596,11 +677,10 @@ def test_config_C3_full_size_five_members_64_vs_oracle():
     from oracle.unet3d_oracle import unet3d_forward
     with torch.no_grad():
         lg = np.stack([unet3d_forward(formula_sd_torch(seed_tag=s), x[:1])[0].numpy() for s in range(M)])
-    assert np.abs(out["logits"][0].cpu().numpy() - lg).max() < LOGIT_TOL
+    assert_close(np.abs(out["logits"][0].cpu().numpy() - lg).max(), LOGIT_TOL, REG_LOGIT_TOL, "logits")
     ref = uo.calculate_uncertainty(uo.softmax(lg, axis=1))
     for k in KEYS:
-        err = np.abs(out[k][0].cpu().numpy() - ref[k]).max()
-        assert err < MAP_TOL, (k, err)
+        assert_close(np.abs(out[k][0].cpu().numpy() - ref[k]).max(), MAP_TOL, REG_MAP_TOL, k)
     sh = ensemble_uncertainty_sharded(models, x.float().cuda(), world=1, rank=0, n_pred=1)
     for k in KEYS + ("mean_softmax",):
         assert (sh[k] - out[k]).abs().max().item() < 2e-6, k

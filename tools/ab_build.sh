@@ -7,6 +7,6 @@ REV="${1:-HEAD}"
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OBJ=/tmp/vx_ab_obj
 rm -rf $OBJ && mkdir -p $OBJ
-git -C "$ROOT" archive "$REV" values_amd/csrc include | tar -x -C $OBJ
+git -C "$ROOT" archive "$REV" values_amd/csrc include tools/rsrc_table.py | tar -x -C $OBJ
 make -C $OBJ/values_amd/csrc -j8 OUT=$ROOT/values_amd/libvalues_amd_base.so > /dev/null
 ls -la $ROOT/values_amd/libvalues_amd_base.so

@@ -10,91 +10,100 @@ from values_amd import _lib
 
 lib = _lib.load()
 dev = torch.device("cuda", 0)
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0
-nzc = 0
-for case in range(cases):
-    cin, cout = rng.choice([(8, 8), (16, 8), (8, 8), (16, 8), (16, 16), (8, 16), (32, 16), (32, 32), (24, 8), (16, 32), (64, 32), (32, 64),
-                            (64, 64), (48, 96)])
-    big = rng.random() < 0.6
-    d = rng.randint(1, 9)
-    h = rng.randint(32, 70) if big else rng.randint(1, 31)
-    w = rng.randint(1, 70)
-    if cout == 16 and cin in (8, 16) and rng.random() < 0.6:
-        # shapes the role-split z-column kernel of round 5 takes (conv3d_zc16.hip): W % 32 == 0, H % 8 == 0, D even >= 4
-        d, h, w = 2 * rng.randint(2, 6), 8 * rng.randint(1, 5), 32 * rng.randint(1, 2)
-    if cout % 32 == 0 and rng.random() < 0.7:
-        # shapes the role-split kernel of the deep layers takes (conv3d_deep.hip): power-of-two tiles of 512 / 256 voxels
-        w = rng.choice([4, 8, 16, 32])
-        h = rng.choice([4, 8, 16, 24, 32])
-        d = rng.choice([2, 4, 8, 12, 16])
-    n = rng.randint(1, 40 if rng.random() < 0.2 else 4)
-    if cout % 32 == 0 and d * h * w <= 64 and rng.random() < 0.7:
-        n = 4 * rng.randint(1, 6)            # several whole samples per tile
-    mode = rng.choice(["plain_stats", "lrelu_hash", "head", "relu"])
-    if mode == "head" and (cout != 8 or cin not in (8, 16)):
-        mode = "lrelu_hash"
-    g = torch.Generator().manual_seed(case)
-    x = torch.randn((n, d, h, w, cin), generator=g).to(dev)
-    wt = (torch.randn((cout, cin, 3, 3, 3), generator=g) * (1.0 / (27 * cin)) ** 0.5).to(dev)
-    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
-    hw = (torch.randn((2, 8), generator=g) * 0.3).contiguous().to(dev)
-    hb = torch.randn((2,), generator=g).to(dev)
-    nt = lib.vx_conv3d_k3_tiles(d, h, w)
 
-    def run(env):
-        with _lib.config(**{"s16_no_xp8": 0, "s16_generic": 0, "conv_fp32": 0, **env}):
-            wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
-            _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
-            out = torch.full((n, d, h, w, cout), -3.0, device=dev)
-            st = torch.zeros((n, nt, cout, 2), device=dev)
-            head = torch.full((n, 2, d, h, w), -5.0, device=dev)
-            a = _lib.ConvArgs()
-            a.w_family = lib.vx_conv3d_k3_family(cin, cout)
-            a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
-            a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
-            a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
-            if mode == "plain_stats":
-                a.stats_partial = st.data_ptr()
-            elif mode == "relu":
-                a.act = _lib.VX_ACT_RELU
-            else:
-                a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 9, 3
-            if mode == "head":
-                a.out = None
-                a.head_out, a.head_w, a.head_b, a.head_C = head.data_ptr(), hw.data_ptr(), hb.data_ptr(), 2
-            _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
-            torch.cuda.synchronize()
-            run.kernel = lib.vx_last_kernel_name().decode()
-            return out, st, head
 
-    if os.environ.get("FUZZ_VERBOSE"):
-        print(f"case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}", flush=True)
-    got = run({})
-    zc16 = run.kernel.startswith("conv3d_zc16") or run.kernel.startswith("conv3d_deep")
-    nzc = nzc + 1 if zc16 else nzc
-    if os.environ.get("FUZZ_VERBOSE"):
-        print("  default ok", run.kernel, flush=True)
-    gen = run({"s16_no_xp8": 1, "s16_generic": 1, "s16_no_zc16": 1, "s16_no_deep": 1})     # the tile kernel's generic instance (round 4: s16_no_db / s16_no_epi became ONE field)
-    if os.environ.get("FUZZ_VERBOSE"):
-        print("  generic ok", flush=True)
-    f32 = run({"conv_fp32": 1})
-    if zc16:    # another K schedule and another statistics tiling than the tile kernel: the same function to float32 rounding
-        ok = (got[0] - gen[0]).abs().max().item() < 2e-5 and \
-            (got[1].double().sum(1) - gen[1].double().sum(1)).abs().max().item() < 1e-4 * max(1.0, d * h * w) ** 0.5
-    else:
-        ok = all(torch.equal(p, q) for p, q in zip(got, gen))
-    tile_counts_differ = False
-    err = max((got[0] - f32[0]).abs().max().item(), (got[2] - f32[2]).abs().max().item())
-    serr = 0.0
-    if mode == "plain_stats":   # tilings differ between the two modes: compare the totals
-        serr = (got[1].double().sum((0, 1)) - f32[1].double().sum((0, 1))).abs().max().item() / max(1.0, n * d * h * w) ** 0.5
-    # (the native-fp32 matrix instruction rounds after every K = 4: its error grows with K -- at 32 -> 32 it is 1.0e-5 from float64
-    # where both split-fp16 kernels are 2.4e-6 (seed 42, case 378), times the dropout's 2)
-    tol32 = 3e-5 * max(1.0, (cin / 32.0) ** 0.5)
-    if not ok or err > tol32 or serr > 1e-4 or torch.isnan(got[0]).any():
-        bad += 1
-        print(f"FAIL case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}: bit-equal={ok} err_vs_fp32={err:.2e} stats={serr:.2e}")
-print(f"{cases} cases ({nzc} on the role-split kernels of the 16-channel / deep layers), {bad} failures")
-sys.exit(1 if bad else 0)
+def run_cases(cases, seed, verbose=False):
+    """-> (cases on the role-split kernels of the 16-channel / deep layers, failures); tests/test_gpu_kernels.py runs a fixed-seed slice"""
+    rng = random.Random(seed)
+    bad = 0
+    nzc = 0
+    for case in range(cases):
+        cin, cout = rng.choice([(8, 8), (16, 8), (8, 8), (16, 8), (16, 16), (8, 16), (32, 16), (32, 32), (24, 8), (16, 32), (64, 32), (32, 64),
+                                (64, 64), (48, 96)])
+        big = rng.random() < 0.6
+        d = rng.randint(1, 9)
+        h = rng.randint(32, 70) if big else rng.randint(1, 31)
+        w = rng.randint(1, 70)
+        if cout == 16 and cin in (8, 16) and rng.random() < 0.6:
+            # shapes the role-split z-column kernel of round 5 takes (conv3d_zc16.hip): W % 32 == 0, H % 8 == 0, D even >= 4
+            d, h, w = 2 * rng.randint(2, 6), 8 * rng.randint(1, 5), 32 * rng.randint(1, 2)
+        if cout % 32 == 0 and rng.random() < 0.7:
+            # shapes the role-split kernel of the deep layers takes (conv3d_deep.hip): power-of-two tiles of 512 / 256 voxels
+            w = rng.choice([4, 8, 16, 32])
+            h = rng.choice([4, 8, 16, 24, 32])
+            d = rng.choice([2, 4, 8, 12, 16])
+        n = rng.randint(1, 40 if rng.random() < 0.2 else 4)
+        if cout % 32 == 0 and d * h * w <= 64 and rng.random() < 0.7:
+            n = rng.randint(1, 24)               # several whole samples per tile; the last tile may hold fewer (round 6)
+        mode = rng.choice(["plain_stats", "lrelu_hash", "head", "relu"])
+        if mode == "head" and (cout != 8 or cin not in (8, 16)):
+            mode = "lrelu_hash"
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn((n, d, h, w, cin), generator=g).to(dev)
+        wt = (torch.randn((cout, cin, 3, 3, 3), generator=g) * (1.0 / (27 * cin)) ** 0.5).to(dev)
+        b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+        hw = (torch.randn((2, 8), generator=g) * 0.3).contiguous().to(dev)
+        hb = torch.randn((2,), generator=g).to(dev)
+        nt = lib.vx_conv3d_k3_tiles(d, h, w)
+
+        def run(env):
+            with _lib.config(**{"s16_no_xp8": 0, "s16_generic": 0, "conv_fp32": 0, **env}):
+                wp = torch.empty(lib.vx_conv3d_k3_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+                _lib.check(lib.vx_pack_conv3d_k3(_lib.ptr(wt), _lib.ptr(wp), cin, cout, _lib.stream_ptr()), "pack")
+                out = torch.full((n, d, h, w, cout), -3.0, device=dev)
+                st = torch.zeros((n, nt, cout, 2), device=dev)
+                head = torch.full((n, 2, d, h, w), -5.0, device=dev)
+                a = _lib.ConvArgs()
+                a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+                a.in_ = x.data_ptr(); a.w_packed = wp.data_ptr(); a.bias = b.data_ptr(); a.out = out.data_ptr()
+                a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+                a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+                if mode == "plain_stats":
+                    a.stats_partial = st.data_ptr()
+                elif mode == "relu":
+                    a.act = _lib.VX_ACT_RELU
+                else:
+                    a.act, a.drop_mode, a.drop_seed, a.drop_layer = _lib.VX_ACT_LRELU, _lib.VX_DROP_HASH, 9, 3
+                if mode == "head":
+                    a.out = None
+                    a.head_out, a.head_w, a.head_b, a.head_C = head.data_ptr(), hw.data_ptr(), hb.data_ptr(), 2
+                _lib.check(lib.vx_conv3d_k3(C.byref(a), _lib.stream_ptr()), "conv")
+                torch.cuda.synchronize()
+                run.kernel = lib.vx_last_kernel_name().decode()
+                return out, st, head
+
+        if verbose:
+            print(f"case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}", flush=True)
+        got = run({})
+        zc16 = run.kernel.startswith("conv3d_zc16") or run.kernel.startswith("conv3d_deep")
+        nzc = nzc + 1 if zc16 else nzc
+        if verbose:
+            print("  default ok", run.kernel, flush=True)
+        gen = run({"s16_no_xp8": 1, "s16_generic": 1, "s16_no_zc16": 1, "s16_no_deep": 1})     # the tile kernel's generic instance (round 4: s16_no_db / s16_no_epi became ONE field)
+        if verbose:
+            print("  generic ok", flush=True)
+        f32 = run({"conv_fp32": 1})
+        if zc16:    # another K schedule and another statistics tiling than the tile kernel: the same function to float32 rounding
+            ok = (got[0] - gen[0]).abs().max().item() < 2e-5 and \
+                (got[1].double().sum(1) - gen[1].double().sum(1)).abs().max().item() < 1e-4 * max(1.0, d * h * w) ** 0.5
+        else:
+            ok = all(torch.equal(p, q) for p, q in zip(got, gen))
+        tile_counts_differ = False
+        err = max((got[0] - f32[0]).abs().max().item(), (got[2] - f32[2]).abs().max().item())
+        serr = 0.0
+        if mode == "plain_stats":   # tilings differ between the two modes: compare the totals
+            serr = (got[1].double().sum((0, 1)) - f32[1].double().sum((0, 1))).abs().max().item() / max(1.0, n * d * h * w) ** 0.5
+        # (the native-fp32 matrix instruction rounds after every K = 4: its error grows with K -- at 32 -> 32 it is 1.0e-5 from float64
+        # where both split-fp16 kernels are 2.4e-6 (seed 42, case 378), times the dropout's 2)
+        tol32 = 3e-5 * max(1.0, (cin / 32.0) ** 0.5)
+        if not ok or err > tol32 or serr > 1e-4 or torch.isnan(got[0]).any():
+            bad += 1
+            print(f"FAIL case {case}: {cin}->{cout} n={n} {d}x{h}x{w} {mode}: bit-equal={ok} err_vs_fp32={err:.2e} stats={serr:.2e}")
+    return nzc, bad
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    nzc, bad = run_cases(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1, bool(os.environ.get("FUZZ_VERBOSE")))
+    print(f"{cases} cases ({nzc} on the role-split kernels of the 16-channel / deep layers), {bad} failures")
+    sys.exit(1 if bad else 0)

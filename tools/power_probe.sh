@@ -10,4 +10,4 @@ for i in 1 2 3 4 5 6; do
   sleep 0.7
 done
 wait $pid
-echo "== $label"; grep TFLOP /tmp/probe_$label.out | cut -c1-90
+echo "== $label"; grep -E "TFLOP|instr/s" /tmp/probe_$label.out | cut -c1-260

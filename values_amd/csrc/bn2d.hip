@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void affine_gather_kernel(vx_affine_args a, un
     const int c = ((int)p - ox * C4) * 4;
     const int oy = (int)blockIdx.y;
     const int n = (int)blockIdx.z;
-    const uint32_t dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
+    const vx_dkey dkey = vx_drop_key(a.drop_seed, a.drop_layer, (uint32_t)n);
     auto fetch = [&](int y, int x) {
       const size_t pix = ((size_t)n * a.H + y) * a.W + x;
       f32x4 v = *reinterpret_cast<const f32x4*>(a.x + pix * a.x_pitch + c);

@@ -47,8 +47,28 @@ __device__ __forceinline__ uint32_t vx_mix32(uint32_t h) {
   h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ uint32_t vx_drop_key(uint32_t seed, uint32_t layer, uint32_t sample) {
-  return vx_mix32(seed * 0x9E3779B1u + layer * 0x85EBCA6Bu + sample * 0xC2B2AE35u + 0x27D4EB2Fu);
+// Round 6: the key of a (seed, layer, sample) stream is TWO words.  Until round 5 a keep-word was vx_mix32(word index ^ key) with one
+// 32-bit key: two streams whose keys agreed in the bits above the stream's word count (2^16 words at 64^3 x 8 channels) were the same
+// words in XOR-permuted order (probability 2^-16 per pair of streams, ~0.2 such pairs among the 170 streams of one T = 10 volume).  The
+// second word enters by ADDITION between the two multiply-xorshift rounds, so streams that meet after the first round part again in
+// the second: a permuted copy now needs both words to agree (2^-48 per pair).  One v_add_u32 per hash round (= per 32 elements).
+struct vx_dkey { uint32_t a, b; };
+__device__ __forceinline__ vx_dkey vx_drop_key(uint32_t seed, uint32_t layer, uint32_t sample) {
+  vx_dkey k;
+  k.a = vx_mix32(seed * 0x9E3779B1u + layer * 0x85EBCA6Bu + sample * 0xC2B2AE35u + 0x27D4EB2Fu);
+  k.b = vx_mix32(seed * 0xC2B2AE3Du + layer * 0x27D4EB2Fu + sample * 0x165667B1u + 0x9E3779B9u);
+  return k;
+}
+// keep-word (32 consecutive elements) number widx of the stream
+__device__ __forceinline__ uint32_t vx_drop_word(vx_dkey k, uint32_t widx) {
+  uint32_t h = widx ^ k.a;
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h += k.b;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
 }
 // seed of a launch: the by-value seed plus an optional DEVICE word -- a captured hipGraph replays with the kernel
 // arguments it was captured with, so a caller that wants fresh dropout bits per replay updates that word instead
@@ -57,10 +77,10 @@ __device__ __forceinline__ uint32_t vx_seed_of(const A& a, uint32_t by_value) {
   return by_value + (a.seed_dev ? *a.seed_dev : 0u);
 }
 // keep-bits for elements [e, e+4) of sample-local linear index e (e % 4 == 0)
-__device__ __forceinline__ uint32_t vx_drop_bits4(uint32_t key, uint32_t e) {
-  // (the word index enters by XOR: the key is already a full avalanche of (seed, layer, sample), and vx_mix32's two
+__device__ __forceinline__ uint32_t vx_drop_bits4(vx_dkey key, uint32_t e) {
+  // (the word index enters by XOR: key.a is already a full avalanche of (seed, layer, sample), and the two
   // multiply-xorshift rounds spread consecutive indices on their own -- one quarter-rate integer multiply less per piece)
-  uint32_t w = vx_mix32((e >> 5) ^ key);
+  const uint32_t w = vx_drop_word(key, e >> 5);
   return (w >> (e & 31u)) & 0xFu;
 }
 

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(TXV * TY * TZ, (TXV * TY * TZ) / 128) void conv3d_k
       }
       if (a.drop_mode == VX_DROP_HASH) {
         // elements e .. e + 7 share one 32-element hash word (e % 8 == 0)
-        const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
-        const uint32_t bits = vx_mix32((e >> 5) ^ dkey) >> (e & 31u);
+        const vx_dkey dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
+        const uint32_t bits = vx_drop_word(dkey, e >> 5) >> (e & 31u);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] *= __uint_as_float((bits << (30 - c)) & 0x40000000u);   // keep ? 2 : 0
       } else if (a.drop_mode == VX_DROP_MASK) {

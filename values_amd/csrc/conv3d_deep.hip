@@ -135,6 +135,7 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
     unsigned voff[IN_IT];
     int ldst[IN_IT];
     unsigned ibad_always = 0, ibad_xlo = 0, ibad_xhi = 0, ibad_ylo = 0, ibad_yhi = 0, ibad_zlo = 0, ibad_zhi = 0;
+    unsigned ibad_sge[3] = {0, 0, 0};              // pieces of tile samples >= 1, 2, 3: the last tile of a batch that is no multiple of ts
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
       const int idx = t + it * NST;
@@ -160,12 +161,16 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       if (dyr >= a.H - lasty) ibad_yhi |= 1u << it;
       if (dzr < 0) ibad_zlo |= 1u << it;
       if (dzr >= a.D - lastz) ibad_zhi |= 1u << it;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (smp > k) ibad_sge[k] |= 1u << it;
     }
     const uint32_t seed_in = PRE == 1 ? vx_seed_of(a, a.in_drop_seed) : 0u;
 
     f32x4 ibuf[IN_IT];
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
-    unsigned p_bad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;
+    unsigned p_bad = 0xFFFFFFFFu, p_e0 = 0;
+    vx_dkey p_key = {0u, 0u};
     // per-PAIR state (recomputed at chunk 0)
     unsigned cs_bad = 0xFFFFFFFFu, cs_soff = 0;
     int cs_n = 0;
@@ -181,6 +186,10 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
       if (tyi == ka.tiles_y - 1) bad |= ibad_yhi;
       if (tzi == 0) bad |= ibad_zlo;
       if (tzi == ka.tiles_z - 1) bad |= ibad_zhi;
+      // samples past the batch (ts <= 4 samples per tile, host-checked): their pieces read zeros, their voxels are not stored --
+      // a sample's numbers do not depend on how many batch mates share its tile
+      const int nv = a.N - n0;
+      if (nv < ka.ts) bad |= ibad_sge[nv >= 1 ? nv - 1 : 0];
       if (!have) bad = 0xFFFFFFFFu;
       cs_bad = bad;
       cs_soff = (unsigned)((((tzi * TZ) * a.H + tyi * TY) * rowf + txi * TX * voxf) * 4);
@@ -417,12 +426,14 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
         vox_of((wave * R + r) * 16 + m_, cx_, ly, lz, smp);
         const int ovox = (lz * a.H + ly) * a.W + cx_;
         // (32-bit offsets: the host checked that a tile's samples stay below 2 GiB)
-        const unsigned ovoff_r = ((unsigned)smp * (unsigned)out_sample + (unsigned)ovox * (unsigned)out_voxf + (unsigned)kp->a.out_coff + 4u * g) * 4u;
+        const unsigned ovoff_r = n0 + smp < a.N
+            ? ((unsigned)smp * (unsigned)out_sample + (unsigned)ovox * (unsigned)out_voxf + (unsigned)kp->a.out_coff + 4u * g) * 4u
+            : VX_OOB;                                   // a tile sample past the batch: the store is dropped
         // ONE keep-word per voxel: the workgroup's 32 output channels are bits 0..31 of word voxel * (Cout / 32) + cg
         uint32_t hword = 0;
         if (EPI == 1) {
-          const uint32_t key = vx_drop_key(seed_out, kp->a.drop_layer, (uint32_t)(n0 + smp));
-          hword = vx_mix32(((vox0 + (unsigned)ovox) * (unsigned)ka.ncg + (unsigned)cg) ^ key) >> (4 * g);
+          const vx_dkey key = vx_drop_key(seed_out, kp->a.drop_layer, (uint32_t)(n0 + smp));
+          hword = vx_drop_word(key, (vox0 + (unsigned)ovox) * (unsigned)ka.ncg + (unsigned)cg) >> (4 * g);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -604,9 +615,11 @@ int vx_pack_conv3d_deep(const float* w_torch, float* w_packed, int Cin, int Cout
 }
 
 // Tile of a layer: 128 R voxels, x first (the whole row up to 16), then y (up to 8), then z; a tile that is a whole sample
-// takes further samples (N must divide).  0 = no tile of this size.
+// takes further samples (the last tile of a batch may hold fewer: the kernel masks them).  false = no tile of this size.
+// The geometry is a function of the VOLUME's shape and the channel count only, never of the batch size: a sample's bits must not
+// depend on its batch mates (round-5 advice; tests/test_gpu_kernels.py::test_conv3d_deep_is_batch_independent).
 struct DeepGeo { int tx, ty, tz, ts, tiles_x, tiles_y, tiles_z, npos; };
-static bool deep_geo(int N, int D, int H, int W, int R, DeepGeo* o) {
+static bool deep_geo(int D, int H, int W, int R, DeepGeo* o) {
   const int vox = 128 * R;
   const int tx = W < 16 ? W : 16;
   if (tx < 4 || (tx & (tx - 1)) || W % tx) return false;
@@ -619,7 +632,7 @@ static bool deep_geo(int N, int D, int H, int W, int R, DeepGeo* o) {
   int ts = vox / (tx * ty * tz);
   if (ts * tx * ty * tz != vox) return false;
   if ((ty & (ty - 1)) || (tz & (tz - 1))) return false;      // (the kernel decodes a tile's voxels with shifts)
-  if (ts > 1 && (tx != W || ty != H || tz != D || N % ts)) return false;
+  if (ts > 1 && (tx != W || ty != H || tz != D || ts > 4)) return false;
   const int npos = ts * (tx + 2) * (ty + 2) * (tz + 2);
   if (npos > (R == 4 ? DEEP_NPOS : 896)) return false;      // the image's positions; 2 npos pieces in IN_IT x 256
   o->tx = tx; o->ty = ty; o->tz = tz; o->ts = ts;
@@ -627,20 +640,15 @@ static bool deep_geo(int N, int D, int H, int W, int R, DeepGeo* o) {
   return true;
 }
 
-// the layer's tile: R = 4 unless only R = 2 fits, or R = 2 fills the 256 persistent workgroups markedly better
-static int deep_pick(int N, int D, int H, int W, int Cout, DeepGeo* o) {
+// the layer's tile: R = 4 wherever it fits, else R = 2.  (Until round 5 the choice also looked at how the batch filled the 256
+// persistent workgroups -- R = 2 for small batches at 8^3 -- which made the fp32 tile sums behind InstanceNorm, and so a sample's
+// bits, a function of the batch size.  At 8^3 x 64 channels and 320 samples the large tile is 2 % faster anyway; at 16^3 the small
+// tile costs 20 %.)
+static int deep_pick(int D, int H, int W, int Cout, DeepGeo* o) {
   DeepGeo g4, g2;
-  const bool ok4 = deep_geo(N, D, H, W, 4, &g4), ok2 = deep_geo(N, D, H, W, 2, &g2);
+  const bool ok4 = deep_geo(D, H, W, 4, &g4), ok2 = deep_geo(D, H, W, 2, &g2);
   if (!ok4 && !ok2) return 0;
-  auto eff = [&](const DeepGeo& g) {
-    const int64_t pairs = (int64_t)(N / g.ts) * g.tiles_x * g.tiles_y * g.tiles_z * (Cout / 32);
-    const int64_t rounds = (pairs + 255) / 256;
-    return (double)pairs / (double)(rounds * 256);
-  };
-  int r = ok4 ? 4 : 2;
-  // (8^3 x 64 channels at 320 samples: 640 large tiles fill 2.5 rounds of workgroups, 1 280 small ones 5 -- and the large tile is
-  // still 2 % faster; at 16^3 the small tile costs 20 %)
-  if (ok4 && ok2 && eff(g2) > 1.3 * eff(g4)) r = 2;
+  const int r = ok4 ? 4 : 2;
   *o = r == 4 ? g4 : g2;
   return r;
 }
@@ -650,7 +658,7 @@ bool vx_conv3d_deep_applies(int N, int D, int H, int W, int Cin, int Cout) {
   if (!vx_conv3d_deep_packs(Cin, Cout)) return false;
   if (W > 32 || H > 32 || D > 32) return false;        // (the larger layers keep the tile kernel's XCD-ordered small tiles)
   DeepGeo g;
-  return deep_pick(N, D, H, W, Cout, &g) != 0;
+  return deep_pick(D, H, W, Cout, &g) != 0;
 }
 
 template <int R, int EPI, int PRE>
@@ -681,7 +689,7 @@ int vx_conv3d_k3_deep(const vx_conv3d_args& a, const float* w_block, int stat_ti
   if (a.drop_mode == VX_DROP_MASK || a.in_drop_mode == VX_DROP_MASK) return 1;
   if (!a.out) return 1;
   DeepGeo g;
-  const int R = deep_pick(a.N, a.D, a.H, a.W, a.Cout, &g);
+  const int R = deep_pick(a.D, a.H, a.W, a.Cout, &g);
   if (!R) return 1;
   if (a.in_xblk) {
     const int csrc = a.Cin / 2;
@@ -701,15 +709,18 @@ int vx_conv3d_k3_deep(const vx_conv3d_args& a, const float* w_block, int stat_ti
   ka.nchunks = a.Cin / 8;
   ka.ncg = a.Cout / 32;
   const int tps = g.tiles_x * g.tiles_y * g.tiles_z;
-  const int64_t npairs = (int64_t)(a.N / g.ts) * tps * ka.ncg;
+  const int64_t npairs = (int64_t)((a.N + g.ts - 1) / g.ts) * tps * ka.ncg;
   if (npairs >= (1ll << 31)) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(deep): too many tiles");
   ka.npairs = (int)npairs;
   auto magic = [](int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
   ka.m_cg = magic(ka.ncg); ka.m_tx = magic(g.tiles_x); ka.m_ty = magic(g.tiles_y); ka.m_tz = magic(g.tiles_z);
   ka.stat_epc = 0;
   if (a.stats_partial) {
-    if (stat_tiles % tps || a.act != VX_ACT_NONE || a.drop_mode != VX_DROP_NONE)
-      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(deep): statistics go with a plain epilogue (%d entries per sample over %d tiles)", stat_tiles, tps);
+    // the caller's partials buffer holds stat_tiles entries per sample (the tile kernel's count): this kernel's tiles must divide it,
+    // else the tile kernel takes the launch (round-5 advice: D % 4 == 2 volumes gave 3 tiles against 4 entries and failed here)
+    if (stat_tiles % tps) return 1;
+    if (a.act != VX_ACT_NONE || a.drop_mode != VX_DROP_NONE)
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(deep): statistics go with a plain epilogue");
     ka.stat_epc = stat_tiles / tps;
   }
   ka.stamps = nullptr;

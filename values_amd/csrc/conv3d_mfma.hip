@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_mfma_kernel(ConvKArgs ka) {
       const unsigned e0 = vox0 * (unsigned)a.Cout;
       const __amdgpu_buffer_rsrc_t osrd =
           __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
-      const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
+      const vx_dkey dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
 
       float ssum[NT][4], ssq[NT][4];
 #pragma unroll

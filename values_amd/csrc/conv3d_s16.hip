@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
   uint32_t fbuf[POOLFIN ? IN_IT : 1];
   const int in_rep = a.in_repeat > 1 ? a.in_repeat : 1;
   f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
-  unsigned p_bad = 0, p_e0 = 0, p_key = 0;
+  unsigned p_bad = 0, p_e0 = 0;
+  vx_dkey p_key = {0u, 0u};
   const bool w_resident = ka.nchunks == 1 || ka.w_all;
   bool w_fresh = true;
 
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_k3_s16_kernel(ConvSArgs ka) {
     const unsigned e0 = vox0 * (unsigned)a.Cout;
     const __amdgpu_buffer_rsrc_t osrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * out_sample), 0, VX_NUMREC, 0x00020000);
-    const uint32_t dkey = f_dhash ? vx_drop_key(seed_out, a.drop_layer, (uint32_t)n) : 0u;
+    const vx_dkey dkey = vx_drop_key(seed_out, a.drop_layer, (uint32_t)n);
     const size_t hnvox = (size_t)a.D * a.H * a.W;
     int hflip = 0;
     float* hbase = nullptr;

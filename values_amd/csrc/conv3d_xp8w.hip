@@ -349,7 +349,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     f32x4 cbuf[CPT];
     unsigned p_ubad = 0;
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
-    unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;   // bit i: row unit i of the staged step lies outside the volume
+    vx_dkey p_key = {0u, 0u};
+    unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0;   // bit i: row unit i of the staged step lies outside the volume
     bool p_hbad = true;                                      // this lane's halo piece of the staged step lies outside
 
     // per-COLUMN state of the staging (recomputed at step 0 of a column, KZ + 1 steps apart): sample, tile position, the
@@ -509,7 +510,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if (hashed) {
           // keep-words of this wave's rows, one hash round per eight rows
 #pragma unroll
-          for (int rd = 0; rd < HR; ++rd) hw[rd] = vx_mix32((uint32_t)((int)(p_e0 >> 5) + l_hw[rd]) ^ p_key);
+          for (int rd = 0; rd < HR; ++rd) hw[rd] = vx_drop_word(p_key, (uint32_t)((int)(p_e0 >> 5) + l_hw[rd]));
         }
       }
       // rows: straight-line code (the compiler interleaves the rows' dependent chains; a row outside the volume arrives as
@@ -936,11 +937,8 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
 
     // ---- epilogue state of THIS wave (column it is storing) ----
     int e_ci = -1, e_n = 0, e_ty = 0, e_tx = 0, e_hflip = 0;
-    uint32_t e_key = 0;
+    vx_dkey e_key = {0u, 0u};
     float* e_ho = nullptr;     // head: this lane's output pointer for z0 = 0, r = 0 (un-flipped position)
-#ifdef VX_HEAD_PAIRS
-    float* e_hs = nullptr;     // (timing experiment) the slot's base
-#endif
     ptrdiff_t e_hz = 0, e_hy = 0;
 
     auto epilogue = [&](int ci, int k) {
@@ -956,9 +954,6 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           if (e_hflip & 2) gy = a.H - 1 - gy;
           if (e_hflip & 4) gx = a.W - 1 - gx;
           e_ho = a.head_out + (size_t)slot * a.head_C * hnvox + ((size_t)gz * a.H + gy) * a.W + gx;
-#ifdef VX_HEAD_PAIRS
-          e_hs = a.head_out + (size_t)slot * a.head_C * hnvox;
-#endif
           e_hz = (ptrdiff_t)((e_hflip & 1) ? -1 : 1) * TZ * a.H * a.W;
           e_hy = (e_hflip & 2) ? -a.W : a.W;
         }
@@ -967,7 +962,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       const unsigned osoff = a.out_xblk ? (unsigned)((((k * TZ) * a.H + e_ty * 8) * (2 * a.W * 8) + e_tx * 32 * 16) * 4)
                                         : vox0 * (unsigned)a.out_pitch * 4u;
       const unsigned e0 = vox0 * 8u;
-      const uint32_t hw_item = (EPI == 1 || EPI == 2 || EPI == 4) ? vx_mix32(((vox0 >> 2) + hword_l) ^ e_key) : 0u;
+      const uint32_t hw_item = (EPI == 1 || EPI == 2 || EPI == 4) ? vx_drop_word(e_key, (vox0 >> 2) + hword_l) : 0u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * (a.out_f16 ? 2 : 4)), 0, VX_NUMREC, 0x00020000);
       // (measured and not kept, round 5: the R keep-words requested up front instead of one ds_bpermute + s_waitcnt lgkmcnt(0) per
@@ -1003,21 +998,6 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         }
         if (HEAD) {
           float* o = e_ho + (ptrdiff_t)k * e_hz + (ptrdiff_t)r * e_hy;
-#ifdef VX_HEAD_PAIRS
-          // TIMING EXPERIMENT ONLY (tools/build_variant.sh pairs -DVX_HEAD_PAIRS; round-4 verdict item 2a): the two class logits of
-          // a voxel as ONE interleaved 8-byte store [voxel][2] instead of two planar 4-byte stores.  The addresses are those of
-          // an interleaved tensor laid over the planar buffer (same bytes written in total), so the RESULTS ARE NOT the planar
-          // logits: never built into the product library.
-          {
-            float p0 = hb[0], p1 = hb[1];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { p0 = fmaf(hw4[0][kk], v[kk], p0); p1 = fmaf(hw4[1][kk], v[kk], p1); }
-            p0 = vx_add_xor16(p0);
-            p1 = vx_add_xor16(p1);
-            if (!(g & 1)) *reinterpret_cast<f32x2*>(o + (o - e_hs)) = (f32x2){p0, p1};
-          }
-          continue;
-#endif
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
             if (c < a.head_C) {
@@ -1213,9 +1193,6 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   ka.ncols = a.N * cps;
   ka.mcps = (unsigned)((1ull << 32) / (unsigned)cps) + 1u;
   ka.rep = (a.in_mean && a.in_repeat > 1 && a.N % a.in_repeat == 0) ? a.in_repeat : 1;
-#ifdef XP_NO_REPORDER
-  ka.rep = 1;
-#endif
   ka.mrep = (unsigned)((1ull << 32) / (unsigned)ka.rep) + 1u;
   ka.mtx = (unsigned)((1ull << 32) / (unsigned)ka.tiles_x) + 1u;
   ka.stat_epc = stat_tiles / cps;

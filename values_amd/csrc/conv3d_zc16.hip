@@ -383,7 +383,8 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
     uint32_t fbuf[PRE == 3 ? RPW : 1], hfbuf = 0;          // pool-finish: the any-dropped word of every piece
     f32x4 p_mean = {0.f, 0.f, 0.f, 0.f}, p_rstd = {1.f, 1.f, 1.f, 1.f};
     f32x4 h_mean = {0.f, 0.f, 0.f, 0.f}, h_rstd = {1.f, 1.f, 1.f, 1.f};
-    unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0, p_key = 0;
+    vx_dkey p_key = {0u, 0u};
+    unsigned p_rowbad = 0xFFFFFFFFu, p_e0 = 0;
     bool p_hbad = true;
 
     // per-COLUMN state (recomputed at step 0 of a column)
@@ -483,12 +484,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       return v;
     };
     auto split4 = [&](const f32x4 v, f16x4& hi, f16x4& lo) {
-#ifdef ZC_SPLIT_PACKED
-      if constexpr (PRE != 0) vx_split4_s(v, hi, lo);
-      else vx_split4(v, hi, lo);
-#else
       vx_split4_s(v, hi, lo);      // plain instructions: the staging waves are this kernel's critical path (stamps: 96 % busy)
-#endif
     };
 
     auto commit = [&](int grp) {
@@ -503,7 +499,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         for (int j = 0; j < 4; ++j) { sc[j] = vx_mul1(p_rstd[j], two); hsc[j] = vx_mul1(h_rstd[j], two); }
         if (hashed) {
 #pragma unroll
-          for (int rd = 0; rd < HR; ++rd) hw[rd] = vx_mix32((uint32_t)((int)(p_e0 >> 5) + l_hw[rd]) ^ p_key);
+          for (int rd = 0; rd < HR; ++rd) hw[rd] = vx_drop_word(p_key, (uint32_t)((int)(p_e0 >> 5) + l_hw[rd]));
 #pragma unroll
           for (int i = 0; i < RPW; ++i)
             wrow[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(l_bp + 32 * (i & 7), (int)hw[i >> 3]);
@@ -730,7 +726,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
 
     // ---- epilogue state of THIS wave (column it is storing) ----
     int e_ci = -1, e_n = 0, e_ty = 0, e_tx = 0;
-    uint32_t e_key = 0;
+    vx_dkey e_key = {0u, 0u};
 
     auto epilogue = [&](int ci, int k) {
       if (ci != e_ci) {
@@ -744,7 +740,7 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
       const int hbp = 4 * (m >> 1);                               // (recomputed per item: two registers less across the matrix loop)
       const unsigned hsh = (unsigned)((m & 1) * 16 + oc);
       const bool e_hash = (EPI == 1) || (EPI == 4 && a.drop_mode == VX_DROP_HASH);
-      const uint32_t hw_item = e_hash ? vx_mix32(((vox0 >> 1) + hword_l) ^ e_key) : 0u;
+      const uint32_t hw_item = e_hash ? vx_drop_word(e_key, (vox0 >> 1) + hword_l) : 0u;
       const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(reinterpret_cast<char*>(kernarg()->a.out) + (size_t)e_n * out_sample * 4), 0, VX_NUMREC, 0x00020000);
       float pl_max[4];

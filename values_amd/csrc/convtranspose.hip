@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_kernel(vx_convT_args a, int64_
       }
     }
     const int oz = 2 * z + dz, oy = 2 * y + dy;
-    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
+    const vx_dkey dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const int ox = 2 * x + d;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_mfma_kernel(vx_convT_args a, i
     q = ct_div(r, dc.mH); const int y = (int)(r - q * (unsigned)a.H); r = q;
     q = ct_div(r, dc.mD); const int z = (int)(r - q * (unsigned)a.D);
     const int n = (int)q;
-    const uint32_t dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
+    const vx_dkey dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 acc;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void convT_k2s2_s16_kernel(vx_convT_args a, in
     qq = ct_div(r, dc.mH); const int y = (int)(r - qq * (unsigned)a.H); r = qq;
     qq = ct_div(r, dc.mD); const int z = (int)(r - qq * (unsigned)a.D);
     const int n = (int)qq;
-    const uint32_t dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
+    const vx_dkey dkey = vx_drop_key(seed0, a.drop_layer, (uint32_t)n);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + oco[rt]);

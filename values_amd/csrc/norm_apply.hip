@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
       mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)ns * a.C + c);
       rs = *reinterpret_cast<const f32x4*>(a.rstd + (size_t)ns * a.C + c);
     }
-    const uint32_t dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
+    const vx_dkey dkey = vx_drop_key(vx_seed_of(a, a.drop_seed), a.drop_layer, (uint32_t)n);
     f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     constexpr int NR = POOL ? (WIDE ? 8 : 4) : 1;
     f32x4 v[NR];

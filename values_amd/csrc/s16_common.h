@@ -20,10 +20,6 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
   for (int j = 0; j < 4; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 h = __builtin_convertvector(x, f16x2);
-#ifdef VX_SPLIT_PLAIN
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector((x - hf) * 2048.f, f16x2);
-#else
     // lo = fp16(2048 x - 2048 hi) as one mixed-precision fma per element, reading hi as the fp16 it is and writing
     // the fp16 half directly: 8 instead of 14 VALU instructions per 16-byte piece, the same bits (2048 x, 2048 hi
     // and their difference are all exact in fp32; tools/micro/split_mix.hip compares the two forms)
@@ -34,7 +30,6 @@ __device__ __forceinline__ void vx_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[0]));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs[1]));
     const f16x2 l = __builtin_bit_cast(f16x2, lv);
-#endif
     hi[j] = h[0]; hi[j + 1] = h[1];
     lo[j] = l[0]; lo[j + 1] = l[1];
   }
@@ -63,10 +58,6 @@ __device__ __forceinline__ void vx_split4_s(const f32x4 v, f16x4& hi, f16x4& lo)
   for (int j = 0; j < 4; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 h = __builtin_convertvector(x, f16x2);
-#ifdef VX_SPLIT_S_PLAIN
-    const float r0 = vx_mul1(vx_sub1(v[j], (float)h[0]), 2048.f), r1 = vx_mul1(vx_sub1(v[j + 1], (float)h[1]), 2048.f);
-    const f16x2 l = __builtin_convertvector((f32x2){r0, r1}, f16x2);
-#else
     const float xs0 = vx_mul1(v[j], 2048.f), xs1 = vx_mul1(v[j + 1], 2048.f);
     const float m2048 = -2048.f;
     const uint32_t hv = __builtin_bit_cast(uint32_t, h);
@@ -74,7 +65,6 @@ __device__ __forceinline__ void vx_split4_s(const f32x4 v, f16x4& hi, f16x4& lo)
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hv), "v"(m2048), "v"(xs1));
     const f16x2 l = __builtin_bit_cast(f16x2, lv);
-#endif
     hi[j] = h[0]; hi[j + 1] = h[1];
     lo[j] = l[0]; lo[j + 1] = l[1];
   }

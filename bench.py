@@ -197,7 +197,7 @@ def roofline_leg(model, x, T, reps=3, chunks=None):
     sec = a["ms"] * 1e-3
     tflops = a["flops"] / sec / 1e12
     gbs = a["bytes"] / sec / 1e9
-    split = "s16" in name or "xp8" in name or "zc16" in name
+    split = any(k in name for k in ("s16", "xp8", "zc16", "deep"))      # the split-fp16 kernel families (convT_k2s2_s16 included)
     mpeak = PEAK_SPLIT16_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     t_mfma = a["flops"] / (mpeak * 1e12)
     t_hbm = a["bytes"] / (PEAK_HBM_GBS * 1e9)

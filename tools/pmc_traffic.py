@@ -15,11 +15,15 @@ def norm(name):
     return m.group(1).replace(" ", "") if m else name
 
 
+# every kernel family of the library that moves tensors on the timed paths (round 6: pool_finish_z_kernel was missing)
+KERNELS = ("conv", "norm", "unc_reduce", "pool_finish", "affine_gather", "fuse_sum", "bilinear", "bn_finalize", "tta_views")
+
+
 def mean_per_kernel(pat, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and ("conv" in r["Kernel_Name"] or "norm" in r["Kernel_Name"] or "unc_reduce" in r["Kernel_Name"]):
+            if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in KERNELS):
                 acc[norm(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 

@@ -34,6 +34,18 @@ const char* vx_kname(const char* fmt, ...);   // lib.cpp: the environment is rea
 
 static inline bool vx_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// compute units of the current device (256 on a whole MI355X; a compute partition has fewer): the persistent kernels launch one
+// workgroup per CU.  One process drives one device, so the first answer is kept.
+static inline int vx_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dropout bit generator (VX_DROP_HASH).  p = 0.5 needs one bit per element: a 32-bit avalanche
 // hash of (key, element_index >> 5) yields the keep-bits of 32 consecutive elements, so a lane

@@ -426,9 +426,10 @@ __global__ __launch_bounds__(768) void conv3d_deep_kernel(DeepArgs ka) {
         vox_of((wave * R + r) * 16 + m_, cx_, ly, lz, smp);
         const int ovox = (lz * a.H + ly) * a.W + cx_;
         // (32-bit offsets: the host checked that a tile's samples stay below 2 GiB)
-        const unsigned ovoff_r = n0 + smp < a.N
-            ? ((unsigned)smp * (unsigned)out_sample + (unsigned)ovox * (unsigned)out_voxf + (unsigned)kp->a.out_coff + 4u * g) * 4u
-            : VX_OOB;                                   // a tile sample past the batch: the store is dropped
+        unsigned ovoff_r = ((unsigned)smp * (unsigned)out_sample + (unsigned)ovox * (unsigned)out_voxf + (unsigned)kp->a.out_coff + 4u * g) * 4u;
+        if constexpr (R == 2) {                         // (only the small tile holds several samples: the large one never fits 4^3 x 8)
+          if (n0 + smp >= a.N) ovoff_r = VX_OOB;        // a tile sample past the batch: the store is dropped
+        }
         // ONE keep-word per voxel: the workgroup's 32 output channels are bits 0..31 of word voxel * (Cout / 32) + cg
         uint32_t hword = 0;
         if (EPI == 1) {
@@ -632,7 +633,7 @@ static bool deep_geo(int D, int H, int W, int R, DeepGeo* o) {
   int ts = vox / (tx * ty * tz);
   if (ts * tx * ty * tz != vox) return false;
   if ((ty & (ty - 1)) || (tz & (tz - 1))) return false;      // (the kernel decodes a tile's voxels with shifts)
-  if (ts > 1 && (tx != W || ty != H || tz != D || ts > 4)) return false;
+  if (ts > 1 && (tx != W || ty != H || tz != D || ts > 4 || R != 2)) return false;   // (the kernel masks a partial last tile for R = 2 only)
   const int npos = ts * (tx + 2) * (ty + 2) * (tz + 2);
   if (npos > (R == 4 ? DEEP_NPOS : 896)) return false;      // the image's positions; 2 npos pieces in IN_IT x 256
   o->tx = tx; o->ty = ty; o->tz = tz; o->ts = ts;
@@ -672,7 +673,7 @@ static int launch_deep(const DeepArgs& ka, hipStream_t s) {
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(deep): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     attr = true;
   }
-  int gx = 256;                // one persistent workgroup per CU
+  int gx = vx_cu_count();      // one persistent workgroup per CU
   if (gx > ka.npairs) gx = ka.npairs;
   static const char* kname = vx_kname("conv3d_deep_kernel<%d,%d,%d>", R, EPI, PRE);   // as rocprofv3 prints it
   vx_note_kernel(kname);

@@ -946,6 +946,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         e_ci = ci;
         col_of(ci, e_n, e_ty, e_tx);
         if (EPI == 1 || EPI == 2 || EPI == 4) e_key = vx_drop_key(seed_out, kernarg()->a.drop_layer, (uint32_t)e_n);
+        // the key words live in VECTOR registers across the items of the column: as scalars they raised the pooling instance's
+        // SGPR spills from 6 to 8 and contr_1_2 ran 5 % slower (same-box A/B of the one- and two-word keys, profiles/r06_dropout_generator.txt)
+        asm volatile("" : "+v"(e_key.a), "+v"(e_key.b));
         if (HEAD) {
           e_hflip = a.head_flip ? a.head_flip[e_n] : 0;
           const int slot = a.head_dst ? a.head_dst[e_n] : e_n;
@@ -1174,7 +1177,7 @@ static int launch_xp8w(const Xp8wArgs& ka, hipStream_t s) {
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(xp8w): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     attr = true;
   }
-  int gx = 256;                // one persistent workgroup per CU (its LDS image fills the CU)
+  int gx = vx_cu_count();      // one persistent workgroup per CU (its LDS image fills the CU)
   if (gx > ka.ncols) gx = ka.ncols;
   static const char* kname = vx_kname("conv3d_xp8w_kernel<%d,%d,%d,%d,%d,%d>", NCH, EPI, PRE, UP, NPW, IN16);   // as rocprofv3 prints it
   vx_note_kernel(kname);

@@ -999,7 +999,7 @@ static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
     if (e != hipSuccess) VX_FAIL((int)e, "vx_conv3d_k3(zc16): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     attr = true;
   }
-  int gx = 256;                // one persistent workgroup per CU
+  int gx = vx_cu_count();      // one persistent workgroup per CU
   if (gx > ka.ncols) gx = ka.ncols;
   static const char* kname = vx_kname("conv3d_zc16_kernel<%d,%d,%d,%d,%d>", CIN, EPI, PRE, ACC, UP);   // as rocprofv3 prints it
   vx_note_kernel(kname);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_pool_kernel(vx_norm_args a,
   const int PW = (WIDE ? a.W / 2 : a.W) * C4;  // work items per row
   const int n = blockIdx.y;
   const int RH = POOL ? a.H / 2 : a.H;   // rows (row bundles) per z
-  __shared__ float s_mu[FOLD ? VX_STAT_MAXC : 4], s_rs[FOLD ? VX_STAT_MAXC : 4];
+  alignas(16) __shared__ float s_mu[FOLD ? VX_STAT_MAXC : 4], s_rs[FOLD ? VX_STAT_MAXC : 4];   // (read as 16-byte vectors)
   __shared__ double s_part[FOLD ? 512 : 1];
   if constexpr (FOLD) vx_block_instnorm(st, n / x_repeat, a.C, blockIdx.x == 0, s_mu, s_rs, s_part);
   float rmax = 0.f;   // largest |value| stored: range guard of the split-fp16 consumers when nothing normalises (a.range_flag)
@@ -451,13 +451,12 @@ __global__ __launch_bounds__(256) void pool_finish_z_kernel(const float* __restr
                                                             float* __restrict__ out, int out_pitch, unsigned Dp, unsigned pv_plane, float s,
                                                             StatSrc st) {
   const int n = blockIdx.y;
-  __shared__ float s_mu[FOLD ? 16 : 4], s_rs[FOLD ? 16 : 4];
+  alignas(16) __shared__ float s_mu[FOLD ? 16 : 4], s_rs[FOLD ? 16 : 4];      // (read as 16-byte vectors)
   __shared__ double s_part[FOLD ? 512 : 1];
-  if constexpr (FOLD) {
-    vx_block_instnorm(st, n, 16, blockIdx.x == 0, s_mu, s_rs, s_part);
-    mean = s_mu - (size_t)n * 16;       // (the loads below index [n][16])
-    rstd = s_rs - (size_t)n * 16;
-  }
+  if constexpr (FOLD) vx_block_instnorm(st, n, 16, blockIdx.x == 0, s_mu, s_rs, s_part);
+  // this sample's 16 means / reciprocal deviations: the workgroup's own reduction (LDS) or row n of the caller's tables
+  const float* mu_n = FOLD ? s_mu : mean + (size_t)n * 16;
+  const float* rs_n = FOLD ? s_rs : rstd + (size_t)n * 16;
   const unsigned pieces = Dp * pv_plane * 4u;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
     const unsigned vox = i >> 2, q = i & 3u;
@@ -466,8 +465,8 @@ __global__ __launch_bounds__(256) void pool_finish_z_kernel(const float* __restr
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(raw + v0 * 16 + q * 4);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(raw + v1 * 16 + q * 4);
     const uint32_t fl = flags[v0 * 4 + q] | flags[v1 * 4 + q];
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * 16 + q * 4);
-    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * 16 + q * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_n + q * 4);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rs_n + q * 4);
     f32x4 t;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -485,18 +484,16 @@ template <bool FOLD>
 __global__ __launch_bounds__(256) void prenorm_split_kernel(float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned pieces, float scale, StatSrc st) {
   const int n = blockIdx.y;
-  __shared__ float s_mu[FOLD ? 8 : 4], s_rs[FOLD ? 8 : 4];
+  alignas(16) __shared__ float s_mu[FOLD ? 8 : 4], s_rs[FOLD ? 8 : 4];
   __shared__ double s_part[FOLD ? 512 : 1];
-  if constexpr (FOLD) {
-    vx_block_instnorm(st, n, 8, blockIdx.x == 0, s_mu, s_rs, s_part);
-    mean = s_mu - (size_t)n * 8;
-    rstd = s_rs - (size_t)n * 8;
-  }
+  if constexpr (FOLD) vx_block_instnorm(st, n, 8, blockIdx.x == 0, s_mu, s_rs, s_part);
+  const float* mu_n = FOLD ? s_mu : mean + (size_t)n * 8;
+  const float* rs_n = FOLD ? s_rs : rstd + (size_t)n * 8;
   f32x4* xs = reinterpret_cast<f32x4*>(x) + (size_t)n * pieces;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < pieces; i += gridDim.x * 256u) {
     const int c = (i & 1u) * 4;
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * 8 + c);
-    f32x4 sc = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * 8 + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mu_n + c);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(rs_n + c);
     f32x4 v = xs[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -215,7 +215,7 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
     whose forwards overflowed recomputes its own statistics on the native-fp32 kernels and then joins the one sum-reduce --
     the ranks never disagree about which collective comes next."""
     from . import _lib
-    from .predict import guarded, pin_seeds, predict_logits
+    from .predict import derive_seed, guarded, pin_seeds, predict_logits
     lib = _lib.load()
     dev = x.device
     V = x.shape[0]
@@ -235,7 +235,7 @@ def ensemble_uncertainty_sharded(models, x: torch.Tensor, world: int, rank: int,
             # one dropout stream per (member, volume block).  The block index enters through an odd-constant stride, as
             # predict_logits decorrelates its chunks: UNet3D.next_seed() rises by ONE per call, so `seed + lo` made block
             # lo = k of call c reuse the masks of block 0 of call c + k (round-4 advice)
-            kw = {"seeds": [(int(seeds[m]) + 0x9E3779B1 * lo) & 0xFFFFFFFF]} if seeds is not None else {}
+            kw = {"seeds": [derive_seed(int(seeds[m]), 1, lo)]} if seeds is not None else {}
             if tta:
                 kw["x_noise"] = None if x_noise is None else x_noise[lo:hi]
             logits = predict_logits([models[m]], x[lo:hi], n_pred=n_pred, tta=tta, n_aleatoric_samples=n_aleatoric_samples,

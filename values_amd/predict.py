@@ -21,6 +21,25 @@ FLIP_DIMS = [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]
 TTA_FLIP_CODES = [0] + [sum(1 << (d - 2) for d in dims) for dims in FLIP_DIMS]  # [0,1,2,4,3,5,6,7]
 
 
+
+def derive_seed(seed: int, kind: int, index: int) -> int:
+    """32-bit dropout seed of sub-stream `index` of a driver level: kind 0 = a volume chunk inside predict_logits, kind 1 = an outer
+    block of a driver that calls predict_* per block (dist.ensemble_uncertainty_sharded, sliding.predict_image_sliding).  Index 0
+    keeps the seed (a one-chunk run IS the plain run); every other index goes through a multiply-xorshift finaliser with a
+    constant per kind, so that (block k, chunk 0) and (block 0, chunk k) never meet -- until round 5 both levels ADDED
+    0x9E3779B1 * index, which replayed the same masks for them (round-5 advice)."""
+    seed &= 0xFFFFFFFF
+    if index == 0:
+        return seed
+    h = (seed ^ ((0x85EBCA6B if kind == 0 else 0xC2B2AE35) * (index + 1))) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
 def gaussian_noise_view(x: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """The noisy TTA input.  The reference uses batchgenerators' GaussianNoiseTransform (variance ~ U(0, 0.1),
     test_3D.py:428) -- third-party, absent here, RNG-stream dependent: parity UNPINNED.  Callers that need the
@@ -225,7 +244,9 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
                 if tta:
                     # (a pinned seed reaches the TTA views too: a dropout member under tta=True then replays the same bits
                     # in the range fallback's second run -- round-4 advice)
-                    kw = {"seed": (int(seeds[mi]) + 0x9E3779B1 * ci) & 0xFFFFFFFF} if seeds is not None else {}
+                    kw = {"seed": derive_seed(int(seeds[mi]), 0, ci)} if seeds is not None else {}
+                    if seed_dev is not None:
+                        kw["seed_dev"] = seed_dev
                     model(xin, src=src, flip=flip, dst=dst, out=flat, **kw)
                 else:
                     kw = {}
@@ -233,7 +254,7 @@ def predict_logits(models: Sequence, x: torch.Tensor, n_pred: int = 1, tta: bool
                         kw["dropout_masks"] = dropout_masks[mi]
                     if seeds is not None:
                         # one hash-dropout stream per (member seed, chunk): sample indices restart in every chunk
-                        kw["seed"] = (int(seeds[mi]) + 0x9E3779B1 * ci) & 0xFFFFFFFF
+                        kw["seed"] = derive_seed(int(seeds[mi]), 0, ci)
                     if seed_dev is not None:
                         kw["seed_dev"] = seed_dev
                     model(xc, n_samples=n_pred, dst=dst, out=flat, **kw)

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from .predict import crop_indices, guarded, pin_seeds, predict_logits
+from .predict import crop_indices, derive_seed, guarded, pin_seeds, predict_logits
 from .uncertainty import uncertainty_maps
 
 
@@ -57,7 +57,7 @@ def predict_image_sliding(models: Sequence, image: torch.Tensor, patch_size: int
         x = torch.stack([img[c[0][0]:c[0][1], c[1][0]:c[1][1], c[2][0]:c[2][1]] for c in batch]).unsqueeze(1)
         kw = {}
         if seeds is not None:
-            kw["seeds"] = [(int(s) + 0x9E3779B1 * b0) & 0xFFFFFFFF for s in seeds]   # (odd stride: see dist.ensemble_uncertainty_sharded)
+            kw["seeds"] = [derive_seed(int(s), 1, b0) for s in seeds]   # (one stream per patch batch: predict.derive_seed)
         x_noise = noise_fn(x) if (tta and noise_fn is not None) else None
         logits = predict_logits(models, x, n_pred=n_pred, tta=tta, x_noise=x_noise,
                                 n_aleatoric_samples=n_aleatoric_samples, **kw, **predict_kw)  # (B, T, C, P,P,P)

@@ -1118,7 +1118,7 @@ def test_conv3d_tile_kernel_prologue_matches_oracle(cin, cout, shape, pmode, vxc
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 5: the role-split z-column kernel of the Cout = 16 layers (conv3d_zc16.hip)
 def _zc16_launch(x_cl, cin, wp, bd, n, d, h, w, *, act=0, drop=0, seed=0, layer=0, stats=False, pre=None, out_xblk=0,
-                 pool=False, out_split=False, poolfin=None):
+                 pool=False, out_split=False, poolfin=None, out_planar=False, in_planar=False):
     """one vx_conv3d_k3 launch (16 output channels) on a dense channels-last device input.
     Returns (out device tensor, stats or None, (pool_raw, pool_flags) or None, kernel name)"""
     lib = _lib.load()
@@ -1130,6 +1130,7 @@ def _zc16_launch(x_cl, cin, wp, bd, n, d, h, w, *, act=0, drop=0, seed=0, layer=
     a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, 16
     a.act, a.drop_mode, a.drop_seed, a.drop_layer = act, drop, seed, layer
     a.out_xblk, a.out_half, a.out_split = out_xblk, 1, 1 if out_split else 0
+    a.out_planar, a.in_planar = (1 if out_planar else 0), (1 if in_planar else 0)
     st = None
     if stats:
         nt = lib.vx_conv3d_k3_tiles_for(d, h, w, 16)
@@ -1211,6 +1212,51 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     assert kn.startswith("conv3d_k3_s16_kernel"), kn
     assert (ncdhw(o6).cpu().double() - ref).abs().max().item() < 4e-5
     assert (o6 - out).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("shape", ZC16_SHAPES + [(5, 4, 8, 32), (1, 12, 16, 64)])
+def test_conv3d_zc16_planar_presplit_handover_is_the_float_handover(shape, vxcfg):
+    """Round 6 (verdict item 4; unet3D_module.py:263-267: expand_2_1 -> expand_2_2 with no normalisation in between): the producer's
+    activation epilogue stores its 16 channels as fp16 (hi, lo) planes in the consumer's LDS row order (out_planar: instances
+    <16,5,..> / <16,6,..>), the consumer stages that tensor by LDS-DMA (in_planar: <16,1,4,0,0> / <16,3,4,0,0>).  The planar tensor is
+    the split of the float one, the consumer's output the SAME BITS as over the float hand-over, and the chain matches the float64
+    oracle; two column tiles in x / three in y, an odd number of samples, hash dropout and none."""
+    lib = _lib.load()
+    n, d, h, w = shape
+    assert lib.vx_conv3d_k3_planar_ok(d, h, w, 16, 16) == 1 and lib.vx_conv3d_k3_planar_ok(d, h, 16, 16, 16) == 0
+    x = torch.from_numpy(formula_tensor((n, 16, d, h, w), 831, scale=1.5)).float()
+    w1, b1, wp1, bd1 = _pack16(16, 832)
+    w2, b2, wp2, bd2 = _pack16(16, 834)
+    xd = cl(x).to(dev())
+    for drop in (_lib.VX_DROP_HASH, 0):
+        kw = dict(act=_lib.VX_ACT_LRELU, drop=drop, seed=21)
+        y1, _, _, k1 = _zc16_launch(xd, 16, wp1, bd1, n, d, h, w, layer=11, **kw)
+        z1, _, _, k2 = _zc16_launch(y1, 16, wp2, bd2, n, d, h, w, layer=12, **kw)
+        y2, _, _, k3 = _zc16_launch(xd, 16, wp1, bd1, n, d, h, w, layer=11, out_planar=True, **kw)
+        z2, _, _, k4 = _zc16_launch(y2, 16, wp2, bd2, n, d, h, w, layer=12, in_planar=True, **kw)
+        e = 1 if drop else 3
+        assert k1.startswith(f"conv3d_zc16_kernel<16,{e},0,0,0>") and k3.startswith(f"conv3d_zc16_kernel<16,{5 if drop else 6},0,0,0>"), (k1, k3)
+        assert k4.startswith(f"conv3d_zc16_kernel<16,{e},4,0,0>"), k4
+        # the planar tensor: [n][d][h][octet][hi | lo][w][8 halves] -> channels-last float
+        pl = y2.contiguous().view(torch.float16).view(n, d, h, 2, 2, w, 8).float()
+        back = (pl[:, :, :, :, 0] + pl[:, :, :, :, 1] / 2048.0).permute(0, 1, 2, 4, 3, 5).reshape(n, d, h, w, 16)
+        assert (back - y1).abs().max().item() <= 1e-6 * max(1.0, y1.abs().max().item())
+        assert torch.equal(z2, z1), (z2 - z1).abs().max().item()
+        ref1 = F.leaky_relu(F.conv3d(x.double(), w1.double(), b1.double(), padding=1), 0.01)
+        if drop:
+            ref1 = ref1 * _hash_mask(21, 11, n, 16, d, h, w) * 2.0
+        ref2 = F.leaky_relu(F.conv3d(ref1, w2.double(), b2.double(), padding=1), 0.01)
+        if drop:
+            ref2 = ref2 * _hash_mask(21, 12, n, 16, d, h, w) * 2.0
+        assert (ncdhw(z2).cpu().double() - ref2).abs().max().item() < 8e-5
+    # refusals: only the 16 -> 16 layers of the z-column kernel, activation epilogues, no aliasing of the partial sums
+    with pytest.raises(_lib.VxError):
+        _zc16_launch(xd, 16, wp1, bd1, n, d, h, w, stats=True, out_planar=True)
+    w8, b8, wp8, bd8 = _pack16(8, 836)
+    with pytest.raises(_lib.VxError):
+        _zc16_launch(xd[..., :8].contiguous(), 8, wp8, bd8, n, d, h, w, act=_lib.VX_ACT_RELU, in_planar=True)
+    with pytest.raises(_lib.VxError):      # a shape the z-column kernel does not take: the tile kernel cannot read the planar layout
+        _zc16_launch(xd[:, :, :, :16].contiguous(), 16, wp1, bd1, n, d, h, 16, act=_lib.VX_ACT_RELU, in_planar=True)
 
 
 @pytest.mark.parametrize("shape", ZC16_SHAPES)

@@ -185,7 +185,7 @@ def test_non_cubic_volume_on_the_level1_z_column_kernel_vs_oracle():
     x = torch.from_numpy(np.concatenate([formula_volume((1, 1) + S, tag=91), formula_volume((1, 1) + S, tag=92)], 0))
     out = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
     names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
-    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names) and any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names), names
+    assert any(n.startswith("conv3d_zc16_kernel<16,5,0,1,1>") for n in names) and any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names), names
     sd = formula_sd_torch(seed_tag=3)
     masks = [m.cpu() for m in model.hash_dropout_masks(seed, 2 * T, *S)]           # sample n = volume * T + pass
     for v in range(2):
@@ -578,7 +578,14 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     assert any(n.startswith("conv3d_zc16_kernel<16,4,1,0,0>") for n in names) and any(n.startswith("conv3d_zc16_kernel<8,0,3,0,0>") for n in names), names
     assert any(n.startswith("pool_finish_z_kernel<true>") for n in names) and len(names) <= 30      # (three of the eight finalize launches ride in their consumers)
     assert sum(n.startswith("instnorm_finalize_kernel") for n in names) == 5 and sum(n.startswith("norm_act_drop_pool_kernel<true,false,true>") for n in names) == 2
-    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names), names       # expand_2_1 as two launches over its halves, upscale3 inside
+    # expand_2_1 as two launches over its halves, upscale3 inside; round 6: its output leaves as the planar pre-split tensor (EPI 5)
+    # and expand_2_2 stages it by LDS-DMA (PRE 4)
+    assert any(n.startswith("conv3d_zc16_kernel<16,5,0,1,1>") for n in names) and any(n.startswith("conv3d_zc16_kernel<16,1,4,0,0>") for n in names), names
+    with _lib.config(s16_no_l1dma=1):        # ... the float hand-over staged through registers: the same bits
+        flt = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+        names6 = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    assert any(n.startswith("conv3d_zc16_kernel<16,1,0,1,1>") for n in names6) and any(n.startswith("conv3d_zc16_kernel<16,1,0,0,0>") for n in names6), names6
+    assert torch.equal(flt["logits"], out["logits"])
     assert not any(n.startswith("convT_k2s2_mfma_kernel<32,") for n in names), names           # (no upscale3 launch)
     with _lib.config(s16_no_upfuse=1):       # ... separate upscale launches (upscale2 and upscale3)
         sep = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
@@ -587,7 +594,7 @@ def test_timed_instances_at_64_vs_oracle_with_exported_hash_masks():
     with _lib.config(s16_no_halves=1):       # ... or as one launch of the tile kernel over the x-blocked buffer (skip half normalised on load)
         one = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
         names1 = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
-    assert not any(n.startswith("conv3d_zc16_kernel<16,1,0,1,") for n in names1) and len(names1) == len(names)    # (+ upscale3, - one half)
+    assert not any(n.startswith("conv3d_zc16_kernel<16,1,0,1,") or n.startswith("conv3d_zc16_kernel<16,5,0,1,") for n in names1) and len(names1) == len(names)    # (+ upscale3, - one half)
     assert np.abs(one["logits"][0].cpu().numpy() - logits).max() < LOGIT_TOL
     assert (one["logits"] - out["logits"]).abs().max().item() < 2e-5
     with _lib.config(s16_no_zc16=1):
@@ -865,7 +872,7 @@ def test_graphed_predictor_replays_equal_eager_and_draw_fresh_dropout():
     assert torch.equal(gd(x2)["logits"], predict_uncertainty([det], x2, n_pred=1)["logits"])
 
 
-@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfin=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1), dict(s16_no_deep=1)])
+@pytest.mark.parametrize("knobs", [dict(s16_skip_raw=0), dict(s16_no_prenorm=1), dict(s16_no_xp8=1), dict(s16_no_upfuse=1), dict(s16_no_upcompose=1), dict(no_head_fusion=1), dict(s16_no_poolfuse=1), dict(s16_no_poolfin=1), dict(s16_no_presplit=1), dict(s16_no_dbplain=1), dict(s16_no_upsplit=1), dict(s16_no_deep=1), dict(s16_no_l1dma=1)])
 def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     """The level-0 data-flow variants behind vx_config: a separate normalise pass for the skip half instead of expand_1_1
     normalising the raw tensor on load (s16_skip_raw=0), no normalise-on-load at all (s16_no_prenorm), the general tile
@@ -889,7 +896,7 @@ def test_level0_fusion_variants_vs_oracle_32(knobs, vxcfg):
     # the un-shared first layer (per-sample src / flip: the TTA path) with dropout off
     det = make_model(do_dropout=False)
     a = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
-    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfin=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0, s16_no_deep=0)     # the defaults
+    vxcfg.set(s16_skip_raw=1, s16_no_prenorm=0, s16_no_xp8=0, s16_no_upfuse=0, s16_no_upcompose=0, no_head_fusion=0, s16_no_poolfuse=0, s16_no_poolfin=0, s16_no_presplit=0, s16_no_dbplain=0, s16_no_upsplit=0, s16_no_deep=0, s16_no_l1dma=0)     # the defaults
     b = predict_uncertainty([det], x.float().cuda(), tta=True, x_noise=x.float().cuda() * 1.01)
     assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5
 

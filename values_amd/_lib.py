@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
                 ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
                 ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32),
                 ("out_split", _i32), ("up_split", _i32), ("up_fused", _p), ("in_pool_flags", _p),
-                ("acc_in", _p), ("acc_pitch", _i32)]
+                ("acc_in", _p), ("acc_pitch", _i32), ("out_planar", _i32), ("in_planar", _i32)]
 
 
 class NormArgs(C.Structure):
@@ -90,7 +90,7 @@ class Config(C.Structure):
     """vx_config (include/values_amd.h): kernel-family selection and tuning knobs, read once from VX_* variables."""
     _fields_ = [(n, _i32) for n in (
         "conv_fp32", "s16_no_prenorm", "s16_no_xp8", "s16_skip_raw", "no_head_fusion", "s16_no_upfuse", "s16_no_poolfuse",
-        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "s16_no_zc16", "s16_no_halves", "s16_no_deep", "c2s_no_wide", "c2s_no_oct")]
+        "storage16", "s16_no_dbplain", "s16_generic", "s16_no_upcompose", "s16_no_upsplit", "s16_no_presplit", "s16_no_poolfin", "s16_no_zc16", "s16_no_halves", "s16_no_deep", "s16_no_l1dma", "c2s_no_wide", "c2s_no_oct")]
 
 
 class UncOutputs(C.Structure):
@@ -146,9 +146,11 @@ SIGNATURES = {
     "vx_conv3d_k3_pool_layout": (_i, [_i, _i, _i, _i, _i]),
     "vx_conv3d_k3_skip_prologue_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "vx_conv3d_k3_acc_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vx_conv3d_k3_planar_ok": (_i, [_i, _i, _i, _i, _i]),
     "vx_convT_zc16_packed_floats": (_i64, []),
     "vx_pack_convT_zc16": (_i, [_p, _p, _p]),
     "vx_prenorm_split": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p]),
+    "vx_zero": (_i, [_p, _i64, _p]),
     "vx_conv3d_k3": (_i, [C.POINTER(ConvArgs), _p]),
     "vx_conv3d_k3_c1_tiles": (_i, [_i, _i, _i]),
     "vx_conv3d_k3_c1": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
@@ -272,6 +274,16 @@ def require_gpu():
     import torch
     if not torch.cuda.is_available():
         raise VxError("values_amd needs a ROCm device (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def zeros(shape, dtype=None, device=None):
+    """torch.empty + vx_zero on the current stream: a zero tensor without an ATen fill kernel (the persistent zero-padded
+    buffers of the 2D walk are created through this, once per geometry)"""
+    import torch
+    require_gpu()
+    t = torch.empty(shape, dtype=dtype or torch.float32, device=device)
+    check(load().vx_zero(ptr(t), t.numel() * t.element_size(), stream_ptr()), "vx_zero")
+    return t
 
 
 def stream_ptr():

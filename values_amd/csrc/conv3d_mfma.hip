@@ -662,6 +662,11 @@ extern "C" int vx_conv3d_k3_acc_ok(int D, int H, int W, int Cin, int Cout) {
   return Cin == 16 && Cout == 16 && conv_config(Cin, Cout).S16 && vx_conv3d_zc16_applies(D, H, W, Cin, Cout) ? 1 : 0;
 }
 
+// in_planar / out_planar: the 16 -> 16 layers of the z-column kernel
+extern "C" int vx_conv3d_k3_planar_ok(int D, int H, int W, int Cin, int Cout) {
+  return Cin == 16 && Cout == 16 && conv_config(Cin, Cout).S16 && vx_conv3d_zc16_applies(D, H, W, Cin, Cout) ? 1 : 0;
+}
+
 // in_mean on the SKIP half of an x-blocked concat input (the decoder's first conv reading a contract block's raw output)
 extern "C" int vx_conv3d_k3_skip_prologue_ok(int D, int H, int W, int Cin, int Cout, int xblk) {
   if (Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 8 || (xblk != 1 && xblk != 2 && xblk != 4)) return 0;
@@ -812,6 +817,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
+  if (a.in_planar || a.out_planar)
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the planar pre-split hand-over (in_planar / out_planar) is taken where vx_conv3d_k3_planar_ok "
+            "(got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);
   if (c.S16 && vx_conv3d_deep_applies(a.N, a.D, a.H, a.W, a.Cin, a.Cout)) {
     // the deep layers (Cout % 32 == 0 on small volumes): role-split tile kernel (conv3d_deep.hip); its weights follow the tile
     // kernel's in the packed block (family 7)

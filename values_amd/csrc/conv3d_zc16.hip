@@ -59,7 +59,12 @@ struct Zc16Args {
 // activation without dropout, 4 = 0 PLUS the (y, x) half of the block's 2 x 2 x 2 max-pool (maximum over the KEPT raw values +
 // any-dropped bits of every 2 x 2 window of a z-plane; conv3d_xp8w.hip EPI 4 explains the monotonicity argument; the z
 // pair is finished by vx_pool_finish_z, which reads a quarter of the tensor's voxels).  PRE: 0 none, 1 InstanceNorm +
-// LeakyReLU + dropout of the producing block on load (CIN = 16), 3 pool-finish on load (CIN = 8: vx_conv3d_args.in_pool_flags).
+// LeakyReLU + dropout of the producing block on load (CIN = 16), 3 pool-finish on load (CIN = 8: vx_conv3d_args.in_pool_flags),
+// 4 (round 6, CIN = 16) the input is the PLANAR pre-split tensor of vx_conv3d_args.in_planar -- [N][D][H][octet][hi | lo][W][8 halves],
+// the producer's epilogue (out_planar below) has done the fp16 split -- and the staging waves move it into the image by LDS-DMA
+// (buffer_load_dwordx4 ... lds: 64 consecutive positions of one (octet, precision) plane per instruction, out-of-range lanes
+// write the zero padding): no registers, no conversion, no ds_write stream in front of the multiplying waves' reads
+// (profiles/r05_zc16_stamps.txt: that stream cost 23 % of the launch).
 // ACC: partial sums (vx_conv3d_args.acc_in) are added before the activation instead of the bias; a multiplying wave requests its
 // item's pieces when it starts the item's matrix loop and uses them in the item's epilogue (no branch around the loads, and
 // nothing else of that wave is in flight but the previous item's stores).
@@ -69,12 +74,18 @@ struct Zc16Args {
 // split products) per 16 coarse voxels, 12 tiles per staging wave and step, B operands straight from global memory (pre-split
 // by the producing conv's epilogue: vx_conv3d_args.up_split), results split and written where staged loads would have gone.
 // The transposed conv's launch, its 0.67 GB write and the conv's read of it disappear (unet3D_module.py:157-190, 332-356).
-template <int CIN, int EPI, int PRE, int ACC = 0, int UP = 0>
+// EPI 5 / 6 (round 6) = 1 / 3 with the PLANAR pre-split output of vx_conv3d_args.out_planar (a compile-time variant: as a run-time
+// branch its address arithmetic and the split's temporaries pushed the partial-sum instances past 168 registers into scratch).
+template <int CIN, int EPI_, int PRE, int ACC = 0, int UP = 0>
 __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
+  constexpr bool PLN = EPI_ == 5 || EPI_ == 6;
+  constexpr int EPI = EPI_ == 5 ? 1 : (EPI_ == 6 ? 3 : EPI_);
   static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
+  static_assert(!PLN || CIN == 16, "the planar output is a 16-channel tensor");
   static_assert(UP == 0 || (CIN == 16 && PRE == 0), "the fused up-convolution produces the 16 input channels itself");
   static_assert(ACC == 0 || EPI == 1 || EPI == 3, "partial sums go with the activation epilogues");
-  static_assert(PRE == 0 || (PRE == 1 && CIN == 16) || (PRE == 3 && CIN == 8), "prologues: normalise-on-load for 16, pool-finish for 8 channels");
+  static_assert(PRE == 0 || ((PRE == 1 || PRE == 4) && CIN == 16) || (PRE == 3 && CIN == 8), "prologues: normalise-on-load / planar DMA for 16, pool-finish for 8 channels");
+  static_assert(PRE != 4 || (ACC == 0 && UP == 0), "the planar input is staged by LDS-DMA: no partial sums, no fused up-convolution");
   constexpr int NW = 8, NPW = 4, NTH = (NW + NPW) * 64;
   constexpr int TZ = 2, R = 4;
   constexpr int HX = 34, HY = 10, ZP = HX * HY;
@@ -311,6 +322,89 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         ++st_iters;
 #endif
         advance(cx); advance(cc); advance(cp);
+        grp_x = grp_c;
+      }
+    } else if constexpr (PRE == 4) {
+      // ---- planar pre-split input, LDS-DMA.  Wave pw owns plane (octet pw >> 1, precision pw & 1) of the image: the slot group of
+      // a step is NPOS = 680 consecutive positions of that plane, moved by NI = 11 instructions of 64 positions (the last one
+      // re-covers the tail: every lane of every instruction has a position).  Position -> (plane of the step, row, x) of the 2 x 10 x 34
+      // window; its tensor byte offset is a constant of the lane, the column / step part rides in soffset; a position outside the
+      // volume is steered past the descriptor's range and lands as zeros (tools/micro/lds_dma_oob.hip).
+      const int pw = wave - NW;
+      constexpr int NPOS = TZ * ZP;
+      constexpr int NI = (NPOS + 63) / 64;
+      const int rowB = a.W * 64;                                // bytes of a tensor row: 4 planes x W x 16
+      const int biasB = ((TZ - 1) * a.H + 1) * rowB + 16;       // keeps (plane -(TZ - 1), row -1, x -1) non-negative
+      unsigned l_off[NI];
+      unsigned b_xlo = 0, b_xhi = 0, b_ylo = 0, b_yhi = 0, b_p0 = 0, b_p1 = 0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int pos = (i < NI - 1 ? 64 * i : NPOS - 64) + lane;
+        const int pz = pos / ZP, rem = pos - pz * ZP;
+        const int r = rem / HX, hx = rem - r * HX;
+        l_off[i] = (unsigned)(((pz - (TZ - 1)) * a.H + (r - 1)) * rowB + (hx - 1) * 16 + pw * a.W * 16 + biasB);
+        if (hx == 0) b_xlo |= 1u << i;
+        if (hx == HX - 1) b_xhi |= 1u << i;
+        if (r == 0) b_ylo |= 1u << i;
+        if (r == HY - 1) b_yhi |= 1u << i;
+        if (pz < TZ - 1) b_p0 |= 1u << i;                       // step 0 of a column: planes -(TZ - 1) .. -1 do not exist
+        else b_p1 |= 1u << i;                                   // step KZ: plane D does not exist
+      }
+      typedef int i32x4_ __attribute__((ext_vector_type(4)));
+      const unsigned lds_plane = (unsigned)(unsigned long long)s_img + (unsigned)((pw >> 1) * OCT_B + (pw & 1) * PREC_B);
+      const size_t sampleB = (size_t)a.D * a.H * rowB;
+      bool cs_have = false;
+      unsigned cs_bad = 0xFFFFFFFFu, cs_soff = 0;
+      i32x4_ cs_srd = {0, 0, 0, 0x00020000};
+      auto column_state = [&](int ci) {
+        const bool have = ci < ncol_wg;
+        int n = 0, ty = 0, tx = 0;
+        if (have) col_of(ci, n, ty, tx);
+        cs_have = have;
+        unsigned bad = 0;
+        if (tx == 0) bad |= b_xlo;
+        if (tx == ka.tiles_x - 1) bad |= b_xhi;
+        if (ty == 0) bad |= b_ylo;
+        if (ty == ka.tiles_y - 1) bad |= b_yhi;
+        cs_bad = bad;
+        cs_soff = (unsigned)((ty * 8) * rowB + tx * 32 * 16);
+        const unsigned long long base = (unsigned long long)a.in + (unsigned long long)n * sampleB - (unsigned long long)biasB;
+        cs_srd[0] = (int)(unsigned)(base & 0xFFFFFFFFull);
+        cs_srd[1] = (int)(unsigned)((base >> 32) & 0xFFFFull);
+        cs_srd[2] = (int)VX_NUMREC;
+        cs_srd[3] = 0x00020000;
+      };
+      auto dma = [&](const Cur& c, int grp) {
+        if (c.s == 0) column_state(c.ci);
+        if (!cs_have) return;                                   // (wave-uniform)
+        unsigned bad = cs_bad;
+        if (c.s == 0) bad |= b_p0;
+        if (c.s == KZ) bad |= b_p1;
+        const unsigned soff = cs_soff + (unsigned)(((TZ * c.s) * a.H) * rowB);
+        const unsigned m0g = lds_plane + (unsigned)(grp * GRP_B);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const unsigned vo = ((bad >> i) & 1u) ? VX_OOB : l_off[i];
+          const unsigned m0v = m0g + (unsigned)((i < NI - 1 ? 64 * i : NPOS - 64) * 16);
+          asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(vo), "s"(cs_srd), "s"(soff) : "memory");
+        }
+      };
+      Cur cx = {0, 0}, cc = {0, 0};      // visible / to stage
+      dma(cc, 0); advance(cc);           // S_0 -> slot group 0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int grp_x = 0;
+      while (cx.ci < ncol_wg) {
+        __syncthreads();
+        ZC_STAMP(0);
+        int grp_c = grp_x + 1; if (grp_c == 3) grp_c = 0;               // group S_{j+1} goes into: nobody reads it in this iteration
+        if (cc.ci < ncol_wg && !(ZC_ABL & 4)) dma(cc, grp_c);
+        ZC_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // landed before the barrier that makes the step visible
+        ZC_STAMP(5);
+#ifdef VX_CONV_STAMPS
+        ++st_iters;
+#endif
+        advance(cx); advance(cc);
         grp_x = grp_c;
       }
     } else {
@@ -790,6 +884,25 @@ __global__ __launch_bounds__(768) void conv3d_zc16_kernel(Zc16Args ka) {
         if (!STATS) rmax = fmaxf(fmaxf(rmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         u32x4 sv = __builtin_bit_cast(u32x4, v);
         if (EPI == 1 || EPI == 3) {
+          if constexpr (PLN) {
+            // the consumer stages by LDS-DMA: its image rows are [octet][hi | lo][x][8 halves] -- this lane's 4 channels are one half
+            // of a 16-byte entry of the hi plane and of the lo plane of octet g >> 1 (the lane pair g, g ^ 1 fills the entry)
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            f16x4 hi, lo;
+            vx_split4_s(v, hi, lo);
+            const unsigned rowB = (unsigned)a.W * 64u, plB = (unsigned)a.W * 16u;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));          // (keeps this address arithmetic inside the epilogue: one register less across the matrix loop)
+            const int g_ = ln >> 4, m_ = ln & 15;
+            const unsigned pvo = (unsigned)(lz * a.H + ly0) * rowB + (unsigned)((g_ >> 1) * 2) * plB + (unsigned)(x0 + m_) * 16u + (unsigned)(g_ & 1) * 8u;
+            const unsigned pso = (unsigned)((k * TZ) * a.H + e_ty * 8 + r) * rowB + (unsigned)(e_tx * 32) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), osrd, (int)pvo, (int)pso, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), osrd, (int)pvo, (int)(pso + plB), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 3" ::: "memory");      // (the store-data hazard with an SGPR soffset, below)
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
           if (a.out_split) {   // the consumer is the fused up-convolution: hand the piece over as the fp16 pairs it multiplies
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             f16x4 hi, lo;
@@ -1011,6 +1124,8 @@ static int launch_zc16(const Zc16Args& ka, hipStream_t s) {
 // 1 = not taken (the caller uses the general tile kernel)
 int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_tiles, hipStream_t s) {
   if (a.in_xblk || a.head_out || a.in_split || a.in_f16 || a.out_f16 || (a.in_repeat > 1)) return 1;
+  if ((a.in_planar || a.out_planar) && (a.drop_mode == VX_DROP_MASK || !a.out || a.in_pitch != a.Cin || a.Cout != 16))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): the planar pre-split hand-over needs hash or no dropout and dense 16-channel tensors");
   if (a.up_in && (a.Cin != 16 || a.in_mean || a.stats_partial || a.up_pitch < 32 || a.up_pitch % 4 || a.up_fused))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): the fused up-convolution (32 coarse channels -> the conv's 16 input channels) goes with an "
             "activation epilogue, no prologue, up_pitch >= 32 (got %d), up_w packed by vx_pack_convT_zc16", a.up_pitch);
@@ -1040,17 +1155,37 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
   if (a.in_pool_flags) pre = 3;
   else if (a.in_mean) pre = 1;
   if ((pre == 1 && a.Cin != 16) || (pre == 3 && a.Cin != 8)) return 1;
+  if (a.in_planar) {
+    if (a.Cin != 16 || pre != 0 || a.up_in || a.acc_in || a.stats_partial || !vx_aligned16(a.in) ||
+        (int64_t)a.D * a.H * a.W * 64 >= (1ll << 31))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): a planar pre-split input (in_planar) goes with 16 -> 16, an activation epilogue, no "
+              "prologue / up-convolution / partial sums, a 16-byte aligned tensor, one sample below 2 GiB");
+    pre = 4;
+  }
+  if (a.out_planar && (a.stats_partial || a.out_pitch != 16 || a.out_coff != 0 || a.out_xblk || a.out_split || a.out == a.acc_in ||
+                       (int64_t)a.D * a.H * a.W * 64 >= (1ll << 31)))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): a planar pre-split output (out_planar) goes with an activation epilogue into a dense "
+            "16-channel tensor that is not the partial sums' (another layout), one sample below 2 GiB");
   int epi;
   if (a.stats_partial) epi = a.pool_out ? 4 : 0;
   else if (a.drop_mode == VX_DROP_HASH) { if (a.act != VX_ACT_LRELU) return 1; epi = 1; }
   else epi = 3;
   if (a.out_split && a.stats_partial) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): out_split goes with the activation epilogues");
+  if (a.out_planar) {
+    // the instances that exist: the decoder's up-half launch (partial sums + fused up-convolution) and the plain 16 -> 16 layer
+    if (a.Cin != 16 || pre != 0 || (epi != 1 && epi != 3) || ((a.acc_in != nullptr) != (a.up_in != nullptr)))
+      VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): out_planar goes with 16 -> 16, an activation epilogue, no prologue, and either partial "
+              "sums + the fused up-convolution together or neither");
+    epi = epi == 1 ? 5 : 6;
+  }
   if (a.acc_in) {
     if (a.Cin != 16 || pre != 0 || a.stats_partial || a.acc_pitch < 16 || a.acc_pitch % 4 || !vx_aligned16(a.acc_in) ||
         (int64_t)a.D * a.H * a.W * a.acc_pitch * 4 >= (1ll << 31))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(zc16): partial sums (acc_in) go with 16 -> 16, no prologue, an activation epilogue, a "
               "16-byte aligned tensor of pitch >= 16 (pitch %d), one sample below 2 GiB", a.acc_pitch);
     if (a.up_in) {
+      if (epi == 5) return launch_zc16<16, 5, 0, 1, 1>(ka, s);
+      if (epi == 6) return launch_zc16<16, 6, 0, 1, 1>(ka, s);
       if (epi == 1) return launch_zc16<16, 1, 0, 1, 1>(ka, s);
       return launch_zc16<16, 3, 0, 1, 1>(ka, s);
     }
@@ -1065,6 +1200,7 @@ int vx_conv3d_k3_zc16(const vx_conv3d_args& a, const float* w_block, int stat_ti
 #define ZC16_CASE(C_, E_, P_) if (a.Cin == C_ && epi == E_ && pre == P_) return launch_zc16<C_, E_, P_>(ka, s)
   ZC16_CASE(16, 0, 0); ZC16_CASE(16, 0, 1); ZC16_CASE(16, 4, 0); ZC16_CASE(16, 4, 1);
   ZC16_CASE(16, 1, 0); ZC16_CASE(16, 1, 1); ZC16_CASE(16, 3, 0); ZC16_CASE(16, 3, 1);
+  ZC16_CASE(16, 1, 4); ZC16_CASE(16, 3, 4); ZC16_CASE(16, 5, 0); ZC16_CASE(16, 6, 0);
   ZC16_CASE(8, 0, 0); ZC16_CASE(8, 0, 3); ZC16_CASE(8, 3, 0); ZC16_CASE(8, 1, 0);
 #undef ZC16_CASE
   return 1;

@@ -64,6 +64,7 @@ static void cfg_from_env() {
   g_cfg.s16_no_zc16 = env_int("VX_S16_NO_ZC16", 0);
   g_cfg.s16_no_halves = env_int("VX_S16_NO_HALVES", 0);
   g_cfg.s16_no_deep = env_int("VX_S16_NO_DEEP", 0);
+  g_cfg.s16_no_l1dma = env_int("VX_S16_NO_L1DMA", 0);
   g_cfg.c2s_no_wide = env_int("VX_C2S_NO_WIDE", 0);
   g_cfg.c2s_no_oct = env_int("VX_C2S_NO_OCT", 0);
 }
@@ -88,5 +89,5 @@ extern "C" int vx_set_config(const vx_config* cfg) {
 }
 
 extern "C" const char* vx_last_kernel_name(void) { return g_last_kernel ? g_last_kernel : ""; }
-extern "C" int vx_version(void) { return 501; /* 0.5.1 (round 5, second half): vx_config.s16_no_deep, kernel family 7 (Cout % 32 == 0, Cin >= 16: the tile kernel's fragments + the deep-layer kernel's), vx_convT_k2s2 on split-fp16 products for Cin in {64, 128}, vx_stat_src + vx_norm_act_drop_pool_stats / vx_pool_finish_z_stats / vx_prenorm_split_stats; 0.5.0 (round 5): vx_config.s16_no_zc16 / s16_no_halves, vx_conv3d_args.acc_in, vx_unet3d_weights.split_w, vx_pool_finish_z, vx_conv3d_k3_pool_layout, kernel family 6 (Cout = 16, Cin in {8, 16}: the tile kernel's fragments + the z-column kernel's); 0.4.0 (round 4): vx_config lost conv_no_c8, conv_no_xcd, conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs, s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, c2s_no_nt5, convt_no_mfma, s16_range_check, s16_pw, s16_prio (measured-slower variants and tuning knobs, with their instances); + vx_conv3d_k3_presplit_ok; 0.3.3: vx_config.c2s_no_oct, vx_bilinear_softmax_nchw; 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
+extern "C" int vx_version(void) { return 600; /* 0.6.0 (round 6): vx_config.s16_no_l1dma, vx_conv3d_args.out_planar / in_planar, vx_conv3d_k3_planar_ok; the dropout generator's key is two words (other masks for a given seed than 0.5.x); 0.5.1 (round 5, second half): vx_config.s16_no_deep, kernel family 7 (Cout % 32 == 0, Cin >= 16: the tile kernel's fragments + the deep-layer kernel's), vx_convT_k2s2 on split-fp16 products for Cin in {64, 128}, vx_stat_src + vx_norm_act_drop_pool_stats / vx_pool_finish_z_stats / vx_prenorm_split_stats; 0.5.0 (round 5): vx_config.s16_no_zc16 / s16_no_halves, vx_conv3d_args.acc_in, vx_unet3d_weights.split_w, vx_pool_finish_z, vx_conv3d_k3_pool_layout, kernel family 6 (Cout = 16, Cin in {8, 16}: the tile kernel's fragments + the z-column kernel's); 0.4.0 (round 4): vx_config lost conv_no_c8, conv_no_xcd, conv_per_cu, s16_per_cu, c8_per_cu, convt_wgs, s16_no_xp, s16_no_db, s16_no_db3, s16_no_epi, s16_no_ty8, s16_no_wall, c2s_no_nt5, convt_no_mfma, s16_range_check, s16_pw, s16_prio (measured-slower variants and tuning knobs, with their instances); + vx_conv3d_k3_presplit_ok; 0.3.3: vx_config.c2s_no_oct, vx_bilinear_softmax_nchw; 0.3.2: vx_config.c2s_no_wide; 0.3.1: vx_prenorm_split, vx_conv3d_args.in_split, vx_config.s16_no_presplit; 0.3.0: vx_config lost conv_dma, s16_ping, s16_dbg, c8_dbg, dma_dbg, dma_nw16, c8_tile16, s16_no_wspec (round 3) */ }
 extern "C" const char* vx_last_error_string(void) { return g_err; }

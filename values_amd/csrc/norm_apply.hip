@@ -596,3 +596,12 @@ extern "C" int vx_pool_finish_z_stats(const float* pool_raw, const uint32_t* poo
   VX_CHECK_LAUNCH("vx_pool_finish_z_stats");
   return VX_OK;
 }
+
+
+extern "C" int vx_zero(void* p, int64_t bytes, vx_stream_t stream) {
+  if (bytes < 0 || (!p && bytes > 0)) VX_FAIL(VX_E_NULL, "vx_zero: null pointer / negative size");
+  if (bytes == 0) return VX_OK;
+  const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  if (e != hipSuccess) VX_FAIL((int)e, "vx_zero: hipMemsetAsync(%lld B): %s", (long long)bytes, hipGetErrorString(e));
+  return VX_OK;
+}

@@ -153,6 +153,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // layer pre_layer are applied by the conv while it stages its tiles (pre_rep samples share one raw tensor)
   bool pre_split_ = false;           // set around the contr_1_2 launch when its input went through vx_prenorm_split
   bool osplit_ = false, usplit_ = false;   // pre-split hand-over of B_1 (expand_2_2 -> upscale2 inside expand_1_1)
+  bool in_planar_ = false;                 // set around expand_2_2's launch when expand_2_1 left its output planar (round 6)
   int st16_ = 0;                     // reduced-storage mode: 1 around expand_1_1's launch (fp16 output), 2 around expand_1_2's (fp16 input)
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
@@ -197,6 +198,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.out_f16 = st16_ == 1 ? 1 : 0;
     a.in_f16 = st16_ == 2 ? 1 : 0;
     a.out_split = osplit_ ? 1 : 0;       // expand_2_2 hands B_1 to the fused up-convolution as fp16 pairs
+    a.in_planar = in_planar_ ? 1 : 0;
     a.up_split = (up_in && usplit_) ? 1 : 0;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     if (pool_raw_ && (wi & 1) && wi < 8) {   // contr_l_2 also leaves the window maxima of its block's MaxPool (dropout layer 2 l + 1 = wi)
@@ -281,6 +283,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   // launches of the 16-channel z-column kernel over them (vx_conv3d_args.acc_in) -- level 1 of the F = 8 networks
   bool halves[4] = {false, false, false, false};
   bool fuse_up1 = false, usplit1_ = false;   // upscale3 inside expand_2_1's up-half launch; B_2 handed over as fp16 pairs
+  bool planar1 = false;                      // expand_2_1's output left as the planar pre-split tensor expand_2_2 stages by LDS-DMA
   // ---------------- encoder ----------------
   const bool inorm = !w->no_instancenorm;
   const int ICH = w->in_channels > 1 ? w->in_channels : 1;
@@ -466,6 +469,14 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       if (fuse_up1) {   // upscale3 evaluated by this launch's staging waves from B_2 (the up tensor never exists)
         a2.in = p.B[l + 1]; a2.up_in = p.B[l + 1]; a2.up_pitch = 2 * C; a2.up_w = w->up3_zc16; a2.up_b = w->up_b[2];
         a2.up_split = usplit1_ ? 1 : 0;
+        // Round 6: the block's second conv has no normalisation in front of it (unet3D_module.py:263-267), so this launch's epilogue
+        // hands the tensor over as the fp16 (hi, lo) planes expand_2_2's matrix instructions take, in its LDS row order, and
+        // expand_2_2 stages it by LDS-DMA.  The planar tensor goes into the up half of CAT_l, free since upscale3 lives inside
+        // this launch (it cannot overwrite A_l in place: the partial sums there have the float layout).
+        if (l == 1 && dm != VX_DROP_MASK && !vx_cfg().s16_no_l1dma && vx_conv3d_k3_planar_ok(L.D, L.H, L.W, C, C)) {
+          a2.out = p.CAT[l]; a2.out_planar = 1;
+          planar1 = true;
+        }
       }
       VX_STEP(fuse_up1 ? "upscale3+expand_2_1(up half)" : "expand_2_1(up half)", vx_conv3d_k3(&a2, stream));
     }
@@ -483,7 +494,9 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       fuse_up1 = true;
       if (!vx_cfg().s16_no_upsplit) { osplit_ = true; usplit1_ = true; }
     }
-    VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
+    in_planar_ = l == 1 && planar1;
+    VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(in_planar_ ? p.CAT[l] : p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
+    in_planar_ = false;
     st16_ = 0;
     osplit_ = false;
     if ((l > 1 || (l == 1 && !fuse_up)) && !(l == 2 && fuse_up1))

@@ -358,7 +358,7 @@ class HighResolutionNet(nn.Module):
             geo = (n, oh, ow, pitch)
             hit = self._zcache.get(key)
             if hit is None or hit[0] != geo:
-                hit = self._zcache[key] = (geo, torch.zeros(geo, dtype=torch.float32, device=x.t.device))
+                hit = self._zcache[key] = (geo, _lib.zeros(geo, dtype=torch.float32, device=x.t.device))
             self._zreal[name] = cout
             out = hit[1]
         else:
@@ -404,7 +404,7 @@ class HighResolutionNet(nn.Module):
             geo = (2, G, raw.C)
             hit = self._zcache.get(key)
             if hit is None or hit[0] != geo:
-                hit = self._zcache[key] = (geo, torch.zeros(geo, dtype=torch.float32, device=raw.t.device))
+                hit = self._zcache[key] = (geo, _lib.zeros(geo, dtype=torch.float32, device=raw.t.device))
             ss = hit[1]
         else:
             ss = torch.empty((2, G, raw.C), dtype=torch.float32, device=raw.t.device)
@@ -609,7 +609,7 @@ class HighResolutionNet(nn.Module):
             n, cin, h, w = x.shape
             if cin != self.in_channels:
                 raise ValueError(f"expected {self.in_channels} input channels, got {cin}")
-            xin = torch.zeros((n, h, w, _rp(cin)), dtype=torch.float32, device=x.device)   # channels-last, pitch round4(cin)
+            xin = _lib.zeros((n, h, w, _rp(cin)), dtype=torch.float32, device=x.device)   # channels-last, pitch round4(cin)
             xin[..., :cin] = x.permute(0, 2, 3, 1)
         self._hold.append(xin)
         a = _Act(xin, _rp(cin))

@@ -595,6 +595,22 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
                 "note": "vx_config.storage16 = 1: expand_1_1 -> expand_1_2 tensor stored as fp16 (2 instead of 3 matrix products "
                         "in expand_1_2); NOT the default, NOT within the 1e-4 parity bar -- the deviation from the float64 "
                         "oracle is asserted in tests/test_gpu_unet3d.py::test_storage16_mode_reports_its_deviation..."}
+        # mode 2 (round 6): besides that tensor, ONE fp16 product per fp32 product on the three full-resolution launches
+        with _lib.config(storage16=2):
+            red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+            dev_maps2 = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
+            flips2 = int((red["pred_seg_mean"] != ref_seg).sum().item())
+
+            def step16b(i):
+                return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
+            t16b = timed_regions(step16b, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+        s16b = summarise(t16b, V * world * args.steps, args.steps)
+        st16["fp16_products"] = {"value": s16b["value"], "ms_per_step": s16b["ms_per_step"], "unit": "volumes/s",
+                                 "max_abs_diff_vs_default_path": dev_maps2, "argmax_flips": flips2,
+                                 "note": "vx_config.storage16 = 2: mode 1 plus one fp16 product per fp32 product (activations and "
+                                         "weights rounded to fp16, fp32 accumulation) on contr_1_2, upscale2 + expand_1_1 and "
+                                         "expand_1_2 + head -- what BASELINE config 2 calls bf16; a side number, never `value`; "
+                                         "deviation from the float64 oracle asserted in test_fp16_products_mode_reports_its_deviation_at_64"}
 
     pcie = None
     if args.pcie and world == 1:

@@ -977,3 +977,34 @@ def test_storage16_mode_reports_its_deviation_and_leaves_the_default_alone(vxcfg
     assert d_logit > 0.0                                                      # the mode really ran (fp16 rounding is visible)
     assert d_logit < 2e-2 and all(v < 5e-3 for v in d_maps.values())          # ... and stays a rounding effect
     assert flips <= S ** 3 // 500
+
+
+def test_fp16_products_mode_reports_its_deviation_at_64(vxcfg):
+    """vx_config.storage16 = 2 (round 6; what BASELINE config 2 calls "bf16"): besides the fp16 tensor of mode 1 the three
+    full-resolution launches run ONE fp16 product per fp32 product (vx_conv3d_args.products = 1: instances <1,4,2,0,4,2>,
+    <2,1,1,2,8,2>, <1,2,0,0,4,3>).  Like mode 1 it is measured against the float64 oracle through the exported hash masks, has to
+    stay a rounding effect, does not pretend to meet the parity bar, and leaves the default path's bits alone.  64^3: the
+    smallest volume at which the z-column kernels that carry the mode run."""
+    from values_amd import _lib, predict_uncertainty
+    import bench
+    S, T, seed = 64, 2, 4242
+    model = make_model(do_dropout=True)
+    x = torch.from_numpy(formula_volume((1, 1, S, S, S), tag=71))
+    base = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    vxcfg.set(storage16=2)
+    red = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    names = [r[1] for r in bench.profiled_forward(model, x.float().cuda(), T, seed)]
+    for inst in ("conv3d_xp8w_kernel<1,4,2,0,4,2>", "conv3d_xp8w_kernel<2,1,1,2,8,2>", "conv3d_xp8w_kernel<1,2,0,0,4,3>"):
+        assert any(n.startswith(inst) for n in names), (inst, names)
+    vxcfg.set(storage16=0)
+    again = predict_uncertainty([model], x.float().cuda(), n_pred=T, seeds=[seed])
+    assert torch.equal(again["logits"], base["logits"])
+    masks = [m.cpu() for m in model.hash_dropout_masks(seed, T, S, S, S)]
+    logits, ref = _oracle_maps(formula_sd_torch(), x, [[m[t:t + 1] for m in masks] for t in range(T)])
+    d_logit = np.abs(red["logits"][0].cpu().numpy() - logits).max()
+    d_maps = {k: float(np.abs(red[k][0].cpu().numpy() - ref[k]).max()) for k in KEYS}
+    flips = int((red["pred_seg_mean"] != base["pred_seg_mean"]).sum().item())
+    print(f"fp16 products: max|d| logits {d_logit:.2e}, maps {d_maps}, argmax flips {flips} of {S ** 3}")
+    assert d_logit > 1e-5                                                     # the mode really ran
+    assert d_logit < 5e-2 and all(v < 1e-2 for v in d_maps.values())          # ... and stays a rounding effect
+    assert flips <= S ** 3 // 200

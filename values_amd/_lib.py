@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
                 ("up_in", _p), ("up_w", _p), ("up_b", _p), ("up_pitch", _i32), ("pool_out", _p), ("pool_flags", _p),
                 ("in_split", _i32), ("out_f16", _i32), ("in_f16", _i32),
                 ("out_split", _i32), ("up_split", _i32), ("up_fused", _p), ("in_pool_flags", _p),
-                ("acc_in", _p), ("acc_pitch", _i32), ("out_planar", _i32), ("in_planar", _i32)]
+                ("acc_in", _p), ("acc_pitch", _i32), ("out_planar", _i32), ("in_planar", _i32), ("products", _i32)]
 
 
 class NormArgs(C.Structure):

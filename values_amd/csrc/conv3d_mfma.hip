@@ -817,6 +817,9 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
+  if (a.products != 0 && a.products != 3)
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: products = %d is taken by the full-resolution z-column kernel only (got %dx%dx%d, %d -> %d)",
+            a.products, a.D, a.H, a.W, a.Cin, a.Cout);
   if (a.in_planar || a.out_planar)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the planar pre-split hand-over (in_planar / out_planar) is taken where vx_conv3d_k3_planar_ok "
             "(got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);

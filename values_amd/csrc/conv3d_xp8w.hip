@@ -58,9 +58,14 @@ struct Xp8wArgs {
 // part, the lo plane is zero: the staging waves copy 8 bytes per piece without a split, the multiplying waves skip the
 // lo-activation product (2 matrix instructions per product instead of 3).  Not the default: a tensor rounded to fp16
 // (2^-11 relative) cannot meet the 1e-4 parity of the maps.
+// IN16 >= 2 (round 6, vx_config.storage16 = 2, opt-in like IN16 = 1): ONE fp16 product per fp32 product -- the multiplying waves run
+// only hi x hi (activations and weights rounded to fp16, fp32 accumulation), a third of the matrix instructions; IN16 = 3 combines it
+// with the fp16 input.  What BASELINE config 2 calls "bf16": a throughput mode outside the 1e-4 parity bar, never the default.
 template <int NCH, int EPI, int PRE, int UP, int NPW, int IN16 = 0>
 __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka) {
-  static_assert(IN16 == 0 || (NCH == 1 && PRE == 0 && UP == 0), "fp16 input: one-chunk layers without a prologue");
+  constexpr int IN16S = IN16 & 1;          // the input tensor is stored as fp16
+  constexpr bool ONEP = IN16 >= 2;         // one product per fp32 product
+  static_assert(IN16S == 0 || (NCH == 1 && PRE == 0 && UP == 0), "fp16 input: one-chunk layers without a prologue");
   static_assert(UP == 0 || NCH == 2, "the fused up-convolution produces chunk 0 of a two-chunk layer");
   // UP = 2 (round 4): the up-convolution COMPOSED into this conv's weights (vx_conv3d_args.up_fused).  The up half of the
   // input never exists, not even in LDS: the image holds the skip chunk plus a rolling window of COARSE planes (18 x 6
@@ -209,7 +214,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // then the odd ones: 16 consecutive lanes write 128 contiguous bytes of ONE parity plane (natural order: 2-way conflicts)
     const int l_hx = (lane >> 5) ? 1 + (lane & 30) : 2 + (lane & 30);
     const int l_dx = l_hx - 1;
-    constexpr int ISZ = IN16 ? 2 : 4;                                      // bytes per input element
+    constexpr int ISZ = IN16S ? 2 : 4;                                      // bytes per input element
     const unsigned l_voff = (unsigned)((xpart(l_dx, 0) + biasf) * ISZ);    // chunk term rides in the row's scalar offset
     const int l_lds = (l_hx & 1) * PP * 8 + (l_hx >> 1) * 8 + qq * 4;      // halves
     const int l_bp = 4 * (l_dx >> 2);                                      // ds_bpermute address of this lane's keep-word within its row
@@ -340,11 +345,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const size_t up_sample = (size_t)(a.D >> 1) * Hc * urow;
 
     // ---- register staging: the loads of one step (and what its commit needs to know) ----
-    f32x4 ibuf[IN16 ? 1 : RPW], hbuf = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ibuf[IN16S ? 1 : RPW], hbuf = {0.f, 0.f, 0.f, 0.f};
     // fp16 input: 8 bytes per piece, kept as integer pairs (hipcc 7.2 narrows a 64-bit buffer load to ONE dword when its
     // halves travel through float lanes of a wider vector -- the second dword was garbage; tools/micro/load_b64_narrow.hip)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 ibuf16[IN16 ? RPW : 1], hbuf16 = {0u, 0u};
+    u32x2 ibuf16[IN16S ? RPW : 1], hbuf16 = {0u, 0u};
     f32x4 ubuf[UP == 1 ? UT : 1];
     f32x4 cbuf[CPT];
     unsigned p_ubad = 0;
@@ -418,10 +423,10 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int i = 0; i < RPW; ++i) {
         const int so = soff + (LIN ? u_soff[0] + i * row_soff_step : u_soff[LIN ? 0 : i]);
         const bool rb = (bad >> i) & 1u;
-        if constexpr (IN16 != 0) {
+        if constexpr (IN16S != 0) {
           ibuf16[i] = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0);
         } else {
-          ibuf[IN16 ? 0 : i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0));
+          ibuf[IN16S ? 0 : i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(rb ? VX_OOB : l_voff), rb ? 0 : so, 0));
         }
       }
       p_rowbad = bad;
@@ -431,7 +436,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         if (c.s == KZ) hb |= 64u;
         if (!have) hb = 0x7Fu;
         const bool lbad = (h_flags & hb) != 0u;      // waves without a halo iteration: flag 1 in every lane
-        if constexpr (IN16 != 0) {
+        if constexpr (IN16S != 0) {
           hbuf16 = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0);
         } else {
           hbuf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(lbad ? VX_OOB : h_voff), soff, 0));
@@ -528,11 +533,11 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int i = 0; i < RPW; ++i) {
         if (!LIN && !((um_valid >> i) & 1u)) continue;       // (only the last unit of a wave can be missing)
         _Float16* dst = s_img + gofs + l_lds + (LIN ? u_lds[0] + i * (HXP * 8) : u_lds[LIN ? 0 : i]);
-        if constexpr (IN16 != 0) {     // the stored halves ARE the hi plane; nobody reads a lo plane in this mode
+        if constexpr (IN16S != 0) {     // the stored halves ARE the hi plane; nobody reads a lo plane in this mode
           *reinterpret_cast<f16x4*>(dst) = __builtin_bit_cast(f16x4, ibuf16[i]);
           continue;
         }
-        f32x4 v = ibuf[IN16 ? 0 : i];
+        f32x4 v = ibuf[IN16S ? 0 : i];
         f16x4 hi, lo;
         if constexpr (PRE == 2) {
           // pre-split input (vx_prenorm_split): only this sample's keep bits are left to apply (a row outside the volume
@@ -559,7 +564,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       if (has_halo && !(h_flags & 1u)) {
         f32x4 v = hbuf;                      // zeros where the piece lies outside the volume (out-of-range load)
         f16x4 hi, lo;
-        if constexpr (IN16 != 0) {
+        if constexpr (IN16S != 0) {
           hi = __builtin_bit_cast(f16x4, hbuf16);
           lo = (f16x4){0, 0, 0, 0};
         } else if constexpr (PRE == 2) {
@@ -805,55 +810,65 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           for (int r = 0; r < R; ++r) {
             const _Float16* wp = s_wc + ((((pz * 2 + r) * 6 + cs_) * 2) * 64 + lane) * 8;
             cA[set][r][0] = *reinterpret_cast<const f16x8*>(wp);
-            cA[set][r][1] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
+            if constexpr (!ONEP) cA[set][r][1] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
             cB[set][r][0] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8);
-            cB[set][r][1] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8 + CPL * 8);
+            if constexpr (!ONEP) cB[set][r][1] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8 + CPL * 8);
           }
         };
         auto load_skip = [&](int kz, int ky) {    // what step (kz, ky) needs beyond what step (kz, ky - 1) left
           const _Float16* wp = wsk + (kz * 3 + ky) * (2 * 32 * 8);
           sA[(kz * 3 + ky) & 1][0] = *reinterpret_cast<const f16x8*>(wp);
-          sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+          if constexpr (!ONEP) sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
           for (int jr = (ky == 0 ? 0 : ky + 1); jr <= ky + 1; ++jr) {
             sR[kz & 1][jr][0] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8);
-            sR[kz & 1][jr][1] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8 + PREC_H);
+            if constexpr (!ONEP) sR[kz & 1][jr][1] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8 + PREC_H);
           }
         };
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        constexpr int RDP = ONEP ? 1 : 2;         // fragments per operand: hi (+ lo)
         load_coarse(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * R, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RDP * R, 0);
 #pragma unroll
         for (int t = 0; t < 15; ++t) {
           int nrd = 0;                            // reads requested during this step
-          if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = 4 * R; }
-          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = 2 + (q % 3 == 0 ? 4 : 2); }
+          if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = 2 * RDP * R; }
+          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = RDP * (1 + (q % 3 == 0 ? 2 : 1)); }
           if (t < 6) {
             const int set = t & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][0], t == 0 ? b4[r] : acc[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][1], t == 0 ? zero4 : accx[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][1], cB[set][r][0], accx[r], 0, 0, 0);
+              if constexpr (ONEP) {
+                if (t == 0) accx[r] = zero4;
+              } else {
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][1], t == 0 ? zero4 : accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][1], cB[set][r][0], accx[r], 0, 0, 0);
+              }
             }
           } else {
             const int q = t - 6, kz = q / 3, ky = q % 3;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][0], acc[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
-              accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][r + ky][0], accx[r], 0, 0, 0);
+              if constexpr (!ONEP) {
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][r + ky][0], accx[r], 0, 0, 0);
+              }
             }
           }
           // pin: one read of the next step behind each of this step's matrix instructions
-          constexpr int NMF = 3 * R;
+          constexpr int NMF = (ONEP ? 1 : 3) * R;
           const int pairs = nrd < NMF ? nrd : NMF;
 #pragma unroll
           for (int i = 0; i < NMF; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (i < pairs) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-          constexpr int EXTRA = 4 * R > NMF ? 4 * R - NMF : 1;     // (only a coarse step requests more reads than it multiplies)
-          if (t + 1 < 6 && 4 * R > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXTRA, 0);
+          // (a step that requests more reads than it multiplies: the coarse steps; with one product also the first skip step of a plane)
+          constexpr int EXC = 2 * RDP * R > NMF ? 2 * RDP * R - NMF : 1;
+          if (t + 1 < 6 && 2 * RDP * R > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXC, 0);
+          constexpr int EXS = 3 * RDP > NMF ? 3 * RDP - NMF : 1;
+          if (t + 1 >= 6 && t + 1 < 15 && (t + 1 - 6) % 3 == 0 && 3 * RDP > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXS, 0);
         }
         return;
       }
@@ -864,23 +879,23 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         const _Float16* wch = s_w + wslot * 8;
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
-          f16x8 ah[3], al[3];
+          f16x8 ah[3], al[ONEP ? 1 : 3];
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const _Float16* wp = wch + (kz * 3 + ky) * (2 * 32 * 8);
             ah[ky] = *reinterpret_cast<const f16x8*>(wp);
-            al[ky] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+            if constexpr (!ONEP) al[ky] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
           }
 #pragma unroll
           for (int pq = 0; pq < 2; ++pq) {
             int slot = rb + lz + pq + kz;
             if (slot >= NZ) slot -= NZ;
             const _Float16* row0 = img + slot * (ZP * 8);
-            f16x8 bh[4], bl[4];
+            f16x8 bh[4], bl[ONEP ? 1 : 4];
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
               bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8);
-              bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
+              if constexpr (!ONEP) bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -890,8 +905,12 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
                 const bool fresh = kz == 0 && ky == 0;      // the bias is the first product's C operand
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ky], bh[rr + ky], fresh ? bias4 : acc[r], 0, 0, 0);
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ky], bl[rr + ky], fresh ? zero : accx[r], 0, 0, 0);
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ky], bh[rr + ky], accx[r], 0, 0, 0);
+                if constexpr (ONEP) {
+                  if (fresh) accx[r] = zero;
+                } else {
+                  accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ky], bl[rr + ky], fresh ? zero : accx[r], 0, 0, 0);
+                  accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ky], bh[rr + ky], accx[r], 0, 0, 0);
+                }
               }
             }
           }
@@ -907,23 +926,26 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           int slot = rb + lz + kz;
           if (slot >= NZ) slot -= NZ;
           const _Float16* row0 = img + slot * (ZP * 8);
-          f16x8 bh[R + 2], bl[IN16 ? 1 : R + 2];
+          f16x8 bh[R + 2], bl[(IN16S || ONEP) ? 1 : R + 2];
 #pragma unroll
           for (int jr = 0; jr < R + 2; ++jr) {
             bh[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8);
-            if constexpr (IN16 == 0) bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);
+            if constexpr (IN16 == 0) bl[jr] = *reinterpret_cast<const f16x8*>(row0 + jr * HXP * 8 + PREC_H);      // (neither fp16 input nor one product)
           }
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const _Float16* wp = wch + (kz * 3 + ky) * (2 * 32 * 8);
             const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+            f16x8 al = ah;
+            if constexpr (!ONEP) al = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               const bool fresh = UP != 2 && chunk == 0 && kz == 0 && ky == 0;      // the bias is the first product's C operand
               const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
               acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[r + ky], fresh ? bias4 : acc[r], 0, 0, 0);
-              if constexpr (IN16 == 0) {
+              if constexpr (ONEP) {
+                if (fresh) accx[r] = zero;
+              } else if constexpr (IN16 == 0) {
                 accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[r + ky], fresh ? zero : accx[r], 0, 0, 0);
                 accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[r + ky], accx[r], 0, 0, 0);
               } else {                                                   // fp16 input: its lo part is zero
@@ -974,7 +996,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int r = 0; r < R; ++r) {
         f32x4 v;       // main + cross * 2^-11: one fma per element (exact scaling: the bits of multiply-then-add)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(accx[r][j], 1.0f / 2048.f, acc[r][j]);
+        for (int j = 0; j < 4; ++j) v[j] = ONEP ? acc[r][j] : fmaf(accx[r][j], 1.0f / 2048.f, acc[r][j]);
         if (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
@@ -1234,7 +1256,15 @@ int vx_conv3d_k3_xp8(const vx_conv3d_args& a, int stat_tiles, hipStream_t s) {
   if (a.in_f16) {
     if (!(nch == 1 && epi == 2 && pre == 0 && !up && !a.in_xblk))
       VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): fp16 input goes with the dense 8-channel layer that carries the fused head");
+    if (a.products == 1) return launch_xp8w<1, 2, 0, 0, 4, 3>(ka, s);
     return launch_xp8w<1, 2, 0, 0, 4, 1>(ka, s);
+  }
+  if (a.products == 1) {
+    // opt-in throughput mode (vx_config.storage16 = 2): one fp16 product per fp32 product on the three full-resolution launches
+    if (nch == 1 && epi == 4 && pre == 2 && up == 0) return launch_xp8w<1, 4, 2, 0, 4, 2>(ka, s);
+    if (nch == 2 && epi == 1 && pre == 1 && up == 2) return launch_xp8w<2, 1, 1, 2, 8, 2>(ka, s);
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3(xp8w): products = 1 exists for the MC-dropout forward's contr_1_2, upscale2 + expand_1_1 and "
+            "expand_1_2 + head (nch %d, epilogue %d, prologue %d, up %d)", nch, epi, pre, up);
   }
 #define XP8W_CASE(N_, E_, P_, U_)                                                         \
   if (nch == N_ && epi == E_ && pre == P_ && up == U_)                                    \

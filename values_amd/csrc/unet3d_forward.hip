@@ -154,6 +154,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
   bool pre_split_ = false;           // set around the contr_1_2 launch when its input went through vx_prenorm_split
   bool osplit_ = false, usplit_ = false;   // pre-split hand-over of B_1 (expand_2_2 -> upscale2 inside expand_1_1)
   bool in_planar_ = false;                 // set around expand_2_2's launch when expand_2_1 left its output planar (round 6)
+  int products_ = 0;                       // 1 around the three full-resolution launches in the fp16-products mode (storage16 = 2)
   int st16_ = 0;                     // reduced-storage mode: 1 around expand_1_1's launch (fp16 output), 2 around expand_1_2's (fp16 input)
   float* pool_raw_ = nullptr;        // set around the contr_1_2 launch when its epilogue pools (fuse_pool below)
   uint32_t* pool_flags_ = nullptr;
@@ -199,6 +200,7 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     a.in_f16 = st16_ == 2 ? 1 : 0;
     a.out_split = osplit_ ? 1 : 0;       // expand_2_2 hands B_1 to the fused up-convolution as fp16 pairs
     a.in_planar = in_planar_ ? 1 : 0;
+    a.products = products_;
     a.up_split = (up_in && usplit_) ? 1 : 0;
     a.range_flag = stats ? nullptr : r->range_flag;   // decoder / center outputs feed split-fp16 consumers un-normalised
     if (pool_raw_ && (wi & 1) && wi < 8) {   // contr_l_2 also leaves the window maxima of its block's MaxPool (dropout layer 2 l + 1 = wi)
@@ -371,8 +373,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
         pool_raw_ = p.B[0];
         pool_flags_ = reinterpret_cast<uint32_t*>(p.B[0] + (size_t)N * p.lv[1].nvox * 8);
       }
+      products_ = (st16 && vx_cfg().storage16 == 2 && pre_split_ && fuse_pool) ? 1 : 0;
       VX_STEP(kConv[1], conv(in2, C, 1, p.CAT[0], C, 0, L, C, C, VX_ACT_NONE, -1, p.stats, 0, pre_layer, pre_rep, nullptr,
                              nullptr, xblk_of(L.W)));
+      products_ = 0;
       float* praw = pool_raw_;
       uint32_t* pfl = pool_flags_;
       pool_raw_ = nullptr; pool_flags_ = nullptr;
@@ -442,10 +446,13 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
     const int dl = 9 + 2 * (3 - l);
     const float* up_in = l == 0 && fuse_up ? p.B[1] : nullptr;
     st16_ = (l == 0 && st16) ? 1 : 0;     // expand_1_1 leaves A_0 as fp16 (same buffer, half of it used)
-    if (l == 0 && fuse0)   // the skip half of CAT_0 is contr_1_2's raw output: normalise + LeakyReLU + dropout layer 1 on load
+    if (l == 0 && fuse0) {  // the skip half of CAT_0 is contr_1_2's raw output: normalise + LeakyReLU + dropout layer 1 on load
+      products_ = (st16 && vx_cfg().storage16 == 2 && up_in && w->up_fused && !vx_cfg().s16_no_upcompose) ? 1 : 0;
       VX_STEP(up_in ? "upscale2+expand_1_1" : kConv[wi],
               conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr, xblk_of(L.W), 1, 1,
                    p.mean0, p.rstd0, 0, 0, up_in, 3, 2 * C));
+      products_ = 0;
+    }
     else if (up_in)
       VX_STEP("upscale2+expand_1_1", conv(p.CAT[l], 2 * C, wi, p.A[l], C, 0, L, 2 * C, C, VX_ACT_LRELU, dl, nullptr,
                                           xblk_of(L.W), -1, 1, nullptr, nullptr, 0, 0, up_in, 3, 2 * C));
@@ -495,8 +502,10 @@ extern "C" int vx_unet3d_forward(const vx_unet3d_weights* w, const vx_unet3d_run
       if (!vx_cfg().s16_no_upsplit) { osplit_ = true; usplit1_ = true; }
     }
     in_planar_ = l == 1 && planar1;
+    products_ = (l == 0 && st16 && vx_cfg().storage16 == 2) ? 1 : 0;
     VX_STEP(wi + 1 == 17 ? kLast : kConv[wi + 1], conv(in_planar_ ? p.CAT[l] : p.A[l], C, wi + 1, p.B[l], C, 0, L, C, C, VX_ACT_LRELU, dl + 1, nullptr, 0));
     in_planar_ = false;
+    products_ = 0;
     st16_ = 0;
     osplit_ = false;
     if ((l > 1 || (l == 1 && !fuse_up)) && !(l == 2 && fuse_up1))

@@ -454,8 +454,11 @@ def main():
     ap.add_argument("--hrnet-width", type=int, default=18, choices=(18, 48),
                     help="C4: HRNet-W18 (BASELINE config 4) or W48 (the width of the reference's shipped configs)")
     ap.add_argument("--storage16", action="store_true",
-                    help="C2: ALSO time the opt-in reduced-storage mode (vx_config.storage16: expand_1_1's tensor stored as fp16) and "
-                         "print it as a side object with its measured deviation from the default path; `value` stays the default path")
+                    help="(default at one GPU since round 6; kept so that old command lines parse) C2: ALSO time the opt-in reduced-"
+                         "precision modes (vx_config.storage16 = 1: expand_1_1's tensor stored as fp16; = 2: plus one fp16 product per fp32 "
+                         "product on the full-resolution launches) and print them as a side object with their measured deviation from "
+                         "the default path; `value` stays the default path")
+    ap.add_argument("--no-storage16", action="store_true", help="C2: skip that side measurement")
     ap.add_argument("--graph", action="store_true", help="C2: replay the step as one captured hipGraph (GraphedPredictor)")
     ap.add_argument("--no-gather", action="store_true", help="C2, N > 1: leave the maps on the ranks that computed them (default: "
                     "every step's maps are gathered on rank 0 inside the timed region, the metric SURVEY 8d defines)")
@@ -466,6 +469,8 @@ def main():
                          "reps) and print its object: the command a rocprofv3 --kernel-trace --stats / --pmc pass wraps so that "
                          "the CSV's per-kernel averages are those of the launches the `roofline` object times (the graph replay "
                          "overlaps branch kernels on side streams, where rocprofv3's per-kernel durations are inflated)")
+    ap.add_argument("--roofline-reps", type=int, default=8, help="C4 --roofline-only: timed forwards (a second profile with another count "
+                    "shows which kernels of the trace belong to the model's one-off setup: their call counts do not move)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-inclusive variant (pinned host input, maps copied back)")
     ap.add_argument("--detail", type=str, default=None, help="write the per-kernel breakdown JSON here")
     args = ap.parse_args()
@@ -574,43 +579,46 @@ def run_c2(args, world, rank, dev, barrier, reduce_max):
     model.check_range()      # the fp16-range word keeps the running maximum over every step above
 
     st16 = None
-    if args.storage16:
-        # opt-in reduced-storage throughput mode: never `value` (it cannot meet the 1e-4 parity of the maps); what it buys and
-        # what it costs, measured on the same volumes and dropout seeds as the default path
-        from values_amd import _lib
-        ref_out = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
-        ref_maps = {k: ref_out[k].clone() for k in ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax")}
-        ref_seg = ref_out["pred_seg_mean"].clone()
-        with _lib.config(storage16=1):
-            red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
-            dev_maps = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
-            flips = int((red["pred_seg_mean"] != ref_seg).sum().item())
-            # an EAGER step: a graph captured above replays the default path's kernels whatever the configuration says now
-            def step16(i):
-                return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
-            t16 = timed_regions(step16, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
-        s16 = summarise(t16, V * world * args.steps, args.steps)
-        st16 = {"value": s16["value"], "ms_per_step": s16["ms_per_step"], "unit": "volumes/s",
-                "max_abs_diff_vs_default_path": dev_maps, "argmax_flips": flips, "voxels": int(ref_seg.numel()),
-                "note": "vx_config.storage16 = 1: expand_1_1 -> expand_1_2 tensor stored as fp16 (2 instead of 3 matrix products "
-                        "in expand_1_2); NOT the default, NOT within the 1e-4 parity bar -- the deviation from the float64 "
-                        "oracle is asserted in tests/test_gpu_unet3d.py::test_storage16_mode_reports_its_deviation..."}
-        # mode 2 (round 6): besides that tensor, ONE fp16 product per fp32 product on the three full-resolution launches
-        with _lib.config(storage16=2):
-            red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
-            dev_maps2 = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
-            flips2 = int((red["pred_seg_mean"] != ref_seg).sum().item())
+    if (args.storage16 or world == 1) and not args.no_storage16 and not args.graph:
+        try:
+            # opt-in reduced-storage throughput mode: never `value` (it cannot meet the 1e-4 parity of the maps); what it buys and
+            # what it costs, measured on the same volumes and dropout seeds as the default path
+            from values_amd import _lib
+            ref_out = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+            ref_maps = {k: ref_out[k].clone() for k in ("pred_entropy", "aleatoric_uncertainty", "epistemic_uncertainty", "mean_softmax")}
+            ref_seg = ref_out["pred_seg_mean"].clone()
+            with _lib.config(storage16=1):
+                red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+                dev_maps = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
+                flips = int((red["pred_seg_mean"] != ref_seg).sum().item())
+                # an EAGER step: a graph captured above replays the default path's kernels whatever the configuration says now
+                def step16(i):
+                    return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
+                t16 = timed_regions(step16, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+            s16 = summarise(t16, V * world * args.steps, args.steps)
+            st16 = {"value": s16["value"], "ms_per_step": s16["ms_per_step"], "unit": "volumes/s",
+                    "max_abs_diff_vs_default_path": dev_maps, "argmax_flips": flips, "voxels": int(ref_seg.numel()),
+                    "note": "vx_config.storage16 = 1: expand_1_1 -> expand_1_2 tensor stored as fp16 (2 instead of 3 matrix products "
+                            "in expand_1_2); NOT the default, NOT within the 1e-4 parity bar -- the deviation from the float64 "
+                            "oracle is asserted in tests/test_gpu_unet3d.py::test_storage16_mode_reports_its_deviation..."}
+            # mode 2 (round 6): besides that tensor, ONE fp16 product per fp32 product on the three full-resolution launches
+            with _lib.config(storage16=2):
+                red = predict_uncertainty([model], x, n_pred=T, seeds=[777], range_check="off")
+                dev_maps2 = {k: round(float((red[k] - ref_maps[k]).abs().max().item()), 7) for k in ref_maps}
+                flips2 = int((red["pred_seg_mean"] != ref_seg).sum().item())
 
-            def step16b(i):
-                return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
-            t16b = timed_regions(step16b, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
-        s16b = summarise(t16b, V * world * args.steps, args.steps)
-        st16["fp16_products"] = {"value": s16b["value"], "ms_per_step": s16b["ms_per_step"], "unit": "volumes/s",
-                                 "max_abs_diff_vs_default_path": dev_maps2, "argmax_flips": flips2,
-                                 "note": "vx_config.storage16 = 2: mode 1 plus one fp16 product per fp32 product (activations and "
-                                         "weights rounded to fp16, fp32 accumulation) on contr_1_2, upscale2 + expand_1_1 and "
-                                         "expand_1_2 + head -- what BASELINE config 2 calls bf16; a side number, never `value`; "
-                                         "deviation from the float64 oracle asserted in test_fp16_products_mode_reports_its_deviation_at_64"}
+                def step16b(i):
+                    return pipe.submit(predict_uncertainty([model], x, n_pred=T, seeds=[i], range_check="off"))
+                t16b = timed_regions(step16b, pipe.flush, barrier, args.steps, 2, min(3, max(1, args.repeats)), reduce_max)
+            s16b = summarise(t16b, V * world * args.steps, args.steps)
+            st16["fp16_products"] = {"value": s16b["value"], "ms_per_step": s16b["ms_per_step"], "unit": "volumes/s",
+                                     "max_abs_diff_vs_default_path": dev_maps2, "argmax_flips": flips2,
+                                     "note": "vx_config.storage16 = 2: mode 1 plus one fp16 product per fp32 product (activations and "
+                                             "weights rounded to fp16, fp32 accumulation) on contr_1_2, upscale2 + expand_1_1 and "
+                                             "expand_1_2 + head -- what BASELINE config 2 calls bf16; a side number, never `value`; "
+                                             "deviation from the float64 oracle asserted in test_fp16_products_mode_reports_its_deviation_at_64"}
+        except Exception as e:      # a side measurement must never take the line with it
+            st16 = {"error": f"{type(e).__name__}: {e}"}
 
     pcie = None
     if args.pcie and world == 1:
@@ -842,7 +850,7 @@ def run_c4(args, world, rank, dev, barrier, reduce_max):
 
     if args.roofline_only:
         roof = model.profile_forward(views.t.view(-1, H, W, 4), peak_tflops=PEAK_SPLIT16_TFLOPS, hbm_gbs=PEAK_HBM_GBS, groups=8,
-                                     nhwc=True, reps=8)
+                                     nhwc=True, reps=max(1, args.roofline_reps))
         # the PMC record is a mean over ALL launches of the instance (several layer shapes): it cannot be the traffic of the one
         # shape the object names -- quoted beside it, `traffic` stays null
         roof["instance_traffic_mean"] = pmc_traffic(roof["kernel"], f"traffic_c4w{args.hrnet_width}.json")

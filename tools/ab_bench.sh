@@ -4,8 +4,8 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 for i in 1 2; do
-  VX_LIB_PATH=values_amd/libvalues_amd_base.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --min-gpu-seconds 2 --detail gpurun_out/${TAG}_base_layers_$i.json "$@" > gpurun_out/${TAG}_base_$i.json 2> gpurun_out/${TAG}_base.err
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --min-gpu-seconds 2 --detail gpurun_out/${TAG}_new_layers_$i.json "$@" > gpurun_out/${TAG}_new_$i.json 2> gpurun_out/${TAG}_new.err
+  VX_LIB_PATH=values_amd/libvalues_amd_base.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-storage16 --min-gpu-seconds 2 --detail gpurun_out/${TAG}_base_layers_$i.json "$@" > gpurun_out/${TAG}_base_$i.json 2> gpurun_out/${TAG}_base.err
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency --no-storage16 --min-gpu-seconds 2 --detail gpurun_out/${TAG}_new_layers_$i.json "$@" > gpurun_out/${TAG}_new_$i.json 2> gpurun_out/${TAG}_new.err
 done
 python - <<PY
 import json

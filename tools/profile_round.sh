@@ -5,9 +5,9 @@ tag=${1:-rXX}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency --no-batch64 > gpurun_out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-latency --no-batch64 --no-storage16 > gpurun_out/${tag}_prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_${tag}_$c --output-format csv -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-latency --no-batch64 > gpurun_out/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_${tag}_$c --output-format csv -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-latency --no-batch64 --no-storage16 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1; mean per launch"
@@ -28,6 +28,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_traffic.py "gpurun_out/pmc_${tag}_c4_FETCH_SIZE/**/*counter_collection.csv" "gpurun_out/pmc_${tag}_c4_WRITE_SIZE/**/*counter_collection.csv" gpurun_out/${tag}_traffic_c4w18.json > /dev/null
 cp gpurun_out/${tag}_traffic_c4w18.json profiles/traffic_c4w18.json     # (on the GPU box: the bench line below quotes it; copy it into profiles/ at home too)
+# which kernels of the C4 trace are the model's one-off SETUP (parameter uploads, the persistent zero buffers, weight packing): a second
+# kernel trace with 2 timed forwards instead of 8 -- their call counts do not move, the per-forward kernels' scale with the forwards
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_c4r2 -o ${tag}_c4r2 -- python3 bench.py --config C4 --roofline-only --roofline-reps 2 > gpurun_out/${tag}_c4r2_prof.log 2>&1
+find gpurun_out/prof_${tag}_c4r2 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_c4r2_kernel_stats.csv \;
+python3 - <<PY > gpurun_out/${tag}_c4_setup_kernels.txt
+import csv
+a = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open("gpurun_out/${tag}_c4_kernel_stats.csv"))}
+b = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open("gpurun_out/${tag}_c4r2_kernel_stats.csv"))}
+print("# bench.py --config C4 --roofline-only: kernel call counts with 8 + 1 and with 2 + 1 forwards (rocprofv3 --kernel-trace --stats)")
+print("# a kernel whose count does not move belongs to the one-off setup; per-forward kernels scale 9 : 3")
+for k in sorted(a, key=lambda k: -a[k]):
+    kind = "setup (count fixed)" if a[k] == b.get(k) else ("per forward" if b.get(k) and a[k] * 3 == b[k] * 9 else "other")
+    print(f"{a[k]:6d} {b.get(k, 0):6d}  {kind:20s} {k[:110]}")
+PY
 python3 bench.py --config C4 --steps 5 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4_bench.json 2> gpurun_out/${tag}_c4_bench.err
 python3 bench.py --config C4 --volumes 4 --steps 5 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4b4_bench.json 2> gpurun_out/${tag}_c4b4_bench.err
 python3 bench.py --config C4 --hrnet-width 48 --steps 4 --warmup 2 --repeats 3 > gpurun_out/${tag}_c4w48_bench.json 2> gpurun_out/${tag}_c4w48_bench.err

@@ -739,9 +739,9 @@ class HighResolutionNet(nn.Module):
             if user_out and groups > 1:   # image b of view g -> slot b * slot_stride + slot_offset + g
                 dst = self._itensor([(i % per) * slot_stride + slot_offset + i // per for i in range(n)], dev)
             elif user_out:  # image b, sample t -> slot b * slot_stride + slot_offset + t  (per-image (Npred, C, H, W) stacks)
-                dst = torch.arange(n, dtype=torch.int32, device=dev) * slot_stride + (slot_offset + t)
-            else:
-                dst = torch.arange(t * n, (t + 1) * n, dtype=torch.int32, device=dev)
+                dst = self._itensor([i * slot_stride + slot_offset + t for i in range(n)], dev)
+            else:      # (cached per content like every slot table: no per-forward ATen kernel, nothing a capture cannot hold)
+                dst = self._itensor(range(t * n, (t + 1) * n), dev)
             self._hold.append(dst)
             self._head(feats, out, (h, w), dst, flip, mode, seed, masks, softmax=softmax_out)
         self._hold_last = self._hold  # keep everything alive until the stream has consumed it

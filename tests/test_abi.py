@@ -169,6 +169,61 @@ def test_host_only_queries(lib, vxcfg):
     assert lib.vx_unet3d_workspace_bytes(0, 64, 64, 64, 8) == 0
 
 
+def test_round6_host_queries_and_arg_checks_without_a_gpu(lib, vxcfg):
+    """Round 6, host side only: where the planar pre-split hand-over applies; the argument checks of vx_conv3d_k3 run BEFORE any
+    launch, so a wrong combination is refused on a box without a GPU too (the round-5 advisor found a shape bug this way); the
+    deep-layer kernel's applicability no longer depends on the batch size."""
+    import ctypes as C
+    from values_amd import _lib
+    assert lib.vx_conv3d_k3_planar_ok(32, 32, 32, 16, 16) == 1 and lib.vx_conv3d_k3_planar_ok(16, 24, 64, 16, 16) == 1
+    assert lib.vx_conv3d_k3_planar_ok(32, 32, 16, 16, 16) == 0 and lib.vx_conv3d_k3_planar_ok(32, 32, 32, 8, 16) == 0
+    assert lib.vx_conv3d_k3_planar_ok(64, 64, 64, 8, 8) == 0
+    vxcfg.set(s16_no_zc16=1)
+    assert lib.vx_conv3d_k3_planar_ok(32, 32, 32, 16, 16) == 0
+    vxcfg.set(s16_no_zc16=0)
+
+    def args(cin, cout, d, h, w, n=2, **kw):
+        a = _lib.ConvArgs()
+        dummy = 0x10000                      # never dereferenced: every call below is refused by a host-side check
+        a.in_ = dummy; a.w_packed = dummy; a.bias = dummy; a.out = dummy
+        a.in_pitch, a.out_pitch, a.out_coff = cin, cout, 0
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w, cin, cout
+        a.w_family = lib.vx_conv3d_k3_family(cin, cout)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    refused = [args(16, 16, 16, 16, 16, in_planar=1, act=_lib.VX_ACT_RELU),                 # a shape the z-column kernel does not take
+               args(8, 16, 32, 32, 32, in_planar=1, act=_lib.VX_ACT_RELU),                   # Cin = 8
+               args(16, 16, 32, 32, 32, out_planar=1, stats_partial=0x10000),               # statistics epilogue
+               args(16, 16, 32, 32, 32, out_planar=1, act=_lib.VX_ACT_RELU, out_pitch=32),  # not a dense 16-channel output
+               args(32, 32, 16, 16, 16, products=1, act=_lib.VX_ACT_RELU),                   # one-product mode away from the full-resolution kernels
+               args(8, 8, 64, 64, 64, products=1, act=_lib.VX_ACT_LRELU, drop_mode=_lib.VX_DROP_HASH),   # ... and for an instance that does not exist
+               args(16, 16, 32, 32, 32, products=2, act=_lib.VX_ACT_RELU)]
+    for a in refused:
+        rc = lib.vx_conv3d_k3(C.byref(a), None)
+        assert rc == -2, (rc, lib.vx_last_error_string())      # VX_E_SHAPE
+    assert lib.vx_zero(None, 0, None) == 0 and lib.vx_zero(None, 16, None) < 0
+
+
+def test_derive_seed_keeps_index_zero_and_separates_the_driver_levels():
+    """predict.derive_seed (round-5 advice): chunk 0 / block 0 keep the caller's seed (a one-chunk run IS the plain run, the parity
+    tests export masks for that seed); (block k, chunk 0) and (block 0, chunk k) -- which the additive stride of rounds 4-5 made
+    the SAME seed -- differ, and so do all (level, index) pairs of a realistic run."""
+    from values_amd.predict import derive_seed
+    for s in (0, 1, 123, 0xFFFFFFFF, 4242):
+        assert derive_seed(s, 0, 0) == s & 0xFFFFFFFF and derive_seed(s, 1, 0) == s & 0xFFFFFFFF
+        seen = {}
+        for block in range(0, 64):
+            sb = derive_seed(s, 1, block)
+            for chunk in range(0, 8):
+                v = derive_seed(sb, 0, chunk)
+                assert 0 <= v <= 0xFFFFFFFF
+                assert v not in seen, (s, (block, chunk), seen[v])
+                seen[v] = (block, chunk)
+        old = lambda seed, b, c: (seed + 0x9E3779B1 * b + 0x9E3779B1 * c) & 0xFFFFFFFF       # rounds 4-5
+        assert old(s, 3, 0) == old(s, 0, 3) and derive_seed(derive_seed(s, 1, 3), 0, 0) != derive_seed(derive_seed(s, 1, 0), 0, 3)
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

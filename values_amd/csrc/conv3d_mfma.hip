@@ -739,6 +739,13 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
   if (a.out_xblk && ((a.out_xblk != 1 && a.out_xblk != 2 && a.out_xblk != 4) || a.W % a.out_xblk || (a.out_half != 0 && a.out_half != 1)))
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: bad concat output (xblk=%d, half=%d, W=%d)", a.out_xblk, a.out_half, a.W);
   if ((a.in_mean == nullptr) != (a.in_rstd == nullptr)) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: in_mean / in_rstd must come together");
+  // products: 0 / 3 = the split scheme's three products (default); 1 = the opt-in one-product mode of the full-resolution z-column kernel
+  if (a.products != 0 && a.products != 1 && a.products != 3)
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: products = %d (0 / 3: the default split scheme, 1: one fp16 product)", a.products);
+  if (a.products == 1 && !(conv_config(a.Cin, a.Cout).S16 && vx_conv3d_xp8_applies(a.D, a.H, a.W, a.Cin, a.Cout) &&
+                           a.drop_mode != VX_DROP_MASK && a.in_drop_mode != VX_DROP_MASK))
+    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: products = 1 is taken by the full-resolution z-column kernel only (got %dx%dx%d, %d -> %d)",
+            a.D, a.H, a.W, a.Cin, a.Cout);
   if (a.up_in) {
     if (!a.up_w || !a.up_b) VX_FAIL(VX_E_NULL, "vx_conv3d_k3: fused up-convolution without weights");
     if (!vx_conv3d_k3_upfuse_ok(a.D, a.H, a.W, a.Cin, a.Cout) || a.drop_mode == VX_DROP_MASK || a.stats_partial || a.head_out)
@@ -810,6 +817,7 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     // the full-resolution layers: z-column walk with a rolling LDS window (conv3d_xp8w.hip)
     const int rc = vx_conv3d_k3_xp8(a, conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
+    if (a.products == 1) VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: products = 1, but the z-column kernel does not take this launch");
   }
   if (c.S16 && vx_conv3d_zc16_applies(a.D, a.H, a.W, a.Cin, a.Cout)) {
     // the Cout = 16 layers below full resolution: role-split z-column kernel (conv3d_zc16.hip); its weights follow the tile
@@ -817,9 +825,6 @@ extern "C" int vx_conv3d_k3(const vx_conv3d_args* ap, vx_stream_t stream) {
     const int rc = vx_conv3d_k3_zc16(a, a.w_packed + vx_conv3d_s16_packed_floats(a.Cin, a.Cout), conv_tiles(a.D, a.H, a.W, a.Cout), s);
     if (rc != 1) return rc;
   }
-  if (a.products != 0 && a.products != 3)
-    VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: products = %d is taken by the full-resolution z-column kernel only (got %dx%dx%d, %d -> %d)",
-            a.products, a.D, a.H, a.W, a.Cin, a.Cout);
   if (a.in_planar || a.out_planar)
     VX_FAIL(VX_E_SHAPE, "vx_conv3d_k3: the planar pre-split hand-over (in_planar / out_planar) is taken where vx_conv3d_k3_planar_ok "
             "(got %dx%dx%d, %d -> %d)", a.D, a.H, a.W, a.Cin, a.Cout);

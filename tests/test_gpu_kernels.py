@@ -1214,7 +1214,7 @@ def test_conv3d_zc16_plain_and_activation_epilogues_match_oracle(cin, shape, vxc
     assert (o6 - out).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("shape", ZC16_SHAPES + [(5, 4, 8, 32), (1, 12, 16, 64)])
+@pytest.mark.parametrize("shape", ZC16_SHAPES + [(5, 4, 8, 32), (1, 12, 16, 64), (1, 4, 8, 96)])      # (the last: an interior column tile in x)
 def test_conv3d_zc16_planar_presplit_handover_is_the_float_handover(shape, vxcfg):
     """Round 6 (verdict item 4; unet3D_module.py:263-267: expand_2_1 -> expand_2_2 with no normalisation in between): the producer's
     activation epilogue stores its 16 channels as fp16 (hi, lo) planes in the consumer's LDS row order (out_planar: instances

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
               "tools/fuzz_hrnet.py 20" "tools/fuzz_conv2d.py 300" "tests/fuzz/fuzz_vs_oracle.py 12" "tests/fuzz/fuzz_metrics.py 120"; do
     set -- $spec
     echo "== $1 $2 cases, seed $seed"
-    timeout 1500 python3 $1 $2 $seed 2>&1 | grep -v "amdgpu.ids" | tail -4
+    timeout 1500 python3 $1 $2 $seed 2>&1 | grep -v "amdgpu.ids" | tail -12
   done
 } > gpurun_out/${tag}_fuzz.txt 2>&1
 grep -E "^==|failures|FAIL|Error|error" gpurun_out/${tag}_fuzz.txt | tail -40

@@ -28,6 +28,8 @@ for case in range(cases):
                 shape = (rng.randint(1, 3), 2 * rng.randint(1, 4), 2 * rng.randint(1, 6), 2 * rng.randint(1, 10))
             else:
                 shape = (rng.randint(1, 3), rng.randint(1, 7), rng.randint(1, 11), rng.randint(1, 21))
+                if shape[1] * shape[2] * shape[3] == 1:      # one element per (sample, channel): torch's instance_norm (the oracle) refuses it,
+                    shape = shape[:3] + (2,)                 # as the reference's InstanceNorm3d does at 1^3; seed 23, case 142
             tag = f"norm C={c} {shape} pool={pool}"
             T.test_instnorm_lrelu_drop_pool_matches_oracle(c, shape, pool)
         else:

@@ -747,6 +747,15 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     const size_t hnvox = (size_t)a.D * a.H * a.W;
 
 
+    // UP = 2 (round 6): the hi fragments of the nine skip-chunk weight steps stay in registers for the kernel's life -- they do not
+    // depend on the item, the instance has the registers (87 of the 128 its 16 waves allow) and its multiply loop sits at the LDS
+    // array's limit (1.0 ds_read_b128 per matrix instruction): 9 of the 90 reads of an item gone
+    f16x8 sAh[UP == 2 ? 9 : 1];
+    if constexpr (UP == 2) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) sAh[q] = *reinterpret_cast<const f16x8*>(s_w + wslot * 8 + q * (2 * 32 * 8));
+    }
+
     // ---- accumulators ----
     f32x4 acc[R], accx[R];
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -817,8 +826,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         };
         auto load_skip = [&](int kz, int ky) {    // what step (kz, ky) needs beyond what step (kz, ky - 1) left
           const _Float16* wp = wsk + (kz * 3 + ky) * (2 * 32 * 8);
-          sA[(kz * 3 + ky) & 1][0] = *reinterpret_cast<const f16x8*>(wp);
-          if constexpr (!ONEP) sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);
+          if constexpr (!ONEP) sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);      // (hi: sAh, resident)
           for (int jr = (ky == 0 ? 0 : ky + 1); jr <= ky + 1; ++jr) {
             sR[kz & 1][jr][0] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8);
             if constexpr (!ONEP) sR[kz & 1][jr][1] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8 + PREC_H);
@@ -832,7 +840,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         for (int t = 0; t < 15; ++t) {
           int nrd = 0;                            // reads requested during this step
           if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = 2 * RDP * R; }
-          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = RDP * (1 + (q % 3 == 0 ? 2 : 1)); }
+          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = (RDP - 1) + RDP * (q % 3 == 0 ? 2 : 1); }
           if (t < 6) {
             const int set = t & 1;
 #pragma unroll
@@ -849,9 +857,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
             const int q = t - 6, kz = q / 3, ky = q % 3;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][0], acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][r + ky][0], acc[r], 0, 0, 0);
               if constexpr (!ONEP) {
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][0], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
                 accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][r + ky][0], accx[r], 0, 0, 0);
               }
             }
@@ -867,8 +875,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
           // (a step that requests more reads than it multiplies: the coarse steps; with one product also the first skip step of a plane)
           constexpr int EXC = 2 * RDP * R > NMF ? 2 * RDP * R - NMF : 1;
           if (t + 1 < 6 && 2 * RDP * R > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXC, 0);
-          constexpr int EXS = 3 * RDP > NMF ? 3 * RDP - NMF : 1;
-          if (t + 1 >= 6 && t + 1 < 15 && (t + 1 - 6) % 3 == 0 && 3 * RDP > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXS, 0);
+          constexpr int NS0 = (RDP - 1) + 2 * RDP;                  // reads a plane's first skip step requests
+          constexpr int EXS = NS0 > NMF ? NS0 - NMF : 1;
+          if (t + 1 >= 6 && t + 1 < 15 && (t + 1 - 6) % 3 == 0 && NS0 > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXS, 0);
         }
         return;
       }

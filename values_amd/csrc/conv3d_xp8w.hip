@@ -675,7 +675,12 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     // =============================================== CONSUMER ===============================================
     constexpr bool POOLM = EPI == 4;            // tile r of this wave = plane lz + (r >> 1), row ly0 + (r & 1)
     static_assert(!POOLM || (NCH == 1 && R == 4), "pooling epilogue: one-chunk layers");
-    const int lz = POOLM ? (wave >> 2) * 2 : wave / WPZ, ly0 = POOLM ? (wave & 3) * 2 : (wave % WPZ) * R;
+    // UP = 2 (round 6): a wave's two rows are ly0 and ly0 + 2 -- the SAME y-parity, i.e. one composed-weight class for both, so a
+    // coarse K-step reads its class' weights once (2 + 4 reads instead of 4 + 4 for 6 matrix instructions; the skip planes then
+    // need 5 input rows instead of 4: 75 reads per item instead of 81)
+    constexpr int RS = UP == 2 ? 2 : 1;                                   // rows between the wave's column tiles
+    const int wz_ = wave % WPZ;
+    const int lz = POOLM ? (wave >> 2) * 2 : wave / WPZ, ly0 = POOLM ? (wave & 3) * 2 : (UP == 2 ? (wz_ >> 1) * 4 + (wz_ & 1) : wz_ * R);
     const bool late = wave >= NW / 2;
     // ---- compute-phase constants ----
     // B fragment of (kz, row j): s_img[chunk][prec][parity g & 1][(slot * HY + ly0 + j) * HXP + m + (g >> 1)]
@@ -693,7 +698,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
       for (int s = 0; s < 6; ++s) {
         const int o = 4 * s + g;
         const int oct = o & 1, cxi = (o >> 1) % 3, cyi = (o / 6) & 1;
-        cofs[s] = ((oct * 2) * CPL + ((ly0 >> 1) + cyi) * CW + cxi + m) * 8;
+        cofs[s] = ((oct * 2) * CPL + (((ly0 + 1) >> 1) + cyi) * CW + cxi + m) * 8;     // window row of fine row y: ((y + 1) >> 1) + cyi
       }
     }
     int m_ci = -1, m_ty = 0;           // UP = 2: column of the bias classes below
@@ -701,7 +706,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     unsigned ovoff[R], eoff[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int tz_ = lz + (POOLM ? (r >> 1) : 0), ty_ = ly0 + (POOLM ? (r & 1) : r);
+      const int tz_ = lz + (POOLM ? (r >> 1) : 0), ty_ = ly0 + (POOLM ? (r & 1) : RS * r);
       const int ovox = (tz_ * a.H + ty_) * a.W + lx;
       if (a.out_xblk) {
         const int oxb = a.out_xblk;
@@ -719,7 +724,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
     unsigned hword_l;
     {
       const int rr_ = (lane >> 3) < R ? (lane >> 3) : 0;
-      const int tz_ = lz + (POOLM ? (rr_ >> 1) : 0), ty_ = ly0 + (POOLM ? (rr_ & 1) : rr_);
+      const int tz_ = lz + (POOLM ? (rr_ >> 1) : 0), ty_ = ly0 + (POOLM ? (rr_ & 1) : RS * rr_);
       hword_l = (unsigned)((((tz_ * a.H + ty_) * a.W) >> 2) + (lane & 7));
     }
     const int hbp = 4 * (m >> 1);                                    // ds_bpermute byte address of this lane's word in row 0
@@ -796,7 +801,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         f32x4 b4[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int y = m_ty * 8 + ly0 + r;
+          const int y = m_ty * 8 + ly0 + RS * r;
           const int yc = y == 0 ? 0 : (y == a.H - 1 ? 2 : 1);
           b4[r] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_btab) + ((zc * 3 + yc) * 3) * 32 + m_bofs);
         }
@@ -810,16 +815,18 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         //   coarse step s: per row r its class' weights (hi, lo) + its coarse row (hi, lo): 8 reads
         //   skip step (kz, ky): the weights (2 reads) + the image rows ky, ky + 1 of plane kz, of which row ky came with the
         //   previous step: rows 0, 1 with (kz, 0), row ky + 1 later -- 14 reads per kz as in the plain loop
-        f16x8 cA[2][R][2], cB[2][R][2];          // coarse fragments, two sets
+        f16x8 cA[2][2], cB[2][R][2];             // coarse fragments, two sets: the class' weights (one class per wave) and the rows' coarse rows
         f16x8 sA[2][2];                          // skip weights, two sets
-        f16x8 sR[2][4][2];                       // skip image rows of plane kz (set kz & 1): [row][hi | lo]
+        constexpr int NSR = RS * (R - 1) + 3;    // input rows of a plane the wave's rows read (5)
+        f16x8 sR[2][NSR][2];                     // skip image rows of plane kz (set kz & 1): [row][hi | lo]
+        const int cls = pz * 2 + (ly0 & 1);
         auto load_coarse = [&](int cs_, int set) {
           const _Float16* bp = cb[cs_ / 3] + cofs[cs_];
+          const _Float16* wp = s_wc + ((((cls) * 6 + cs_) * 2) * 64 + lane) * 8;
+          cA[set][0] = *reinterpret_cast<const f16x8*>(wp);
+          if constexpr (!ONEP) cA[set][1] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const _Float16* wp = s_wc + ((((pz * 2 + r) * 6 + cs_) * 2) * 64 + lane) * 8;
-            cA[set][r][0] = *reinterpret_cast<const f16x8*>(wp);
-            if constexpr (!ONEP) cA[set][r][1] = *reinterpret_cast<const f16x8*>(wp + 64 * 8);
             cB[set][r][0] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8);
             if constexpr (!ONEP) cB[set][r][1] = *reinterpret_cast<const f16x8*>(bp + r * CW * 8 + CPL * 8);
           }
@@ -827,40 +834,45 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
         auto load_skip = [&](int kz, int ky) {    // what step (kz, ky) needs beyond what step (kz, ky - 1) left
           const _Float16* wp = wsk + (kz * 3 + ky) * (2 * 32 * 8);
           if constexpr (!ONEP) sA[(kz * 3 + ky) & 1][1] = *reinterpret_cast<const f16x8*>(wp + 32 * 8);      // (hi: sAh, resident)
-          for (int jr = (ky == 0 ? 0 : ky + 1); jr <= ky + 1; ++jr) {
+          // rows the step's column tiles read (RS r + ky) that no earlier step of the plane has loaded: (0, 2), (1, 3), (4)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int jr = RS * r + ky;
+            if (ky >= RS && r < R - 1) continue;      // row RS r + ky = RS (r + 1) + (ky - RS): came with step ky - RS
             sR[kz & 1][jr][0] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8);
             if constexpr (!ONEP) sR[kz & 1][jr][1] = *reinterpret_cast<const f16x8*>(prow[kz] + jr * HXP * 8 + PREC_H);
           }
         };
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         constexpr int RDP = ONEP ? 1 : 2;         // fragments per operand: hi (+ lo)
+        constexpr int NCR = RDP * (1 + R);        // reads of a coarse step: the class' weights + R coarse rows
         load_coarse(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RDP * R, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NCR, 0);
 #pragma unroll
         for (int t = 0; t < 15; ++t) {
           int nrd = 0;                            // reads requested during this step
-          if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = 2 * RDP * R; }
-          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = (RDP - 1) + RDP * (q % 3 == 0 ? 2 : 1); }
+          if (t + 1 < 6) { load_coarse(t + 1, (t + 1) & 1); nrd = NCR; }
+          else if (t + 1 < 15) { const int q = t + 1 - 6; load_skip(q / 3, q % 3); nrd = (RDP - 1) + RDP * (q % 3 < RS ? R : 1); }
           if (t < 6) {
             const int set = t & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][0], t == 0 ? b4[r] : acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][0], cB[set][r][0], t == 0 ? b4[r] : acc[r], 0, 0, 0);
               if constexpr (ONEP) {
                 if (t == 0) accx[r] = zero4;
               } else {
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][0], cB[set][r][1], t == 0 ? zero4 : accx[r], 0, 0, 0);
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][r][1], cB[set][r][0], accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][0], cB[set][r][1], t == 0 ? zero4 : accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cA[set][1], cB[set][r][0], accx[r], 0, 0, 0);
               }
             }
           } else {
             const int q = t - 6, kz = q / 3, ky = q % 3;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][r + ky][0], acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][RS * r + ky][0], acc[r], 0, 0, 0);
               if constexpr (!ONEP) {
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][r + ky][1], accx[r], 0, 0, 0);
-                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][r + ky][0], accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sAh[q], sR[kz & 1][RS * r + ky][1], accx[r], 0, 0, 0);
+                accx[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sA[q & 1][1], sR[kz & 1][RS * r + ky][0], accx[r], 0, 0, 0);
               }
             }
           }
@@ -873,9 +885,9 @@ __global__ __launch_bounds__((8 + NPW) * 64) void conv3d_xp8w_kernel(Xp8wArgs ka
             if (i < pairs) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           // (a step that requests more reads than it multiplies: the coarse steps; with one product also the first skip step of a plane)
-          constexpr int EXC = 2 * RDP * R > NMF ? 2 * RDP * R - NMF : 1;
-          if (t + 1 < 6 && 2 * RDP * R > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXC, 0);
-          constexpr int NS0 = (RDP - 1) + 2 * RDP;                  // reads a plane's first skip step requests
+          constexpr int EXC = NCR > NMF ? NCR - NMF : 1;
+          if (t + 1 < 6 && NCR > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXC, 0);
+          constexpr int NS0 = (RDP - 1) + R * RDP;                  // reads a plane's first skip steps request (R new rows each)
           constexpr int EXS = NS0 > NMF ? NS0 - NMF : 1;
           if (t + 1 >= 6 && t + 1 < 15 && (t + 1 - 6) % 3 == 0 && NS0 > NMF) __builtin_amdgcn_sched_group_barrier(0x100, EXS, 0);
         }

@@ -397,7 +397,7 @@ def spawn_ranks(args):
     passes its exit code on."""
     import socket
     have = kfd_gpu_count()
-    if have is not None and have < args.gpus:
+    if have is not None and have < args.gpus and not os.environ.get("VX_BENCH_EMULATE_RANKS"):
         print(f"bench.py: --gpus {args.gpus} but the kfd topology of this node lists {have} GPU(s)", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -491,11 +491,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: values_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VX_BENCH_EMULATE_RANKS=1 (tests/test_gpu_dist.py only): the N ranks share the visible GPU(s) and talk over gloo -- a functional run
+    # of the whole N > 1 path (rank spawn, shards, the gather pipeline inside the timed region, max over ranks, the JSON line) on a
+    # 1-GPU box.  Not a measurement: the line carries "emulated": true and its value is meaningless.
+    emulate = bool(os.environ.get("VX_BENCH_EMULATE_RANKS")) and world > 1
+    dev_index = local_rank % torch.cuda.device_count() if emulate else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(3)
@@ -523,6 +531,8 @@ def main():
         dist.barrier()
     if rank == 0:
         line["ranks_joined"] = dist.get_world_size() if world > 1 else 1
+        if emulate:
+            line["emulated"] = True      # ranks sharing a GPU over gloo: a functional check of the N > 1 path, not a measurement
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -115,3 +115,38 @@ def test_nccl_backend_two_gpus_sharded_ensemble_and_gather_pipeline():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs on one node (the build pool's boxes have one); covered under gloo above")
     assert all(_run_world2(_worker_nccl))
+
+
+@pytest.mark.parametrize("extra,world,units,workload", [(["--volumes", "4"], 2, 8.0, "C2"), (["--volumes", "2"], 4, 8.0, "C2"),
+                                                        (["--config", "C3", "--volumes", "2"], 2, 4.0, "C3"),
+                                                        (["--config", "C5", "--volumes", "1"], 2, 2.0, "C5"),
+                                                        (["--config", "C4", "--volumes", "1"], 2, 2.0, "C4")])
+def test_bench_ranks_emulated_on_one_gpu(extra, world, units, workload):
+    """The whole `bench.py --gpus N` path, end to end, on a 1-GPU box (VX_BENCH_EMULATE_RANKS=1: both ranks on the visible GPU, gloo
+    instead of RCCL): the parent that never touches a GPU runtime spawns torch.distributed.run, the ranks shard the volumes, every
+    step's maps are gathered on rank 0 INSIDE the timed region (MapGatherPipeline), region times are the max over ranks, rank 0
+    prints one JSON line with the contract's fields.  The round-5 verdict's gap is a run over xGMI, which no box of the pool can
+    give; this is what CAN be checked before the driver's 8-GPU run: that nothing on that path fails to start, deadlocks or
+    miscounts -- for C2 at two and four ranks, the member-sharded C3 (one RCCL-style sum-reduce), the sliding-window C5 and the 2D C4.  The line
+    says "emulated": its value is not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VX_BENCH_EMULATE_RANKS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)] + extra + ["--steps", "2", "--warmup", "1", "--repeats", "1",
+           "--min-gpu-seconds", "0", "--no-cpu-baseline", "--no-roofline", "--no-latency", "--no-batch64", "--no-storage16"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["ranks_joined"] == world and d["emulated"] is True
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 0 and d["unit"] in ("volumes/s", "images/s") and d["config"]["workload"].startswith(workload)
+    # value = the units of ALL ranks per max-over-ranks time (C2: volumes per GPU x ranks; the other configs likewise)
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - units) < 0.05 * units, (d["value"], d["ms_per_step"], units)
+    if workload == "C2":
+        assert "no_gather" in json.dumps(d)       # the side number that leaves the maps on their ranks
